@@ -1,0 +1,169 @@
+/*
+ * vgpu.h — C ABI of the MI355X-native STARK prover backend for Valida (libvgpu.so).
+ *
+ * This is the drop-in boundary for ONE path of the reference: Machine::prove
+ * (basic/src/lib.rs:147-675) and the traits it drives — StarkConfig (machine/src/config.rs:7-31),
+ * Pcs: UnivariatePcsWithLde (call sites basic/src/lib.rs:199,201,223,225,258,261,594,599,619),
+ * generate_permutation_trace (machine/src/chip.rs:121-130), quotient (machine/src/quotient.rs:18-37)
+ * and the Fiat-Shamir challenger (basic/src/lib.rs:185-263,601-619).  The reference has no FFI of its
+ * own (all Rust generics); every entry point below names the reference item it replaces.  A Rust host
+ * binds it with #[repr(C)] structs — see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all structs are POD.
+ *   - field elements cross the ABI as canonical u32 < p = 2013265921 (BabyBear); extension elements
+ *     (BinomialExtensionField<BabyBear,5>) as 5 consecutive u32; digests as 8 u32.
+ *   - matrices cross as the reference's RowMajorMatrix<Val>: row-major u32[height * width].
+ *   - every function returns VGPU_OK (0) or a negative status; vgpu_last_error() gives the message of
+ *     the last failure on the calling thread.  Nothing unwinds across the ABI.
+ *   - one vgpu_prover per device; a prover is not thread-safe; calls are host-synchronous.
+ *   - the library never falls back to a CPU implementation: without a usable HIP device
+ *     vgpu_prover_create fails with VGPU_ERR_HIP.
+ */
+#ifndef VGPU_H
+#define VGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    VGPU_OK = 0,
+    VGPU_ERR_INVALID_ARG = -1,
+    VGPU_ERR_OOM = -2,
+    VGPU_ERR_HIP = -3,
+    VGPU_ERR_UNSUPPORTED = -4,
+    VGPU_ERR_INTERNAL = -5
+};
+enum { VGPU_HASH_KECCAK256 = 0 /* reference configuration, basic/tests/test_prover.rs:424-431 */ };
+
+const char* vgpu_last_error(void);
+const char* vgpu_version(void);
+
+/* ---- StarkConfig (machine/src/config.rs:7-31; instantiated at basic/tests/test_prover.rs:413-455) ---- */
+typedef struct vgpu_config {
+    int32_t device;                /* HIP device ordinal */
+    uint32_t log_blowup;           /* FriConfig.log_blowup      (test_prover.rs:443) */
+    uint32_t num_queries;          /* FriConfig.num_queries     (:444) */
+    uint32_t pow_bits;             /* FriConfig.proof_of_work_bits (:445) */
+    uint32_t hash_kind;            /* VGPU_HASH_KECCAK256 */
+    uint32_t observe_final_poly;   /* convention switch, default 0 */
+    uint32_t poseidon_rc[480];     /* Poseidon<_,CosetMds<16>,16,5> round constants (test_prover.rs:418-422), canonical */
+} vgpu_config_t;
+
+/* ---- AIR capture: the FFI image of SymbolicAirBuilder (machine/src/symbolic/symbolic_builder.rs:57-154).
+ * A host runs its unchanged Chip::eval against a builder that forwards to these calls; node ids are
+ * opaque u32 handles.  Interactions mirror Interaction/VirtualPairCol (machine/src/chip.rs:76-94). ---- */
+typedef struct vgpu_air vgpu_air_t;
+typedef struct vgpu_vcol_term { uint32_t is_preprocessed; uint32_t column; uint32_t weight; } vgpu_vcol_term_t;
+typedef struct vgpu_vcol { const vgpu_vcol_term_t* terms; uint32_t n_terms; uint32_t constant; } vgpu_vcol_t;
+typedef struct vgpu_interaction {
+    const vgpu_vcol_t* fields; uint32_t n_fields;
+    vgpu_vcol_t count;
+    uint32_t is_global;   /* BusArgument::Global / Local */
+    uint32_t bus_index;
+    uint32_t is_send;     /* InteractionType::*Send / *Receive */
+} vgpu_interaction_t;
+
+int32_t vgpu_air_new(const char* name, uint32_t width, uint32_t preprocessed_width, vgpu_air_t** out);
+void vgpu_air_free(vgpu_air_t* air);
+uint32_t vgpu_air_constant(vgpu_air_t* air, uint32_t canonical);                                  /* SymbolicExpression::Constant */
+uint32_t vgpu_air_variable(vgpu_air_t* air, uint32_t is_preprocessed, uint32_t column, uint32_t is_next); /* ::Variable */
+uint32_t vgpu_air_is_first_row(vgpu_air_t* air);
+uint32_t vgpu_air_is_last_row(vgpu_air_t* air);
+uint32_t vgpu_air_is_transition(vgpu_air_t* air);
+uint32_t vgpu_air_add(vgpu_air_t* air, uint32_t a, uint32_t b);
+uint32_t vgpu_air_sub(vgpu_air_t* air, uint32_t a, uint32_t b);
+uint32_t vgpu_air_mul(vgpu_air_t* air, uint32_t a, uint32_t b);
+uint32_t vgpu_air_neg(vgpu_air_t* air, uint32_t a);
+void vgpu_air_assert_zero(vgpu_air_t* air, uint32_t node);                                       /* AirBuilder::assert_zero */
+int32_t vgpu_air_add_interaction(vgpu_air_t* air, const vgpu_interaction_t* it);                 /* Chip::all_interactions order */
+
+/* ---- Machine: ordered chips (basic/src/lib.rs:151-166) ---- */
+typedef struct vgpu_machine vgpu_machine_t;
+int32_t vgpu_machine_new(vgpu_machine_t** out);
+int32_t vgpu_machine_push_air(vgpu_machine_t* m, const vgpu_air_t* air);  /* compiles the constraint program */
+int32_t vgpu_machine_basic(vgpu_machine_t** out);                         /* the 14-chip BasicMachine from the in-tree chip definitions */
+void vgpu_machine_free(vgpu_machine_t* m);
+uint32_t vgpu_machine_num_chips(const vgpu_machine_t* m);
+/* per-chip facts: width, preprocessed width, #interactions, log_quotient_degree (get_log_quotient_degree,
+ * symbolic_builder.rs:17-30), #constraints, program length, registers */
+int32_t vgpu_machine_chip_info(const vgpu_machine_t* m, uint32_t chip, uint32_t out[8]);
+/* Host interpretation of chip `chip`'s compiled program on one row pair (test hook; no GPU needed).
+ * values out: the asserted constraint values in order; returns their count or a negative status. */
+int32_t vgpu_machine_eval_constraints(const vgpu_machine_t* m, uint32_t chip, const uint32_t* main_local, const uint32_t* main_next,
+                                      const uint32_t* prep_local, const uint32_t* prep_next, uint32_t is_first, uint32_t is_last,
+                                      uint32_t is_transition, uint32_t* out, uint32_t cap);
+
+/* ---- Challenger: DuplexChallenger<Val, Poseidon16, 16> (basic/src/lib.rs:185,200,224,229,...) ---- */
+typedef struct vgpu_challenger vgpu_challenger_t;
+int32_t vgpu_challenger_new(const uint32_t poseidon_rc[480], vgpu_challenger_t** out);
+void vgpu_challenger_free(vgpu_challenger_t* ch);
+void vgpu_challenger_observe(vgpu_challenger_t* ch, const uint32_t* values, uint64_t n);         /* CanObserve */
+void vgpu_challenger_sample(vgpu_challenger_t* ch, uint32_t* out, uint64_t n);                    /* sample / sample_ext_element = 5 samples */
+uint64_t vgpu_challenger_sample_bits(vgpu_challenger_t* ch, uint32_t bits);
+uint32_t vgpu_challenger_grind(vgpu_challenger_t* ch, uint32_t bits);                             /* smallest witness */
+void vgpu_poseidon16_permute(const uint32_t poseidon_rc[480], uint32_t state[16]);
+
+/* ---- Prover (one per device) ---- */
+typedef struct vgpu_prover vgpu_prover_t;
+typedef struct vgpu_trace vgpu_trace_t;   /* a RowMajorMatrix resident in HBM */
+typedef struct vgpu_pdata vgpu_pdata_t;   /* Pcs::ProverData: committed LDEs + Merkle tree, in HBM */
+typedef struct vgpu_proof vgpu_proof_t;
+
+int32_t vgpu_prover_create(const vgpu_config_t* cfg, const vgpu_machine_t* machine, vgpu_prover_t** out);
+void vgpu_prover_destroy(vgpu_prover_t* p);
+/* bytes currently held / peak in the HBM pool */
+void vgpu_prover_memory(const vgpu_prover_t* p, uint64_t* live_bytes, uint64_t* peak_bytes);
+
+/* H2D of a host RowMajorMatrix (the reference passes these by value, basic/src/lib.rs:223) */
+int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t height, uint64_t width, vgpu_trace_t** out);
+void vgpu_trace_free(vgpu_trace_t* t);
+
+/* pcs.commit_batches / commit_shifted_batches (basic/src/lib.rs:199,223,258,599): coset_shifts may be NULL */
+int32_t vgpu_commit_batches(vgpu_prover_t* p, const vgpu_trace_t* const* mats, uint32_t n_mats, const uint32_t* coset_shifts,
+                            uint32_t root[8], vgpu_pdata_t** out);
+/* pcs.get_ldes (basic/src/lib.rs:201,225,261): copy LDE `idx` back as row-major canonical, rows in
+ * COMMITTED (bit-reversed) order; out must hold (height << log_blowup) * width words */
+int32_t vgpu_pdata_lde(vgpu_prover_t* p, const vgpu_pdata_t* pd, uint32_t idx, uint32_t* out, uint64_t cap_words);
+void vgpu_pdata_free(vgpu_pdata_t* pd);
+
+/* generate_permutation_trace (machine/src/chip.rs:121-208) for chip `chip` of the prover's machine.
+ * challenges: 3 extension elements (15 words).  out: height x 5(M+1) row-major (flatten_to_base),
+ * cumulative_sum: 5 words. */
+int32_t vgpu_perm_trace(vgpu_prover_t* p, uint32_t chip, const vgpu_trace_t* main, const vgpu_trace_t* preprocessed_or_null,
+                        const uint32_t challenges[15], uint32_t* out, uint64_t cap_words, uint32_t cumulative_sum[5]);
+
+/* FRI fold_even_odd of an Ext5 vector (n x 5 words, bit-reversed domain order) — App. B10 */
+int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uint32_t beta[5], uint32_t* out);
+
+/* Machine::prove (basic/src/lib.rs:147-675).  main[i] = trace of chip i; preprocessed traces are given
+ * with their chip indices in chip order (BasicMachine: program, range). */
+int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
+                   const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t debug_flags, vgpu_proof_t** out);
+uint64_t vgpu_proof_len(const vgpu_proof_t* pr);            /* u32 words of the flat "VPF1" encoding */
+const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr);
+/* 11 doubles, ms: ingest, commit_main, perm, commit_perm, quotient, commit_quotient, open_values, open_reduce, fri, queries, total */
+void vgpu_proof_phase_ms(const vgpu_proof_t* pr, double out[11]);
+/* transcript probe: 8 (preprocessed root) + 15 (perm challenges) + 5 (alpha) + 5 (zeta) words */
+void vgpu_proof_transcript(const vgpu_proof_t* pr, uint32_t out[33]);
+/* with debug_flags & 1: per-chip intermediate matrices, row-major canonical, natural row order */
+int64_t vgpu_proof_debug_perm_trace(const vgpu_proof_t* pr, uint32_t chip, uint32_t* out, uint64_t cap_words);
+int64_t vgpu_proof_debug_quotient(const vgpu_proof_t* pr, uint32_t chip, uint32_t* out, uint64_t cap_words);
+void vgpu_proof_free(vgpu_proof_t* pr);
+
+/* ---- synthetic workloads (bench inputs; upstream of the hot path) ---- */
+typedef struct vgpu_workload vgpu_workload_t;
+/* fib_program (basic/tests/test_prover.rs:35-188) with loop bound n, fp = 0x1000, run to STOP, traces generated */
+int32_t vgpu_workload_fib(uint32_t n, vgpu_workload_t** out);
+void vgpu_workload_free(vgpu_workload_t* w);
+/* stats: [cycles, cpu ops, memory ops, add ops, result word (u32 at fp+4), program length, padded cpu height] */
+void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]);
+int32_t vgpu_workload_main_trace(const vgpu_workload_t* w, uint32_t chip, const uint32_t** data, uint64_t* height, uint64_t* width);
+/* k = 0: program ROM (chip 1), k = 1: range table (chip 12) */
+int32_t vgpu_workload_preprocessed(const vgpu_workload_t* w, uint32_t k, uint32_t* chip, const uint32_t** data, uint64_t* height, uint64_t* width);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGPU_H */

@@ -1,0 +1,346 @@
+"""valida_amd — MI355X-native STARK prover backend for the Valida zkVM (hot path: Machine::prove).
+
+This package is a thin ctypes mirror of the C ABI in include/vgpu.h (libvgpu.so: hand-written
+HIP/gfx950 kernels + C++ host prover).  Names follow the reference's own surface for this path:
+`Machine.prove`, `Pcs.commit_batches` / `get_ldes`, `generate_permutation_trace`, `Challenger`.
+There is NO CPU fallback: constructing a `Prover` without a HIP device raises `VgpuError`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+P = 2013265921
+NUM_CHIPS = 14
+CHIP_NAMES = ["cpu", "program", "mem", "add", "sub", "mul", "div", "shift", "lt", "com", "bitwise", "output", "range", "static_data"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvgpu.so")
+
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class VgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class VgpuConfig(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int32),
+        ("log_blowup", ctypes.c_uint32),
+        ("num_queries", ctypes.c_uint32),
+        ("pow_bits", ctypes.c_uint32),
+        ("hash_kind", ctypes.c_uint32),
+        ("observe_final_poly", ctypes.c_uint32),
+        ("poseidon_rc", ctypes.c_uint32 * 480),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libvgpu.so (built in-tree by valida_amd/build.py).  Fails loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError("libvgpu.so is not built: run `python valida_amd/build.py` (or __graft_entry__.build())")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.vgpu_last_error.restype = ctypes.c_char_p
+        L.vgpu_version.restype = ctypes.c_char_p
+        L.vgpu_proof_len.restype = ctypes.c_uint64
+        L.vgpu_proof_words.restype = c_u32p
+        L.vgpu_challenger_sample_bits.restype = ctypes.c_uint64
+        L.vgpu_proof_debug_perm_trace.restype = ctypes.c_int64
+        L.vgpu_proof_debug_quotient.restype = ctypes.c_int64
+        for name in ("vgpu_air_constant", "vgpu_air_variable", "vgpu_air_is_first_row", "vgpu_air_is_last_row", "vgpu_air_is_transition", "vgpu_air_add",
+                     "vgpu_air_sub", "vgpu_air_mul", "vgpu_air_neg", "vgpu_machine_num_chips", "vgpu_challenger_grind"):
+            getattr(L, name).restype = ctypes.c_uint32
+        _lib = L
+    return _lib
+
+
+def _check(code):
+    if code != 0:
+        raise VgpuError(code, lib().vgpu_last_error().decode())
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(c_u32p)
+
+
+def poseidon_round_constants(seed=0x56414C494441):
+    """480 Poseidon-16 round constants from SplitMix64(seed), rejection-sampled 31-bit values < p.
+
+    The reference draws them from thread_rng (basic/tests/test_prover.rs:422); they are configuration
+    input here — the same array must be given to the prover and the verifier.
+    """
+    out = []
+    x = seed & 0xFFFFFFFFFFFFFFFF
+    while len(out) < 480:
+        x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        v = (z >> 33) & 0x7FFFFFFF
+        if v < P:
+            out.append(v)
+    return np.array(out, dtype=np.uint32)
+
+
+class Workload:
+    """Synthetic workload: fib_program(n) run on the BasicMachine, all chip traces generated (host)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        st = (ctypes.c_uint64 * 8)()
+        lib().vgpu_workload_stats(self._h, st)
+        self.cycles, self.cpu_ops, self.mem_ops, self.add_ops, self.result, self.program_len, self.cpu_height = [int(v) for v in st[:7]]
+
+    @classmethod
+    def fib(cls, n):
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_workload_fib(ctypes.c_uint32(n), ctypes.byref(h)))
+        return cls(h)
+
+    def main_trace(self, chip):
+        data, h, w = c_u32p(), ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib().vgpu_workload_main_trace(self._h, ctypes.c_uint32(chip), ctypes.byref(data), ctypes.byref(h), ctypes.byref(w)))
+        return np.ctypeslib.as_array(data, shape=(h.value, w.value))
+
+    def main_traces(self):
+        return [self.main_trace(i) for i in range(NUM_CHIPS)]
+
+    def preprocessed(self):
+        """[(chip index, matrix)] in chip order: program ROM, range table."""
+        out = []
+        for k in range(2):
+            chip, data, h, w = ctypes.c_uint32(), c_u32p(), ctypes.c_uint64(), ctypes.c_uint64()
+            _check(lib().vgpu_workload_preprocessed(self._h, ctypes.c_uint32(k), ctypes.byref(chip), ctypes.byref(data), ctypes.byref(h), ctypes.byref(w)))
+            out.append((chip.value, np.ctypeslib.as_array(data, shape=(h.value, w.value))))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vgpu_workload_free(self._h)
+            self._h = None
+
+
+class Machine:
+    """Ordered chips with compiled constraint programs (basic/src/lib.rs:151-166)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def basic(cls):
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_machine_basic(ctypes.byref(h)))
+        return cls(h)
+
+    @property
+    def num_chips(self):
+        return int(lib().vgpu_machine_num_chips(self._h))
+
+    def chip_info(self, chip):
+        out = (ctypes.c_uint32 * 8)()
+        _check(lib().vgpu_machine_chip_info(self._h, ctypes.c_uint32(chip), out))
+        keys = ["width", "preprocessed_width", "interactions", "log_quotient_degree", "constraints", "instructions", "registers", "max_degree"]
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def eval_constraints(self, chip, main_local, main_next, prep_local=None, prep_next=None, is_first=0, is_last=0, is_transition=1):
+        info = self.chip_info(chip)
+        pl = np.zeros(max(1, info["preprocessed_width"]), dtype=np.uint32) if prep_local is None else prep_local
+        pn = np.zeros(max(1, info["preprocessed_width"]), dtype=np.uint32) if prep_next is None else prep_next
+        a, ap = _u32(main_local)
+        b, bp = _u32(main_next)
+        c, cp = _u32(pl)
+        d, dp = _u32(pn)
+        out = np.zeros(max(1, info["constraints"]), dtype=np.uint32)
+        n = lib().vgpu_machine_eval_constraints(self._h, ctypes.c_uint32(chip), ap, bp, cp, dp, ctypes.c_uint32(is_first), ctypes.c_uint32(is_last),
+                                                ctypes.c_uint32(is_transition), out.ctypes.data_as(c_u32p), ctypes.c_uint32(out.size))
+        if n < 0:
+            _check(n)
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vgpu_machine_free(self._h)
+            self._h = None
+
+
+class Challenger:
+    """DuplexChallenger<BabyBear, Poseidon16, 16> (host)."""
+
+    def __init__(self, rc):
+        self._rc, rcp = _u32(rc)
+        self._h = ctypes.c_void_p()
+        _check(lib().vgpu_challenger_new(rcp, ctypes.byref(self._h)))
+
+    def observe(self, values):
+        v, vp = _u32(values)
+        lib().vgpu_challenger_observe(self._h, vp, ctypes.c_uint64(v.size))
+
+    def sample(self, n=1):
+        out = np.zeros(n, dtype=np.uint32)
+        lib().vgpu_challenger_sample(self._h, out.ctypes.data_as(c_u32p), ctypes.c_uint64(n))
+        return out
+
+    def sample_bits(self, bits):
+        return int(lib().vgpu_challenger_sample_bits(self._h, ctypes.c_uint32(bits)))
+
+    def grind(self, bits):
+        return int(lib().vgpu_challenger_grind(self._h, ctypes.c_uint32(bits)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vgpu_challenger_free(self._h)
+            self._h = None
+
+
+def poseidon16_permute(rc, state):
+    r, rp = _u32(rc)
+    s = np.array(state, dtype=np.uint32)
+    lib().vgpu_poseidon16_permute(rp, s.ctypes.data_as(c_u32p))
+    return s
+
+
+class DeviceTrace:
+    def __init__(self, prover, handle, shape):
+        self._prover, self._h, self.shape = prover, handle, shape
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vgpu_trace_free(self._h)
+            self._h = None
+
+
+class ProverData:
+    """Pcs::ProverData — committed LDEs + Merkle tree, resident in HBM."""
+
+    def __init__(self, prover, handle, root, shapes):
+        self._prover, self._h, self.root, self._shapes = prover, handle, root, shapes
+
+    def lde(self, idx):
+        """get_ldes()[idx] in committed (bit-reversed) row order, canonical values."""
+        h, w = self._shapes[idx]
+        H = h << self._prover.log_blowup
+        out = np.zeros((H, w), dtype=np.uint32)
+        _check(lib().vgpu_pdata_lde(self._prover._h, self._h, ctypes.c_uint32(idx), out.ctypes.data_as(c_u32p), ctypes.c_uint64(out.size)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vgpu_pdata_free(self._h)
+            self._h = None
+
+
+class Proof:
+    def __init__(self, handle):
+        self._h = handle
+        n = int(lib().vgpu_proof_len(handle))
+        self.words = np.ctypeslib.as_array(lib().vgpu_proof_words(handle), shape=(n,)).copy()
+        ms = (ctypes.c_double * 11)()
+        lib().vgpu_proof_phase_ms(handle, ms)
+        keys = ["ingest", "commit_main", "perm", "commit_perm", "quotient", "commit_quotient", "open_values", "open_reduce", "fri", "queries", "total"]
+        self.phase_ms = dict(zip(keys, [float(v) for v in ms]))
+        t = (ctypes.c_uint32 * 33)()
+        lib().vgpu_proof_transcript(handle, t)
+        self.transcript = np.array(t, dtype=np.uint32)
+
+    def bytes(self):
+        return self.words.tobytes()
+
+    def _dbg(self, fn, chip):
+        n = fn(self._h, ctypes.c_uint32(chip), None, ctypes.c_uint64(0))
+        if n < 0:
+            raise IndexError(chip)
+        out = np.zeros(n, dtype=np.uint32)
+        fn(self._h, ctypes.c_uint32(chip), out.ctypes.data_as(c_u32p), ctypes.c_uint64(n))
+        return out
+
+    def debug_perm_trace(self, chip):
+        return self._dbg(lib().vgpu_proof_debug_perm_trace, chip)
+
+    def debug_quotient(self, chip):
+        return self._dbg(lib().vgpu_proof_debug_quotient, chip)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vgpu_proof_free(self._h)
+            self._h = None
+
+
+class Prover:
+    """One MI355X: StarkConfig + Machine -> prove().  Mirrors machine.prove(&config)."""
+
+    def __init__(self, machine, rc, device=0, log_blowup=1, num_queries=40, pow_bits=8, observe_final_poly=False):
+        cfg = VgpuConfig()
+        cfg.device, cfg.log_blowup, cfg.num_queries, cfg.pow_bits = device, log_blowup, num_queries, pow_bits
+        cfg.hash_kind, cfg.observe_final_poly = 0, int(observe_final_poly)
+        rc = np.ascontiguousarray(rc, dtype=np.uint32)
+        assert rc.size == 480
+        ctypes.memmove(cfg.poseidon_rc, rc.ctypes.data, 480 * 4)
+        self.machine, self.rc, self.log_blowup, self.num_queries, self.pow_bits = machine, rc, log_blowup, num_queries, pow_bits
+        self._h = ctypes.c_void_p()
+        _check(lib().vgpu_prover_create(ctypes.byref(cfg), machine._h, ctypes.byref(self._h)))
+
+    def upload(self, matrix):
+        m = np.ascontiguousarray(matrix, dtype=np.uint32)
+        assert m.ndim == 2
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_trace_upload(self._h, m.ctypes.data_as(c_u32p), ctypes.c_uint64(m.shape[0]), ctypes.c_uint64(m.shape[1]), ctypes.byref(h)))
+        return DeviceTrace(self, h, m.shape)
+
+    def commit_batches(self, traces, coset_shifts=None):
+        arr = (ctypes.c_void_p * len(traces))(*[t._h for t in traces])
+        root = np.zeros(8, dtype=np.uint32)
+        sh = None
+        if coset_shifts is not None:
+            shv, sh = _u32(coset_shifts)
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_commit_batches(self._h, arr, ctypes.c_uint32(len(traces)), sh, root.ctypes.data_as(c_u32p), ctypes.byref(h)))
+        return ProverData(self, h, root, [t.shape for t in traces])
+
+    def generate_permutation_trace(self, chip, main, challenges, preprocessed=None):
+        info = self.machine.chip_info(chip)
+        n = main.shape[0]
+        out = np.zeros((n, 5 * (info["interactions"] + 1)), dtype=np.uint32)
+        ch, chp = _u32(challenges)
+        cs = np.zeros(5, dtype=np.uint32)
+        _check(lib().vgpu_perm_trace(self._h, ctypes.c_uint32(chip), main._h, preprocessed._h if preprocessed is not None else None, chp,
+                                     out.ctypes.data_as(c_u32p), ctypes.c_uint64(out.size), cs.ctypes.data_as(c_u32p)))
+        return out, cs
+
+    def fri_fold(self, f, beta):
+        f = np.ascontiguousarray(f, dtype=np.uint32)
+        n = f.shape[0]
+        b, bp = _u32(beta)
+        out = np.zeros((n // 2, 5), dtype=np.uint32)
+        _check(lib().vgpu_fri_fold(self._h, f.ctypes.data_as(c_u32p), ctypes.c_uint64(n), bp, out.ctypes.data_as(c_u32p)))
+        return out
+
+    def prove(self, main, preprocessed, debug=False):
+        """main: list of DeviceTrace (chip order); preprocessed: list of (chip index, DeviceTrace)."""
+        arr = (ctypes.c_void_p * len(main))(*[t._h for t in main])
+        chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
+        parr = (ctypes.c_void_p * max(1, len(preprocessed)))(*[t._h for _, t in preprocessed])
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_prove(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)), ctypes.c_uint32(1 if debug else 0),
+                                ctypes.byref(h)))
+        return Proof(h)
+
+    def memory(self):
+        live, peak = ctypes.c_uint64(), ctypes.c_uint64()
+        lib().vgpu_prover_memory(self._h, ctypes.byref(live), ctypes.byref(peak))
+        return live.value, peak.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vgpu_prover_destroy(self._h)
+            self._h = None

@@ -1,0 +1,333 @@
+// extern "C" surface of libvgpu.so — see include/vgpu.h for the contract and the reference item each
+// entry point replaces.
+#include "../../include/vgpu.h"
+#include <cstring>
+#include <memory>
+#include <string>
+#include "host/prover.hpp"
+#include "workload/basic_vm.hpp"
+
+using namespace vhost;
+
+static thread_local std::string g_err;
+static int32_t fail(int32_t code, const std::string& msg) { g_err = msg; return code; }
+#define VG_TRY(...)                                                         \
+    try { __VA_ARGS__; return VGPU_OK; }                                           \
+    catch (const std::invalid_argument& e) { return fail(VGPU_ERR_INVALID_ARG, e.what()); } \
+    catch (const std::bad_alloc& e) { return fail(VGPU_ERR_OOM, e.what()); }                \
+    catch (const std::exception& e) {                                       \
+        std::string m = e.what();                                           \
+        return fail(m.find("hip") != std::string::npos ? VGPU_ERR_HIP : VGPU_ERR_INTERNAL, m); \
+    }
+
+struct vgpu_air { std::string name; vair::Dag dag; std::vector<vair::Interaction> interactions; };
+struct vgpu_machine { MachineDesc desc; };
+struct vgpu_challenger { std::unique_ptr<Poseidon16> perm; std::unique_ptr<Challenger> ch; };
+struct vgpu_prover { std::unique_ptr<Prover> p; };
+struct vgpu_trace { std::unique_ptr<DeviceTrace> t; };
+struct vgpu_pdata { std::unique_ptr<ProverData> pd; };
+struct vgpu_proof { std::vector<uint32_t> words; PhaseTimes tm; ProveDebugOut dbg; };
+struct vgpu_workload {
+    std::unique_ptr<vwork::BasicVm> vm;
+    std::vector<vwork::RowMajor> main;
+    vwork::RowMajor prep_program, prep_range;
+    uint64_t result = 0;
+};
+
+extern "C" {
+
+const char* vgpu_last_error(void) { return g_err.c_str(); }
+const char* vgpu_version(void) { return "valida_amd 0.1 (gfx950)"; }
+
+// ---- AIR capture
+int32_t vgpu_air_new(const char* name, uint32_t width, uint32_t preprocessed_width, vgpu_air_t** out) {
+    VG_TRY({
+        if (!out) throw std::invalid_argument("null out");
+        auto* a = new vgpu_air();
+        a->name = name ? name : "";
+        a->dag.width = (int)width; a->dag.prep_width = (int)preprocessed_width;
+        *out = a;
+    })
+}
+void vgpu_air_free(vgpu_air_t* air) { delete air; }
+uint32_t vgpu_air_constant(vgpu_air_t* a, uint32_t canonical) { return a->dag.constant(canonical); }
+uint32_t vgpu_air_variable(vgpu_air_t* a, uint32_t is_prep, uint32_t column, uint32_t is_next) { return a->dag.var(is_prep != 0, (int)column, is_next != 0); }
+uint32_t vgpu_air_is_first_row(vgpu_air_t* a) { return a->dag.selector(vair::N_FIRST); }
+uint32_t vgpu_air_is_last_row(vgpu_air_t* a) { return a->dag.selector(vair::N_LAST); }
+uint32_t vgpu_air_is_transition(vgpu_air_t* a) { return a->dag.selector(vair::N_TRANS); }
+uint32_t vgpu_air_add(vgpu_air_t* a, uint32_t x, uint32_t y) { return a->dag.add(x, y); }
+uint32_t vgpu_air_sub(vgpu_air_t* a, uint32_t x, uint32_t y) { return a->dag.sub(x, y); }
+uint32_t vgpu_air_mul(vgpu_air_t* a, uint32_t x, uint32_t y) { return a->dag.mul(x, y); }
+uint32_t vgpu_air_neg(vgpu_air_t* a, uint32_t x) { return a->dag.neg(x); }
+void vgpu_air_assert_zero(vgpu_air_t* a, uint32_t node) { a->dag.constraints.push_back(node); }
+static vair::VirtualCol to_vcol(const vgpu_vcol_t& v) {
+    vair::VirtualCol c;
+    c.constant = v.constant;
+    for (uint32_t i = 0; i < v.n_terms; i++) c.terms.push_back({v.terms[i].is_preprocessed != 0, (int)v.terms[i].column, v.terms[i].weight});
+    return c;
+}
+int32_t vgpu_air_add_interaction(vgpu_air_t* a, const vgpu_interaction_t* it) {
+    VG_TRY({
+        if (!a || !it) throw std::invalid_argument("null argument");
+        vair::Interaction x;
+        for (uint32_t i = 0; i < it->n_fields; i++) x.fields.push_back(to_vcol(it->fields[i]));
+        x.count = to_vcol(it->count);
+        x.bus_kind = it->is_global ? vair::BusKind::Global : vair::BusKind::Local;
+        x.bus_index = (int)it->bus_index;
+        x.type = it->is_global ? (it->is_send ? vair::InteractionType::GlobalSend : vair::InteractionType::GlobalReceive)
+                               : (it->is_send ? vair::InteractionType::LocalSend : vair::InteractionType::LocalReceive);
+        a->interactions.push_back(std::move(x));
+    })
+}
+
+// ---- machine
+int32_t vgpu_machine_new(vgpu_machine_t** out) { VG_TRY({ if (!out) throw std::invalid_argument("null out"); *out = new vgpu_machine(); }) }
+int32_t vgpu_machine_push_air(vgpu_machine_t* m, const vgpu_air_t* air) {
+    VG_TRY({
+        if (!m || !air) throw std::invalid_argument("null argument");
+        m->desc.airs.push_back(MachineDesc::make_air_from_dag(air->name, air->dag, air->interactions));
+    })
+}
+int32_t vgpu_machine_basic(vgpu_machine_t** out) {
+    VG_TRY({ if (!out) throw std::invalid_argument("null out"); auto* m = new vgpu_machine(); m->desc = MachineDesc::basic(); *out = m; })
+}
+void vgpu_machine_free(vgpu_machine_t* m) { delete m; }
+uint32_t vgpu_machine_num_chips(const vgpu_machine_t* m) { return (uint32_t)m->desc.airs.size(); }
+int32_t vgpu_machine_chip_info(const vgpu_machine_t* m, uint32_t chip, uint32_t out[8]) {
+    VG_TRY({
+        if (!m || chip >= m->desc.airs.size()) throw std::invalid_argument("bad chip index");
+        const AirDesc& a = m->desc.airs[chip];
+        out[0] = a.width; out[1] = a.prep_width; out[2] = (uint32_t)a.interactions.size(); out[3] = a.log_quotient_degree;
+        out[4] = a.program.num_asserts; out[5] = (uint32_t)a.program.instrs.size(); out[6] = a.program.num_regs; out[7] = (uint32_t)a.max_constraint_degree;
+    })
+}
+int32_t vgpu_machine_eval_constraints(const vgpu_machine_t* m, uint32_t chip, const uint32_t* main_local, const uint32_t* main_next,
+                                      const uint32_t* prep_local, const uint32_t* prep_next, uint32_t is_first, uint32_t is_last,
+                                      uint32_t is_transition, uint32_t* out, uint32_t cap) {
+    try {
+        if (!m || chip >= m->desc.airs.size()) throw std::invalid_argument("bad chip index");
+        const AirDesc& a = m->desc.airs[chip];
+        std::vector<Fp> ml(a.width), mn(a.width), pl(a.prep_width), pn(a.prep_width);
+        for (uint32_t i = 0; i < a.width; i++) { ml[i] = Fp::from_canonical(main_local[i]); mn[i] = Fp::from_canonical(main_next[i]); }
+        for (uint32_t i = 0; i < a.prep_width; i++) { pl[i] = Fp::from_canonical(prep_local[i]); pn[i] = Fp::from_canonical(prep_next[i]); }
+        vair::HostEval ev{ml.data(), mn.data(), pl.data(), pn.data(), Fp::from_canonical(is_first), Fp::from_canonical(is_last), Fp::from_canonical(is_transition)};
+        auto vals = ev.run(a.program);
+        if (vals.size() > cap) throw std::invalid_argument("output buffer too small");
+        for (size_t i = 0; i < vals.size(); i++) out[i] = vals[i].canonical();
+        return (int32_t)vals.size();
+    } catch (const std::exception& e) { return fail(VGPU_ERR_INVALID_ARG, e.what()); }
+}
+
+// ---- challenger
+int32_t vgpu_challenger_new(const uint32_t rc[480], vgpu_challenger_t** out) {
+    VG_TRY({
+        if (!rc || !out) throw std::invalid_argument("null argument");
+        auto* c = new vgpu_challenger();
+        c->perm.reset(new Poseidon16(rc));
+        c->ch.reset(new Challenger(c->perm.get()));
+        *out = c;
+    })
+}
+void vgpu_challenger_free(vgpu_challenger_t* ch) { delete ch; }
+void vgpu_challenger_observe(vgpu_challenger_t* ch, const uint32_t* v, uint64_t n) { for (uint64_t i = 0; i < n; i++) ch->ch->observe_canonical(v[i]); }
+void vgpu_challenger_sample(vgpu_challenger_t* ch, uint32_t* out, uint64_t n) { for (uint64_t i = 0; i < n; i++) out[i] = ch->ch->sample().canonical(); }
+uint64_t vgpu_challenger_sample_bits(vgpu_challenger_t* ch, uint32_t bits) { return ch->ch->sample_bits(bits); }
+uint32_t vgpu_challenger_grind(vgpu_challenger_t* ch, uint32_t bits) { return ch->ch->grind(bits); }
+void vgpu_poseidon16_permute(const uint32_t rc[480], uint32_t state[16]) {
+    Poseidon16 p(rc);
+    Fp st[16];
+    for (int i = 0; i < 16; i++) st[i] = Fp::from_canonical(state[i]);
+    p.permute(st);
+    for (int i = 0; i < 16; i++) state[i] = st[i].canonical();
+}
+
+// ---- prover
+int32_t vgpu_prover_create(const vgpu_config_t* cfg, const vgpu_machine_t* machine, vgpu_prover_t** out) {
+    VG_TRY({
+        if (!cfg || !machine || !out) throw std::invalid_argument("null argument");
+        if (cfg->hash_kind != VGPU_HASH_KECCAK256) { g_err = "only VGPU_HASH_KECCAK256 is implemented"; return VGPU_ERR_UNSUPPORTED; }
+        if (cfg->log_blowup < 1 || cfg->log_blowup > 4) throw std::invalid_argument("log_blowup must be in 1..4");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= cfg->device) throw std::runtime_error("hip: no usable device (the product path has no CPU fallback)");
+        FriParams fp;
+        fp.log_blowup = cfg->log_blowup; fp.num_queries = cfg->num_queries; fp.pow_bits = cfg->pow_bits; fp.observe_final_poly = cfg->observe_final_poly != 0;
+        auto* p = new vgpu_prover();
+        p->p.reset(new Prover(cfg->device, machine->desc, cfg->poseidon_rc, fp));
+        *out = p;
+    })
+}
+void vgpu_prover_destroy(vgpu_prover_t* p) { delete p; }
+void vgpu_prover_memory(const vgpu_prover_t* p, uint64_t* live, uint64_t* peak) {
+    auto& c = const_cast<vgpu_prover_t*>(p)->p->ctx();
+    if (live) *live = c.live;
+    if (peak) *peak = c.peak_live;
+}
+int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t height, uint64_t width, vgpu_trace_t** out) {
+    VG_TRY({
+        if (!p || !data || !out || !height || !width) throw std::invalid_argument("bad trace");
+        auto* t = new vgpu_trace();
+        t->t = p->p->upload_trace(HostMatrix{data, height, width});
+        *out = t;
+    })
+}
+void vgpu_trace_free(vgpu_trace_t* t) { delete t; }
+
+static DMat ingest(DeviceCtx& c, const DeviceTrace& t) {
+    if (t.height & (t.height - 1)) throw std::invalid_argument("matrix height must be a power of two");
+    DMat m(&c, t.height, t.width);
+    vk::launch_ingest(c.stream, t.raw.data, m.view(), false);
+    return m;
+}
+
+int32_t vgpu_commit_batches(vgpu_prover_t* p, const vgpu_trace_t* const* mats, uint32_t n_mats, const uint32_t* coset_shifts, uint32_t root[8],
+                            vgpu_pdata_t** out) {
+    VG_TRY({
+        if (!p || !mats || !n_mats || !root || !out) throw std::invalid_argument("null argument");
+        DeviceCtx& c = p->p->ctx();
+        std::vector<DMat> nat;
+        for (uint32_t i = 0; i < n_mats; i++) nat.push_back(ingest(c, *mats[i]->t));
+        std::vector<CommitInput> in;
+        for (auto& m : nat) in.push_back({&m, false, false});
+        std::vector<Fp> shifts;
+        if (coset_shifts) for (uint32_t i = 0; i < n_mats; i++) shifts.push_back(Fp::from_canonical(coset_shifts[i]));
+        auto* pd = new vgpu_pdata();
+        pd->pd = commit_batches(&c, in, coset_shifts ? &shifts : nullptr, p->p->fri());
+        memcpy(root, pd->pd->tree.root, 32);
+        *out = pd;
+    })
+}
+int32_t vgpu_pdata_lde(vgpu_prover_t* p, const vgpu_pdata_t* pd, uint32_t idx, uint32_t* out, uint64_t cap_words) {
+    VG_TRY({
+        if (!p || !pd || idx >= pd->pd->ldes.size() || !out) throw std::invalid_argument("bad argument");
+        DeviceCtx& c = p->p->ctx();
+        const DMat& l = pd->pd->ldes[idx];
+        if (cap_words < l.height * l.width) throw std::invalid_argument("output buffer too small");
+        DBuf tmp(&c, (size_t)(l.height * l.width));
+        vk::launch_export_rows(c.stream, l.view(), 0, l.height, tmp.data);
+        c.download(out, tmp.data, l.height * l.width * 4);
+    })
+}
+void vgpu_pdata_free(vgpu_pdata_t* pd) { delete pd; }
+
+int32_t vgpu_perm_trace(vgpu_prover_t* p, uint32_t chip, const vgpu_trace_t* main, const vgpu_trace_t* prep, const uint32_t challenges[15], uint32_t* out,
+                        uint64_t cap_words, uint32_t cumulative_sum[5]) {
+    VG_TRY({
+        if (!p || !main || !challenges || !out) throw std::invalid_argument("null argument");
+        const MachineDesc& md = p->p->machine();
+        if (chip >= md.airs.size()) throw std::invalid_argument("bad chip index");
+        const AirDesc& air = md.airs[chip];
+        if (main->t->width != air.width) throw std::invalid_argument("trace width mismatch");
+        DeviceCtx& c = p->p->ctx();
+        DMat m = ingest(c, *main->t);
+        DMat pm;
+        if (prep) pm = ingest(c, *prep->t);
+        Ext5 rnd[3];
+        for (int i = 0; i < 3; i++) for (int k = 0; k < 5; k++) rnd[i].c[k] = Fp::from_canonical(challenges[5 * i + k]);
+        uint32_t M = (uint32_t)air.interactions.size();
+        std::vector<uint32_t> pool;
+        size_t maxf = 0;
+        for (auto& it : air.interactions) { put_ext(pool, (it.is_local() ? rnd[0] : rnd[1]).pow((uint64_t)it.bus_index + 1)); maxf = std::max(maxf, it.fields.size()); }
+        Ext5 bp = Ext5::one();
+        for (size_t j = 0; j < maxf; j++) { put_ext(pool, bp); bp *= rnd[2]; }
+        pool.push_back(0);
+        DBuf pool_dev(&c, pool), iw(&c, air.interaction_words), scratch(&c, (size_t)vk::perm_scratch_words(m.height));
+        DMat perm(&c, m.height, 5 * (M + 1));
+        if (cap_words < perm.height * perm.width) throw std::invalid_argument("output buffer too small");
+        vk::launch_perm_trace(c.stream, m.view(), prep ? pm.view() : vk::DMatView{nullptr, 0, 0, 0}, iw.data, pool_dev.data, M, perm.view(), scratch.data);
+        DBuf tmp(&c, (size_t)(perm.height * perm.width));
+        vk::launch_export_rows(c.stream, perm.view(), 0, perm.height, tmp.data);
+        c.check_launch("perm trace");
+        c.download(out, tmp.data, perm.height * perm.width * 4);
+        if (cumulative_sum) for (int k = 0; k < 5; k++) cumulative_sum[k] = out[(perm.height - 1) * perm.width + 5 * M + k];
+    })
+}
+
+int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uint32_t beta[5], uint32_t* out) {
+    VG_TRY({
+        if (!p || !f || !beta || !out || n < 4 || (n & (n - 1))) throw std::invalid_argument("fri_fold: n must be a power of two >= 4");
+        DeviceCtx& c = p->p->ctx();
+        uint64_t half = n / 2, q = half / 2;
+        std::vector<uint32_t> in(5 * n), bw(8, 0);
+        for (uint64_t i = 0; i < n; i++) for (int k = 0; k < 5; k++) in[((i & 1) * 5 + k) * half + (i >> 1)] = Fp::from_canonical(f[5 * i + k]).v;
+        for (int k = 0; k < 5; k++) bw[k] = Fp::from_canonical(beta[k]).v;
+        DBuf din(&c, in), db(&c, bw), dout(&c, (size_t)(5 * half));
+        vk::launch_fri_fold(c.stream, din.data, n, db.data, nullptr, c.tables, dout.data);
+        c.check_launch("fri fold");
+        std::vector<uint32_t> o(5 * half);
+        c.download(o.data(), dout.data, o.size() * 4);
+        for (uint64_t i = 0; i < half; i++) for (int k = 0; k < 5; k++) out[5 * i + k] = Fp::raw(o[((i & 1) * 5 + k) * q + (i >> 1)]).canonical();
+    })
+}
+
+int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips, const vgpu_trace_t* const* prep,
+                   uint32_t n_prep, uint32_t debug_flags, vgpu_proof_t** out) {
+    VG_TRY({
+        if (!p || !main || !out) throw std::invalid_argument("null argument");
+        std::vector<const DeviceTrace*> m;
+        for (uint32_t i = 0; i < n_main; i++) m.push_back(main[i]->t.get());
+        std::vector<std::pair<int, const DeviceTrace*>> pr;
+        for (uint32_t i = 0; i < n_prep; i++) pr.push_back({(int)prep_chips[i], prep[i]->t.get()});
+        auto proof = std::make_unique<vgpu_proof>();
+        proof->dbg.keep_matrices = (debug_flags & 1) != 0;
+        proof->words = p->p->prove(m, pr, &proof->tm, &proof->dbg);
+        *out = proof.release();
+    })
+}
+uint64_t vgpu_proof_len(const vgpu_proof_t* pr) { return pr->words.size(); }
+const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr) { return pr->words.data(); }
+void vgpu_proof_phase_ms(const vgpu_proof_t* pr, double out[11]) {
+    const PhaseTimes& t = pr->tm;
+    double v[11] = {t.ingest, t.commit_main, t.perm, t.commit_perm, t.quotient, t.commit_quotient, t.open_values, t.open_reduce, t.fri, t.queries, t.total};
+    memcpy(out, v, sizeof(v));
+}
+void vgpu_proof_transcript(const vgpu_proof_t* pr, uint32_t out[33]) {
+    memcpy(out, pr->dbg.prep_root, 32);
+    memcpy(out + 8, pr->dbg.perm_challenges, 60);
+    memcpy(out + 23, pr->dbg.alpha, 20);
+    memcpy(out + 28, pr->dbg.zeta, 20);
+}
+static int64_t copy_dbg(const std::vector<std::vector<uint32_t>>& v, uint32_t chip, uint32_t* out, uint64_t cap) {
+    if (chip >= v.size()) return -1;
+    if (out && cap >= v[chip].size()) memcpy(out, v[chip].data(), v[chip].size() * 4);
+    return (int64_t)v[chip].size();
+}
+int64_t vgpu_proof_debug_perm_trace(const vgpu_proof_t* pr, uint32_t chip, uint32_t* out, uint64_t cap) { return copy_dbg(pr->dbg.perm_traces, chip, out, cap); }
+int64_t vgpu_proof_debug_quotient(const vgpu_proof_t* pr, uint32_t chip, uint32_t* out, uint64_t cap) { return copy_dbg(pr->dbg.quotient_chunks, chip, out, cap); }
+void vgpu_proof_free(vgpu_proof_t* pr) { delete pr; }
+
+// ---- workloads
+int32_t vgpu_workload_fib(uint32_t n, vgpu_workload_t** out) {
+    VG_TRY({
+        if (!out) throw std::invalid_argument("null out");
+        auto w = std::make_unique<vgpu_workload>();
+        w->vm.reset(new vwork::BasicVm(vwork::fib_program(n)));
+        w->vm->run();
+        w->main = w->vm->main_traces();
+        w->prep_program = w->vm->program_preprocessed();
+        w->prep_range = vwork::BasicVm::range_preprocessed();
+        auto it = w->vm->cells.find(0x1000 + 4);
+        w->result = it == w->vm->cells.end() ? 0 : it->second;
+        *out = w.release();
+    })
+}
+void vgpu_workload_free(vgpu_workload_t* w) { delete w; }
+void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]) {
+    out[0] = w->vm->clock; out[1] = w->vm->cpu_ops.size(); out[2] = w->vm->mem_ops.size(); out[3] = w->vm->add_ops.size();
+    out[4] = w->result; out[5] = w->vm->rom.size(); out[6] = w->main[0].height; out[7] = 0;
+}
+int32_t vgpu_workload_main_trace(const vgpu_workload_t* w, uint32_t chip, const uint32_t** data, uint64_t* height, uint64_t* width) {
+    VG_TRY({
+        if (!w || chip >= w->main.size()) throw std::invalid_argument("bad chip index");
+        *data = w->main[chip].v.data(); *height = w->main[chip].height; *width = w->main[chip].width;
+    })
+}
+int32_t vgpu_workload_preprocessed(const vgpu_workload_t* w, uint32_t k, uint32_t* chip, const uint32_t** data, uint64_t* height, uint64_t* width) {
+    VG_TRY({
+        if (!w || k > 1) throw std::invalid_argument("bad index");
+        const vwork::RowMajor& m = k == 0 ? w->prep_program : w->prep_range;
+        *chip = k == 0 ? (uint32_t)vchips::CHIP_PROGRAM : (uint32_t)vchips::CHIP_RANGE;
+        *data = m.v.data(); *height = m.height; *width = m.width;
+    })
+}
+
+}  // extern "C"

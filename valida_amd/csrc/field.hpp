@@ -1,0 +1,151 @@
+// BabyBear (p = 2^31 - 2^27 + 1) in Montgomery form (R = 2^32) and its degree-5 binomial extension
+// F[X]/(X^5 - 2), usable from host and gfx950 device code.  Replaces p3-baby-bear / p3-field's
+// BabyBear and BinomialExtensionField<BabyBear, 5> (reference instantiation:
+// basic/tests/test_prover.rs:413-416; constants: SURVEY.md §7.1 step 0).
+//
+// Device notes: a Montgomery product is 2x v_mul_lo_u32 + 2x v_mul_hi_u32 + 3 VALU; there is no MFMA
+// path for 31-bit modular integer arithmetic.  Field elements cross the C ABI as canonical u32 < p and
+// live in HBM in Montgomery form.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define VG_HD __host__ __device__ __forceinline__
+#else
+#define VG_HD inline
+#endif
+
+namespace vg {
+
+constexpr uint32_t P = 0x78000001u;       // 2013265921
+constexpr uint32_t P_INV_NEG = 0x77ffffffu;  // -p^{-1} mod 2^32   (p^{-1} = 0x88000001)
+constexpr uint32_t R_MOD_P = 268435454u;     // 2^32 mod p  (Montgomery form of 1)
+constexpr uint32_t R2_MOD_P = 1172168163u;   // 2^64 mod p
+constexpr uint32_t GENERATOR = 31;
+constexpr uint32_t TWO_ADIC_ROOT_27 = 0x1a427a41u;  // canonical; 31^15
+
+VG_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// Montgomery reduction of a 64-bit value t < p * 2^32: returns t / 2^32 mod p, in [0, p).
+VG_HD uint32_t monty_reduce(uint64_t t) {
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo * 0x88000001u;         // lo * p^{-1} mod 2^32
+    uint32_t u = mul_hi_u32(m, P);         // (m * p) >> 32 ; low word of m*p equals lo
+    uint32_t r = hi - u;
+    return hi < u ? r + P : r;
+}
+
+struct Fp {
+    uint32_t v;  // Montgomery representation, < p
+    VG_HD static Fp raw(uint32_t m) { Fp r; r.v = m; return r; }
+    VG_HD static Fp zero() { return raw(0); }
+    VG_HD static Fp one() { return raw(R_MOD_P); }
+    VG_HD static Fp from_canonical(uint32_t x) { return raw(monty_reduce((uint64_t)x * R2_MOD_P)); }  // x < p (or any u32: result is x mod p)
+    VG_HD uint32_t canonical() const { return monty_reduce((uint64_t)v); }
+    VG_HD bool is_zero() const { return v == 0; }
+    VG_HD bool operator==(const Fp& o) const { return v == o.v; }
+    VG_HD bool operator!=(const Fp& o) const { return v != o.v; }
+    VG_HD Fp operator+(const Fp& o) const { uint32_t s = v + o.v; return raw(s >= P ? s - P : s); }
+    VG_HD Fp operator-(const Fp& o) const { uint32_t d = v - o.v; return raw(v < o.v ? d + P : d); }
+    VG_HD Fp operator-() const { return raw(v ? P - v : 0); }
+    VG_HD Fp operator*(const Fp& o) const { return raw(monty_reduce((uint64_t)v * o.v)); }
+    VG_HD Fp& operator+=(const Fp& o) { *this = *this + o; return *this; }
+    VG_HD Fp& operator-=(const Fp& o) { *this = *this - o; return *this; }
+    VG_HD Fp& operator*=(const Fp& o) { *this = *this * o; return *this; }
+    VG_HD Fp square() const { return *this * *this; }
+    VG_HD Fp pow(uint64_t e) const {
+        Fp r = one(), b = *this;
+        while (e) { if (e & 1) r *= b; b *= b; e >>= 1; }
+        return r;
+    }
+    VG_HD Fp exp_power_of_2(unsigned k) const { Fp r = *this; for (unsigned i = 0; i < k; i++) r *= r; return r; }
+    VG_HD Fp inv() const { return pow(P - 2); }  // 0 -> 0
+    VG_HD Fp halve() const { return raw((v & 1) ? (uint32_t)(((uint64_t)v + P) >> 1) : v >> 1); }
+};
+
+VG_HD Fp two_adic_generator(unsigned bits) {  // bits <= 27
+    return Fp::from_canonical(TWO_ADIC_ROOT_27).exp_power_of_2(27 - bits);
+}
+
+struct Ext5 {
+    Fp c[5];
+    VG_HD static Ext5 zero() { Ext5 r; for (int i = 0; i < 5; i++) r.c[i] = Fp::zero(); return r; }
+    VG_HD static Ext5 one() { Ext5 r = zero(); r.c[0] = Fp::one(); return r; }
+    VG_HD static Ext5 from_base(Fp b) { Ext5 r = zero(); r.c[0] = b; return r; }
+    VG_HD bool is_zero() const { return (c[0].v | c[1].v | c[2].v | c[3].v | c[4].v) == 0; }
+    VG_HD bool operator==(const Ext5& o) const { for (int i = 0; i < 5; i++) if (c[i].v != o.c[i].v) return false; return true; }
+    VG_HD bool operator!=(const Ext5& o) const { return !(*this == o); }
+    VG_HD Ext5 operator+(const Ext5& o) const { Ext5 r; for (int i = 0; i < 5; i++) r.c[i] = c[i] + o.c[i]; return r; }
+    VG_HD Ext5 operator-(const Ext5& o) const { Ext5 r; for (int i = 0; i < 5; i++) r.c[i] = c[i] - o.c[i]; return r; }
+    VG_HD Ext5 operator-() const { Ext5 r; for (int i = 0; i < 5; i++) r.c[i] = -c[i]; return r; }
+    VG_HD Ext5 operator*(const Fp& s) const { Ext5 r; for (int i = 0; i < 5; i++) r.c[i] = c[i] * s; return r; }
+    VG_HD Ext5 operator+(const Fp& s) const { Ext5 r = *this; r.c[0] += s; return r; }
+    VG_HD Ext5 operator-(const Fp& s) const { Ext5 r = *this; r.c[0] -= s; return r; }
+    // Schoolbook, X^5 = 2 folded by pre-doubling one operand: limb k = sum_i a_i * B_{k,i} with
+    // B_{k,i} = b_{k-i} (i <= k) or 2*b_{k+5-i} (i > k).  Two products (< 2 p^2 < p * 2^32) share one
+    // Montgomery reduction: 3 reductions per limb instead of 5.
+    VG_HD Ext5 operator*(const Ext5& o) const {
+        Fp d[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) d[j] = o.c[j] + o.c[j];
+        Ext5 r;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            uint32_t bb[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) bb[i] = i <= k ? o.c[k - i].v : d[k + 5 - i].v;
+            uint64_t t01 = (uint64_t)c[0].v * bb[0] + (uint64_t)c[1].v * bb[1];
+            uint64_t t23 = (uint64_t)c[2].v * bb[2] + (uint64_t)c[3].v * bb[3];
+            uint64_t t4 = (uint64_t)c[4].v * bb[4];
+            r.c[k] = Fp::raw(monty_reduce(t01)) + Fp::raw(monty_reduce(t23)) + Fp::raw(monty_reduce(t4));
+        }
+        return r;
+    }
+    VG_HD Ext5& operator+=(const Ext5& o) { *this = *this + o; return *this; }
+    VG_HD Ext5& operator-=(const Ext5& o) { *this = *this - o; return *this; }
+    VG_HD Ext5& operator*=(const Ext5& o) { *this = *this * o; return *this; }
+    VG_HD Ext5 square() const { return *this * *this; }
+    VG_HD Ext5 pow(uint64_t e) const {
+        Ext5 r = one(), b = *this;
+        while (e) { if (e & 1) r *= b; b *= b; e >>= 1; }
+        return r;
+    }
+    VG_HD Ext5 exp_power_of_2(unsigned k) const { Ext5 r = *this; for (unsigned i = 0; i < k; i++) r *= r; return r; }
+    // Frobenius x -> x^p acts on X^i by multiplying with z^i, z = 2^((p-1)/5) (canonical 815036133).
+    VG_HD Ext5 frobenius() const {
+        const Fp z1 = Fp::from_canonical(815036133u);
+        const Fp z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        Ext5 r; r.c[0] = c[0]; r.c[1] = c[1] * z1; r.c[2] = c[2] * z2; r.c[3] = c[3] * z3; r.c[4] = c[4] * z4;
+        return r;
+    }
+    // a^{-1} = (prod_{k=1..4} frob^k(a)) / Norm(a), Norm(a) = a * prod in the base field.  0 -> 0.
+    VG_HD Ext5 inv() const {
+        Ext5 f1 = frobenius(), f2 = f1.frobenius(), f3 = f2.frobenius(), f4 = f3.frobenius();
+        Ext5 prod = (f1 * f2) * (f3 * f4);
+        // only the constant coefficient of a*prod is needed
+        Fp hi = c[1] * prod.c[4] + c[2] * prod.c[3] + c[3] * prod.c[2] + c[4] * prod.c[1];
+        Fp norm = c[0] * prod.c[0] + hi + hi;
+        return prod * norm.inv();
+    }
+};
+
+VG_HD uint32_t reverse_bits_len(uint32_t x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    uint32_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+inline unsigned log2_strict_u64(uint64_t n) { unsigned k = 0; while ((1ull << k) < n) k++; return k; }
+
+}  // namespace vg

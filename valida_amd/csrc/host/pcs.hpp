@@ -1,0 +1,129 @@
+// Device PCS: the GPU counterpart of `TwoAdicFriPcs` as Valida drives it through
+// UnivariatePcsWithLde (machine/src/config.rs:17-22):
+//   commit_batches / commit_shifted_batches   basic/src/lib.rs:199,223,258,599
+//   get_ldes                                  basic/src/lib.rs:201,225,261   (zero-copy: the LDEs stay in HBM)
+//   coset_shift / log_blowup                  basic/src/lib.rs:594, machine/src/quotient.rs:41,98
+// Conventions: SURVEY.md App. B3-B5.  Opening (open_multi_batches) lives in prover.cpp because it is
+// interleaved with the host transcript.
+#pragma once
+#include <algorithm>
+#include <memory>
+#include "runtime.hpp"
+
+namespace vhost {
+
+struct FriParams {
+    unsigned log_blowup = 1, num_queries = 40, pow_bits = 8;
+    bool observe_final_poly = false;
+};
+
+// One Merkle tree over column-major device matrices of mixed heights (FieldMerkleTreeMmcs, App. B5).
+struct DeviceTree {
+    DeviceCtx* ctx = nullptr;
+    std::vector<DBuf> layers;          // layers[i]: (max_height >> i) digests of 8 words; back() = root
+    std::vector<uint64_t> layer_len;
+    unsigned log_max_height = 0;
+    uint32_t root[8] = {0};            // canonical
+
+    // mats: views in commit order.  Enqueues all kernels; root is read back (sync) at the end.
+    void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats) {
+        ctx = c;
+        std::vector<size_t> order(mats.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return mats[a].height > mats[b].height; });
+        // column-pointer lists per height group, uploaded in one transfer
+        struct Group { uint64_t height; size_t first, count; };
+        std::vector<Group> groups;
+        std::vector<uint64_t> ptrs;
+        for (size_t pos = 0; pos < order.size();) {
+            uint64_t h = mats[order[pos]].height;
+            Group g{h, ptrs.size(), 0};
+            while (pos < order.size() && mats[order[pos]].height == h) {
+                const vk::DMatView& m = mats[order[pos++]];
+                for (uint64_t col = 0; col < m.width; col++) ptrs.push_back((uint64_t)(m.data + col * m.stride));
+            }
+            g.count = ptrs.size() - g.first;
+            groups.push_back(g);
+        }
+        DBuf ptr_buf(c, ptrs.size() * 2);
+        c->upload(ptr_buf.data, ptrs.data(), ptrs.size() * 8);
+        const uint32_t* const* pd = (const uint32_t* const*)ptr_buf.data;
+
+        uint64_t maxh = groups[0].height;
+        log_max_height = vg::log2_strict_u64(maxh);
+        layers.clear(); layer_len.clear();
+        layers.emplace_back(c, (size_t)maxh * 8);
+        layer_len.push_back(maxh);
+        vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
+        size_t gi = 1;
+        for (uint64_t len = maxh / 2; len >= 1; len /= 2) {
+            layers.emplace_back(c, (size_t)len * 8);
+            layer_len.push_back(len);
+            const Group* inj = (gi < groups.size() && groups[gi].height == len) ? &groups[gi] : nullptr;
+            vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
+                                       layers.back().data);
+            if (inj) gi++;
+            if (len == 1) break;
+        }
+        if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
+        c->check_launch("mmcs build");
+        c->download(root, layers.back().data, 32);  // also keeps ptr_buf alive until the kernels finished
+    }
+};
+
+// ProverData of one commitment round: the committed (bit-reversed) LDEs + their tree.
+struct ProverData {
+    std::vector<DMat> ldes;  // commit order
+    DeviceTree tree;
+};
+
+// One matrix handed to commit: column-major evaluations over H_n with rows in natural order, or already
+// at bit-reversed positions (`rows_bitrev`).  `consume`: the buffer may be used as the coefficient
+// scratch and released (only meaningful with rows_bitrev); otherwise it is left untouched.
+struct CommitInput {
+    DMat* mat;
+    bool rows_bitrev;
+    bool consume;
+};
+
+// Returns the bit-reversed LDE on lde_shift * H_{n << log_blowup}.
+inline DMat coset_lde(DeviceCtx* c, const CommitInput& in, unsigned log_blowup, Fp lde_shift) {
+    const uint64_t n = in.mat->height, b = 1ull << log_blowup;
+    DMat coeffs;
+    if (in.rows_bitrev && in.consume) coeffs = std::move(*in.mat);
+    else {
+        coeffs = DMat(c, n, in.mat->width);
+        if (in.rows_bitrev) VG_HIP_CHECK(hipMemcpyAsync(coeffs.data, in.mat->data, n * in.mat->width * 4, hipMemcpyDeviceToDevice, c->stream));
+        else vk::launch_bitrev_rows(c->stream, in.mat->view(), coeffs.view());
+    }
+    vk::launch_intt(c->stream, coeffs.view(), c->tables);
+    DMat lde(c, n * b, coeffs.width);
+    const unsigned k = vg::log2_strict_u64(n);
+    Fp w = vg::two_adic_generator(k + log_blowup), wt = Fp::one();
+    for (uint64_t t = 0; t < b; t++) {
+        uint64_t block = vg::reverse_bits_len((uint32_t)t, log_blowup);
+        vk::launch_coset_ntt(c->stream, coeffs.view(), lde.view(), block * n, lde_shift * wt, c->tables);
+        wt *= w;
+    }
+    c->check_launch("coset_lde");
+    // `coeffs` returns to the pool when this function exits while kernels reading it may still be
+    // queued: safe because the pool only ever hands a block to work enqueued LATER on the same stream.
+    return lde;
+}
+
+// pcs.commit_shifted_batches (App. B4): lde_i on (31 / coset_shift_i) * H, bit-reversed rows, one MMCS.
+inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vector<CommitInput>& mats, const std::vector<Fp>* coset_shifts,
+                                                  const FriParams& fri) {
+    auto pd = std::make_unique<ProverData>();
+    Fp g = Fp::from_canonical(vg::GENERATOR);
+    for (size_t i = 0; i < mats.size(); i++) {
+        Fp shift = coset_shifts ? g * (*coset_shifts)[i].inv() : g;
+        pd->ldes.push_back(coset_lde(c, mats[i], fri.log_blowup, shift));
+    }
+    std::vector<vk::DMatView> views;
+    for (auto& l : pd->ldes) views.push_back(l.view());
+    pd->tree.build(c, views);
+    return pd;
+}
+
+}  // namespace vhost

@@ -1,0 +1,547 @@
+// Machine::prove on one MI355X (see prover.hpp).  Phase order and transcript follow
+// basic/src/lib.rs:147-675 / SURVEY.md Appendix C; PCS conventions SURVEY.md Appendix B.
+#include "prover.hpp"
+
+namespace vhost {
+
+using Clock = std::chrono::steady_clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+static Ext5 ext_from_canonical(const uint32_t* w) { Ext5 e; for (int k = 0; k < 5; k++) e.c[k] = Fp::from_canonical(w[k]); return e; }
+static void ext_to_canonical(const Ext5& e, uint32_t* w) { for (int k = 0; k < 5; k++) w[k] = e.c[k].canonical(); }
+
+Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_rc480, const FriParams& fri)
+    : ctx_(new DeviceCtx(device)), machine_(machine), fri_(fri), perm16_(poseidon_rc480) {
+    for (auto& a : machine_.airs) {
+        if (a.log_quotient_degree != 1) throw std::runtime_error("chip " + a.name + ": only log_quotient_degree = 1 is implemented on the device");
+        if (fri_.log_blowup < a.log_quotient_degree) throw std::runtime_error("log_blowup must be >= log_quotient_degree");
+        std::vector<uint32_t> pw(a.program.instrs.size() * 2 + 2, 0);
+        if (!a.program.instrs.empty()) memcpy(pw.data(), a.program.instrs.data(), a.program.instrs.size() * 8);
+        prog_dev_.emplace_back(ctx_.get(), pw);
+        iw_dev_.emplace_back(ctx_.get(), a.interaction_words);
+    }
+}
+Prover::~Prover() {
+    prog_dev_.clear();
+    iw_dev_.clear();
+}
+
+std::unique_ptr<DeviceTrace> Prover::upload_trace(const HostMatrix& m) {
+    auto t = std::make_unique<DeviceTrace>();
+    t->height = m.height; t->width = m.width;
+    t->raw = DBuf(ctx_.get(), (size_t)(m.height * m.width));
+    VG_HIP_CHECK(hipMemcpyAsync(t->raw.data, m.data, m.height * m.width * 4, hipMemcpyHostToDevice, ctx_->stream));
+    ctx_->sync();
+    return t;
+}
+
+namespace {
+struct PointKey {
+    uint32_t w[5];
+    bool operator<(const PointKey& o) const { return memcmp(w, o.w, 20) < 0; }
+};
+PointKey key_of(const Ext5& e) { PointKey k; for (int i = 0; i < 5; i++) k.w[i] = e.c[i].v; return k; }
+
+struct GatherList {
+    std::vector<uint32_t> desc;
+    uint32_t next_dst = 0;
+    // returns dst offset
+    uint32_t add(const uint32_t* src, uint64_t stride, uint32_t count, uint32_t kind) {
+        put_ptr(desc, src);
+        put_u64(desc, stride);
+        desc.push_back(count | (kind << 28));
+        desc.push_back(next_dst);
+        uint32_t at = next_dst;
+        next_dst += count;
+        return at;
+    }
+    size_t n() const { return desc.size() / 6; }
+};
+}  // namespace
+
+std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main, const std::vector<std::pair<int, const DeviceTrace*>>& preprocessed,
+                                    PhaseTimes* times, ProveDebugOut* dbg) {
+    DeviceCtx& c = *ctx_;
+    VG_HIP_CHECK(hipSetDevice(c.device));
+    const size_t NC = machine_.airs.size();
+    if (main.size() != NC) throw std::invalid_argument("prove: need one main trace per chip");
+    const Fp s = Fp::from_canonical(vg::GENERATOR);  // pcs.coset_shift()
+    const unsigned lb = fri_.log_blowup;
+    Challenger ch(&perm16_);
+    PhaseTimes tm;
+    auto t_total = Clock::now();
+    auto t0 = Clock::now();
+
+    // ---------------- ingest: row-major canonical -> column-major Montgomery (natural row order)
+    std::vector<unsigned> log_deg(NC);
+    std::vector<DMat> main_nat(NC);
+    for (size_t i = 0; i < NC; i++) {
+        if (main[i]->width != machine_.airs[i].width) throw std::invalid_argument("prove: trace width mismatch for chip " + machine_.airs[i].name);
+        uint64_t h = main[i]->height;
+        if (h == 0 || (h & (h - 1))) throw std::invalid_argument("prove: trace heights must be powers of two");
+        log_deg[i] = vg::log2_strict_u64(h);
+        main_nat[i] = DMat(&c, h, main[i]->width);
+        vk::launch_ingest(c.stream, main[i]->raw.data, main_nat[i].view(), false);
+    }
+    std::vector<DMat> prep_nat(preprocessed.size());
+    std::vector<int> prep_slot(NC, -1);
+    for (size_t k = 0; k < preprocessed.size(); k++) {
+        const DeviceTrace* t = preprocessed[k].second;
+        int chip = preprocessed[k].first;
+        if (t->width != machine_.airs[chip].prep_width || t->height != main[chip]->height) throw std::invalid_argument("prove: preprocessed trace shape mismatch");
+        prep_nat[k] = DMat(&c, t->height, t->width);
+        vk::launch_ingest(c.stream, t->raw.data, prep_nat[k].view(), false);
+        prep_slot[chip] = (int)k;
+    }
+    c.check_launch("ingest");
+    c.sync();
+    tm.ingest = ms_since(t0);
+
+    // ---------------- preprocessed + main commitments (lib.rs:189-225)
+    t0 = Clock::now();
+    std::unique_ptr<ProverData> prep_pd;
+    if (!prep_nat.empty()) {
+        std::vector<CommitInput> in;
+        for (auto& m : prep_nat) in.push_back({&m, false, false});
+        prep_pd = commit_batches(&c, in, nullptr, fri_);
+        ch.observe_digest(prep_pd->tree.root);
+    }
+    std::unique_ptr<ProverData> main_pd;
+    {
+        std::vector<CommitInput> in;
+        for (auto& m : main_nat) in.push_back({&m, false, false});
+        main_pd = commit_batches(&c, in, nullptr, fri_);
+    }
+    ch.observe_digest(main_pd->tree.root);
+    tm.commit_main = ms_since(t0);
+
+    // ---------------- permutation traces (lib.rs:227-261)
+    t0 = Clock::now();
+    Ext5 rnd[3];
+    for (int i = 0; i < 3; i++) rnd[i] = ch.sample_ext();
+    std::vector<std::vector<Ext5>> bus_alphas(NC), betas(NC);
+    std::vector<DMat> perm_nat(NC);
+    std::vector<Ext5> cumulative_sums(NC);
+    {
+        std::vector<uint32_t> pool;
+        std::vector<size_t> off(NC);
+        for (size_t i = 0; i < NC; i++) {
+            auto& its = machine_.airs[i].interactions;
+            size_t maxf = 0;
+            for (auto& it : its) {
+                const Ext5& r = it.is_local() ? rnd[0] : rnd[1];  // generate_rlc_elements (chip.rs:291-331)
+                bus_alphas[i].push_back(r.pow((uint64_t)it.bus_index + 1));
+                maxf = std::max(maxf, it.fields.size());
+            }
+            Ext5 bp = Ext5::one();
+            for (size_t j = 0; j < maxf; j++) { betas[i].push_back(bp); bp *= rnd[2]; }
+            off[i] = pool.size();
+            for (auto& a : bus_alphas[i]) put_ext(pool, a);
+            for (auto& b : betas[i]) put_ext(pool, b);
+        }
+        pool.push_back(0);
+        DBuf pool_dev(&c, pool);
+        GatherList gl;
+        std::vector<DBuf> scratch;
+        for (size_t i = 0; i < NC; i++) {
+            uint32_t M = (uint32_t)machine_.airs[i].interactions.size();
+            uint64_t n = main_nat[i].height;
+            perm_nat[i] = DMat(&c, n, 5 * (M + 1));
+            vk::DMatView pv{nullptr, 0, 0, 0};
+            if (prep_slot[i] >= 0) pv = prep_nat[prep_slot[i]].view();
+            scratch.emplace_back(&c, (size_t)vk::perm_scratch_words(n));
+            vk::launch_perm_trace(c.stream, main_nat[i].view(), pv, iw_dev_[i].data, pool_dev.data + off[i], M, perm_nat[i].view(), scratch.back().data);
+            gl.add(perm_nat[i].data + (uint64_t)(5 * M) * n + (n - 1), n, 5, 0);  // cumulative sum = last row, last column (lib.rs:247-250)
+        }
+        c.check_launch("perm trace");
+        DBuf gd(&c, gl.desc), gout(&c, gl.next_dst);
+        vk::launch_gather(c.stream, gd.data, gl.n(), gout.data);
+        std::vector<uint32_t> cs(gl.next_dst);
+        c.download(cs.data(), gout.data, cs.size() * 4);
+        for (size_t i = 0; i < NC; i++) cumulative_sums[i] = ext_from_canonical(&cs[5 * i]);
+    }
+    tm.perm = ms_since(t0);
+    if (dbg && dbg->keep_matrices) {
+        dbg->perm_traces.resize(NC);
+        for (size_t i = 0; i < NC; i++) {
+            auto& pm = perm_nat[i];
+            DBuf tmp(&c, (size_t)(pm.height * pm.width));
+            vk::launch_export_rows(c.stream, pm.view(), 0, pm.height, tmp.data);
+            dbg->perm_traces[i].resize(pm.height * pm.width);
+            c.download(dbg->perm_traces[i].data(), tmp.data, dbg->perm_traces[i].size() * 4);
+        }
+    }
+    t0 = Clock::now();
+    std::unique_ptr<ProverData> perm_pd;
+    {
+        std::vector<CommitInput> in;
+        for (auto& m : perm_nat) in.push_back({&m, false, false});
+        perm_pd = commit_batches(&c, in, nullptr, fri_);
+    }
+    ch.observe_digest(perm_pd->tree.root);
+    perm_nat.clear();
+    main_nat.clear();
+    prep_nat.clear();
+    tm.commit_perm = ms_since(t0);
+
+    // ---------------- quotients (lib.rs:263-599)
+    t0 = Clock::now();
+    const Ext5 alpha = ch.sample_ext();
+    std::vector<DMat> quot(NC);
+    std::vector<Fp> quot_shifts(NC);
+    {
+        std::vector<uint32_t> pool;
+        std::vector<size_t> off(NC);
+        std::vector<uint32_t> Ks(NC);
+        for (size_t i = 0; i < NC; i++) {
+            auto& air = machine_.airs[i];
+            uint32_t M = (uint32_t)air.interactions.size(), K = air.program.num_asserts + M + 3;
+            Ks[i] = K;
+            off[i] = pool.size();
+            std::vector<Ext5> ap(K);
+            Ext5 p = Ext5::one();
+            for (uint32_t k = 0; k < K; k++) { ap[K - 1 - k] = p; p *= alpha; }  // constraint k is scaled by alpha^(K-1-k)
+            for (auto& e : ap) put_ext(pool, e);
+            for (auto& e : bus_alphas[i]) put_ext(pool, e);
+            for (auto& e : betas[i]) put_ext(pool, e);
+            put_ext(pool, cumulative_sums[i]);
+        }
+        DBuf pool_dev(&c, pool);
+        for (size_t i = 0; i < NC; i++) {
+            auto& air = machine_.airs[i];
+            vk::QuotientArgs a{};
+            a.main_lde = main_pd->ldes[i].view();
+            a.perm_lde = perm_pd->ldes[i].view();
+            a.prep_lde = prep_slot[i] >= 0 ? prep_pd->ldes[prep_slot[i]].view() : vk::DMatView{nullptr, 0, 0, 0};
+            a.log_n = (int)log_deg[i];
+            a.prog = (const vair::Instr*)prog_dev_[i].data;
+            a.n_instrs = (uint32_t)air.program.instrs.size();
+            a.n_regs = air.program.num_regs;
+            a.n_air_asserts = air.program.num_asserts;
+            a.iw = iw_dev_[i].data;
+            a.consts = pool_dev.data + off[i];
+            a.K = Ks[i];
+            a.coset_shift = s.v;
+            a.coset_shift_inv = s.inv().v;
+            Fp sn = s.exp_power_of_2(log_deg[i]);
+            Fp z0 = sn - Fp::one(), z1 = -sn - Fp::one();
+            a.zh[0] = z0.v; a.zh[1] = z1.v;
+            a.zh_inv[0] = z0.inv().v; a.zh_inv[1] = z1.inv().v;
+            a.g_inv = vg::two_adic_generator(log_deg[i]).inv().v;
+            quot[i] = DMat(&c, 1ull << log_deg[i], 10);
+            a.out = quot[i].view();
+            vk::launch_quotient(c.stream, a, c.tables);
+            quot_shifts[i] = s.exp_power_of_2(air.log_quotient_degree);  // lib.rs:593-596
+        }
+        c.check_launch("quotient");
+        c.sync();
+    }
+    tm.quotient = ms_since(t0);
+    if (dbg && dbg->keep_matrices) {
+        dbg->quotient_chunks.resize(NC);
+        for (size_t i = 0; i < NC; i++) {
+            auto& q = quot[i];
+            DMat nat(&c, q.height, q.width);
+            if (q.height > 1) vk::launch_bitrev_rows(c.stream, q.view(), nat.view());
+            else VG_HIP_CHECK(hipMemcpyAsync(nat.data, q.data, q.width * 4, hipMemcpyDeviceToDevice, c.stream));
+            DBuf tmp(&c, (size_t)(q.height * q.width));
+            vk::launch_export_rows(c.stream, nat.view(), 0, q.height, tmp.data);
+            dbg->quotient_chunks[i].resize(q.height * q.width);
+            c.download(dbg->quotient_chunks[i].data(), tmp.data, dbg->quotient_chunks[i].size() * 4);
+        }
+    }
+    t0 = Clock::now();
+    std::unique_ptr<ProverData> quot_pd;
+    {
+        std::vector<CommitInput> in;
+        for (auto& m : quot) in.push_back({&m, true, true});
+        quot_pd = commit_batches(&c, in, &quot_shifts, fri_);
+    }
+    ch.observe_digest(quot_pd->tree.root);
+    quot.clear();
+    tm.commit_quotient = ms_since(t0);
+
+    // ---------------- opening (lib.rs:606-619; App. B9)
+    t0 = Clock::now();
+    const Ext5 zeta = ch.sample_ext();
+    ProverData* rounds[3] = {main_pd.get(), perm_pd.get(), quot_pd.get()};
+    // points[r][i]
+    std::vector<std::vector<std::vector<Ext5>>> points(3, std::vector<std::vector<Ext5>>(NC));
+    for (size_t i = 0; i < NC; i++) {
+        Fp g = vg::two_adic_generator(log_deg[i]);
+        points[0][i] = {zeta, zeta * g};
+        points[1][i] = {zeta, zeta * g};
+        points[2][i] = {zeta.exp_power_of_2(machine_.airs[i].log_quotient_degree)};
+    }
+    // opened[r][i][p] = vector<Ext5> (one per column)
+    std::vector<std::vector<std::vector<std::vector<Ext5>>>> opened(3, std::vector<std::vector<std::vector<Ext5>>>(NC));
+    {
+        // constant pool: distinct (log_n, point) -> z words; per (r, i): scale factors
+        std::map<std::pair<unsigned, PointKey>, size_t> wkey;  // -> index into wlist
+        struct WEntry { unsigned log_n; Ext5 z; size_t pool_off; DBuf buf; };
+        std::vector<WEntry> wlist;
+        std::vector<uint32_t> pool;
+        struct Job { int r; size_t i; int np; size_t w[2]; size_t scale_off; size_t out_off; };
+        std::vector<Job> jobs;
+        size_t out_words = 0;
+        for (int r = 0; r < 3; r++)
+            for (size_t i = 0; i < NC; i++) {
+                const DMat& lde = rounds[r]->ldes[i];
+                unsigned ln = vg::log2_strict_u64(lde.height) - lb;
+                uint64_t n = 1ull << ln;
+                Job j{r, i, (int)points[r][i].size(), {0, 0}, pool.size(), out_words};
+                for (int p = 0; p < j.np; p++) {
+                    const Ext5& z = points[r][i][p];
+                    // scale = (z^n - s^n) / (n s^(n-1))
+                    Ext5 zer = z.exp_power_of_2(ln) - s.exp_power_of_2(ln);
+                    Fp den = Fp::from_canonical((uint32_t)(n % vg::P)) * s.pow(n - 1);
+                    put_ext(pool, zer * den.inv());
+                }
+                for (int p = 0; p < j.np; p++) {
+                    const Ext5& z = points[r][i][p];
+                    auto key = std::make_pair(ln, key_of(z));
+                    auto it = wkey.find(key);
+                    if (it == wkey.end()) {
+                        wkey[key] = wlist.size();
+                        j.w[p] = wlist.size();
+                        wlist.push_back(WEntry{ln, z, 0, DBuf()});
+                    } else j.w[p] = it->second;
+                }
+                out_words += lde.width * j.np * 5;
+                jobs.push_back(j);
+            }
+        for (auto& w : wlist) { w.pool_off = pool.size(); put_ext(pool, w.z); }
+        DBuf pool_dev(&c, pool);
+        for (auto& w : wlist) {
+            uint64_t n = 1ull << w.log_n;
+            w.buf = DBuf(&c, (size_t)(5 * n));
+            vk::launch_bary_weights(c.stream, n, pool_dev.data + w.pool_off, s, c.tables, w.buf.data);
+        }
+        DBuf out_dev(&c, out_words);
+        std::vector<DBuf> partials;
+        for (auto& j : jobs) {
+            const DMat& lde = rounds[j.r]->ldes[j.i];
+            uint64_t n = lde.height >> lb;
+            partials.emplace_back(&c, (size_t)(vk::col_dot_slots(n) * lde.width * j.np * 5));
+            vk::launch_col_dot(c.stream, lde.view(), n, j.np, wlist[j.w[0]].buf.data, wlist[j.w[j.np - 1]].buf.data, partials.back().data,
+                               pool_dev.data + j.scale_off, out_dev.data + j.out_off);
+        }
+        c.check_launch("opened values");
+        std::vector<uint32_t> out(out_words);
+        c.download(out.data(), out_dev.data, out_words * 4);
+        for (auto& j : jobs) {
+            uint64_t w = rounds[j.r]->ldes[j.i].width;
+            opened[j.r][j.i].assign(j.np, std::vector<Ext5>(w));
+            for (uint64_t col = 0; col < w; col++)
+                for (int p = 0; p < j.np; p++) opened[j.r][j.i][p][col] = ext_from_canonical(&out[j.out_off + (col * j.np + p) * 5]);
+        }
+    }
+    tm.open_values = ms_since(t0);
+
+    // reduced openings per LDE height
+    t0 = Clock::now();
+    const Ext5 alpha_b = ch.sample_ext();
+    std::map<unsigned, DBuf> ro;  // log_height -> pair-layout vector
+    unsigned log_max = 0;
+    {
+        struct MatEntry { const DMat* lde; std::vector<std::tuple<uint32_t, Ext5, Ext5>> pts; };
+        struct Group { std::vector<Ext5> zs; std::map<PointKey, uint32_t> slot; std::vector<MatEntry> mats; size_t max_w = 0; uint64_t num_reduced = 0; };
+        std::map<unsigned, Group> groups;
+        size_t max_width = 0;
+        for (int r = 0; r < 3; r++) for (auto& l : rounds[r]->ldes) max_width = std::max<size_t>(max_width, l.width);
+        std::vector<Ext5> apow(max_width);
+        { Ext5 p = Ext5::one(); for (auto& a : apow) { a = p; p *= alpha_b; } }
+        for (int r = 0; r < 3; r++)
+            for (size_t i = 0; i < NC; i++) {
+                const DMat& lde = rounds[r]->ldes[i];
+                unsigned lh = vg::log2_strict_u64(lde.height);
+                Group& g = groups[lh];
+                g.max_w = std::max<size_t>(g.max_w, lde.width);
+                MatEntry me{&lde, {}};
+                for (size_t p = 0; p < points[r][i].size(); p++) {
+                    const Ext5& z = points[r][i][p];
+                    auto key = key_of(z);
+                    auto it = g.slot.find(key);
+                    uint32_t slot;
+                    if (it == g.slot.end()) { slot = (uint32_t)g.zs.size(); g.slot[key] = slot; g.zs.push_back(z); } else slot = it->second;
+                    if (slot >= 4) throw std::runtime_error("open: more than 4 distinct opening points per LDE height is not supported");
+                    Ext5 Y = Ext5::zero();
+                    auto& ys = opened[r][i][p];
+                    for (size_t col = 0; col < ys.size(); col++) Y += apow[col] * ys[col];
+                    me.pts.emplace_back(slot, alpha_b.pow(g.num_reduced), Y);
+                    g.num_reduced += lde.width;
+                }
+                g.mats.push_back(std::move(me));
+            }
+        std::vector<uint32_t> pool;
+        std::map<unsigned, size_t> off;
+        for (auto& kv : groups) {
+            Group& g = kv.second;
+            off[kv.first] = pool.size();
+            pool.push_back((uint32_t)g.mats.size());
+            pool.push_back((uint32_t)g.zs.size());
+            pool.push_back((uint32_t)g.max_w);
+            for (auto& z : g.zs) put_ext(pool, z);
+            for (size_t col = 0; col < g.max_w; col++) put_ext(pool, apow[col]);
+            for (auto& me : g.mats) {
+                put_ptr(pool, me.lde->data);
+                put_u64(pool, me.lde->height);
+                pool.push_back((uint32_t)me.lde->width);
+                pool.push_back((uint32_t)me.pts.size());
+                for (auto& t : me.pts) { pool.push_back(std::get<0>(t)); put_ext(pool, std::get<1>(t)); put_ext(pool, std::get<2>(t)); }
+            }
+        }
+        DBuf pool_dev(&c, pool);
+        for (auto& kv : groups) {
+            uint64_t L = 1ull << kv.first;
+            ro[kv.first] = DBuf(&c, (size_t)(5 * L));
+            vk::launch_reduce_openings(c.stream, pool_dev.data + off[kv.first], L, s, c.tables, ro[kv.first].data);
+            log_max = std::max(log_max, kv.first);
+        }
+        c.check_launch("reduce openings");
+        c.sync();
+    }
+    tm.open_reduce = ms_since(t0);
+
+    // FRI commit phase (App. B10)
+    t0 = Clock::now();
+    std::vector<DBuf> layer_bufs;          // layer i vector (length 2^(log_max - i)), pair layout
+    std::vector<DeviceTree> layer_trees;
+    std::vector<std::array<uint32_t, 8>> commit_phase_commits;
+    DBuf beta_dev(&c, 8);
+    {
+        DBuf cur = std::move(ro[log_max]);
+        ro.erase(log_max);
+        for (unsigned lf = log_max; lf-- > lb;) {
+            uint64_t L = 2ull << lf, half = L >> 1;  // current length 2^(lf+1)
+            layer_trees.emplace_back();
+            layer_trees.back().build(&c, {vk::DMatView{cur.data, half, 10, half}});
+            std::array<uint32_t, 8> root;
+            memcpy(root.data(), layer_trees.back().root, 32);
+            commit_phase_commits.push_back(root);
+            ch.observe_digest(root.data());
+            Ext5 beta = ch.sample_ext();
+            uint32_t bw[5];
+            for (int k = 0; k < 5; k++) bw[k] = beta.c[k].v;
+            c.upload(beta_dev.data, bw, 20);
+            DBuf next(&c, (size_t)(5 * half));
+            auto it = ro.find(lf);
+            vk::launch_fri_fold(c.stream, cur.data, L, beta_dev.data, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);
+            layer_bufs.push_back(std::move(cur));
+            cur = std::move(next);
+        }
+        c.check_launch("fri fold");
+        // `cur` now holds 2^lb values that must all be equal (a constant polynomial)
+        std::vector<uint32_t> fin(5ull << lb);
+        c.download(fin.data(), cur.data, fin.size() * 4);
+        // pair layout of a length-2^lb vector: (2^lb / 2) rows x 10 columns
+        uint64_t rows = (1ull << lb) >> 1;
+        auto elem = [&](uint64_t idx) { Ext5 e; for (int k = 0; k < 5; k++) e.c[k] = Fp::raw(fin[((idx & 1) * 5 + k) * rows + (idx >> 1)]); return e; };
+        Ext5 fp0 = elem(0);
+        for (uint64_t q = 1; q < (1ull << lb); q++) if (elem(q) != fp0) throw std::runtime_error("fri: final polynomial is not constant");
+        layer_bufs.push_back(std::move(cur));  // keep alive (not opened)
+        ro.clear();
+        // stash final poly in canonical form at the end of commit list handling below
+        uint32_t fpw[5];
+        ext_to_canonical(fp0, fpw);
+        if (fri_.observe_final_poly) ch.observe_ext(fp0);
+        uint32_t pow_witness = ch.grind(fri_.pow_bits);
+        tm.fri = ms_since(t0);
+
+        // ---------------- queries
+        t0 = Clock::now();
+        std::vector<uint64_t> indices(fri_.num_queries);
+        for (auto& ix : indices) ix = ch.sample_bits(log_max);
+        GatherList gl;
+        struct QOff { std::vector<uint32_t> sib; std::vector<std::vector<uint32_t>> layer_path; std::vector<std::vector<uint32_t>> rows; std::vector<std::vector<uint32_t>> path; };
+        std::vector<QOff> qoff(indices.size());
+        auto add_path = [&](const DeviceTree& t, uint64_t idx, std::vector<uint32_t>& out) {
+            for (unsigned l = 0; l < t.log_max_height; l++) out.push_back(gl.add(t.layers[l].data + 8 * ((idx >> l) ^ 1), 1, 8, 1));
+        };
+        for (size_t q = 0; q < indices.size(); q++) {
+            uint64_t index = indices[q];
+            QOff& o = qoff[q];
+            o.layer_path.resize(layer_trees.size());
+            for (size_t li = 0; li < layer_trees.size(); li++) {
+                uint64_t idx_i = index >> li, sib = idx_i ^ 1, pair = idx_i >> 1;
+                uint64_t half = 1ull << (log_max - 1 - li);
+                o.sib.push_back(gl.add(layer_bufs[li].data + (5 * (sib & 1)) * half + pair, half, 5, 0));
+                add_path(layer_trees[li], pair, o.layer_path[li]);
+            }
+            o.rows.resize(3); o.path.resize(3);
+            for (int r = 0; r < 3; r++) {
+                const DeviceTree& t = rounds[r]->tree;
+                uint64_t idx_r = index >> (log_max - t.log_max_height);
+                for (auto& lde : rounds[r]->ldes) {
+                    unsigned lh = vg::log2_strict_u64(lde.height);
+                    uint64_t row = idx_r >> (t.log_max_height - lh);
+                    o.rows[r].push_back(gl.add(lde.data + row, lde.height, (uint32_t)lde.width, 0));
+                }
+                add_path(t, idx_r, o.path[r]);
+            }
+        }
+        DBuf gd(&c, gl.desc), gout(&c, gl.next_dst);
+        vk::launch_gather(c.stream, gd.data, gl.n(), gout.data);
+        c.check_launch("query gather");
+        std::vector<uint32_t> g(gl.next_dst);
+        c.download(g.data(), gout.data, g.size() * 4);
+
+        // ---------------- assemble MachineProof (flat "VPF1" words; machine/src/proof.rs:13-44, App. B12)
+        std::vector<uint32_t> pw;
+        pw.push_back(PROOF_MAGIC);
+        pw.push_back((uint32_t)NC);
+        for (int k = 0; k < 8; k++) pw.push_back(main_pd->tree.root[k]);
+        for (int k = 0; k < 8; k++) pw.push_back(perm_pd->tree.root[k]);
+        for (int k = 0; k < 8; k++) pw.push_back(quot_pd->tree.root[k]);
+        auto put_vec = [&](const std::vector<Ext5>& v) {
+            pw.push_back((uint32_t)v.size());
+            for (auto& e : v) { uint32_t w5[5]; ext_to_canonical(e, w5); pw.insert(pw.end(), w5, w5 + 5); }
+        };
+        for (size_t i = 0; i < NC; i++) {
+            pw.push_back(log_deg[i]);
+            put_vec(opened[0][i][0]); put_vec(opened[0][i][1]);
+            put_vec(opened[1][i][0]); put_vec(opened[1][i][1]);
+            put_vec(opened[2][i][0]);
+            uint32_t w5[5]; ext_to_canonical(cumulative_sums[i], w5); pw.insert(pw.end(), w5, w5 + 5);
+        }
+        pw.push_back((uint32_t)commit_phase_commits.size());
+        for (auto& r : commit_phase_commits) pw.insert(pw.end(), r.begin(), r.end());
+        pw.push_back((uint32_t)indices.size());
+        for (size_t q = 0; q < indices.size(); q++) {
+            pw.push_back((uint32_t)layer_trees.size());
+            for (size_t li = 0; li < layer_trees.size(); li++) {
+                pw.insert(pw.end(), &g[qoff[q].sib[li]], &g[qoff[q].sib[li]] + 5);
+                pw.push_back((uint32_t)qoff[q].layer_path[li].size());
+                for (uint32_t o : qoff[q].layer_path[li]) pw.insert(pw.end(), &g[o], &g[o] + 8);
+            }
+        }
+        pw.insert(pw.end(), fpw, fpw + 5);
+        pw.push_back(pow_witness);
+        pw.push_back((uint32_t)indices.size());
+        for (size_t q = 0; q < indices.size(); q++) {
+            pw.push_back(3);
+            for (int r = 0; r < 3; r++) {
+                pw.push_back((uint32_t)rounds[r]->ldes.size());
+                for (size_t i = 0; i < rounds[r]->ldes.size(); i++) {
+                    uint32_t w = (uint32_t)rounds[r]->ldes[i].width;
+                    pw.push_back(w);
+                    pw.insert(pw.end(), &g[qoff[q].rows[r][i]], &g[qoff[q].rows[r][i]] + w);
+                }
+                pw.push_back((uint32_t)qoff[q].path[r].size());
+                for (uint32_t o : qoff[q].path[r]) pw.insert(pw.end(), &g[o], &g[o] + 8);
+            }
+        }
+        tm.queries = ms_since(t0);
+        tm.total = ms_since(t_total);
+        if (times) *times = tm;
+        if (dbg) {
+            if (prep_pd) memcpy(dbg->prep_root, prep_pd->tree.root, 32); else memset(dbg->prep_root, 0, 32);
+            for (int i = 0; i < 3; i++) ext_to_canonical(rnd[i], dbg->perm_challenges + 5 * i);
+            ext_to_canonical(alpha, dbg->alpha);
+            ext_to_canonical(zeta, dbg->zeta);
+        }
+        return pw;
+    }
+}
+
+}  // namespace vhost

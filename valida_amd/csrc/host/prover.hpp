@@ -1,0 +1,62 @@
+// Machine::prove on one MI355X: host orchestration of the transcript-ordered phases of
+// basic/src/lib.rs:147-675 (twin: derive/src/lib.rs:275-446) against the device kernels.
+#pragma once
+#include <chrono>
+#include <map>
+#include <memory>
+#include "challenger.hpp"
+#include "machine.hpp"
+#include "pcs.hpp"
+
+namespace vhost {
+
+constexpr uint32_t PROOF_MAGIC = 0x31465056u;  // "VPF1" flat wire format, see DESIGN.md / oracle/proof_io.hpp
+
+struct HostMatrix {  // canonical row-major, host memory (the reference's RowMajorMatrix<Val>)
+    const uint32_t* data;
+    uint64_t height, width;
+};
+
+// A trace resident in HBM in the layout the reference hands over (row-major, canonical u32).
+struct DeviceTrace {
+    DBuf raw;
+    uint64_t height = 0, width = 0;
+};
+
+struct PhaseTimes {  // milliseconds, host clock around stream syncs
+    double ingest = 0, commit_main = 0, perm = 0, commit_perm = 0, quotient = 0, commit_quotient = 0, open_values = 0, open_reduce = 0, fri = 0,
+           queries = 0, total = 0;
+};
+
+struct ProveDebugOut {  // optional intermediate values for stage-parity tests (canonical words)
+    uint32_t prep_root[8];
+    uint32_t perm_challenges[15], alpha[5], zeta[5];
+    bool keep_matrices = false;                          // when set, the vectors below are filled (D2H copies)
+    std::vector<std::vector<uint32_t>> perm_traces;      // per chip: n x 5(M+1) row-major, natural order
+    std::vector<std::vector<uint32_t>> quotient_chunks;  // per chip: n x 10 row-major, natural order
+};
+
+class Prover {
+  public:
+    Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_rc480, const FriParams& fri);
+    ~Prover();
+    DeviceCtx& ctx() { return *ctx_; }
+    const MachineDesc& machine() const { return machine_; }
+    const FriParams& fri() const { return fri_; }
+
+    // H2D of one host trace (not part of the timed prove()).
+    std::unique_ptr<DeviceTrace> upload_trace(const HostMatrix& m);
+
+    // main[i]: trace of chip i (chip order).  preprocessed: (chip index, trace) in chip order.
+    std::vector<uint32_t> prove(const std::vector<const DeviceTrace*>& main, const std::vector<std::pair<int, const DeviceTrace*>>& preprocessed,
+                                PhaseTimes* times = nullptr, ProveDebugOut* dbg = nullptr);
+
+  private:
+    std::unique_ptr<DeviceCtx> ctx_;
+    MachineDesc machine_;
+    FriParams fri_;
+    Poseidon16 perm16_;
+    std::vector<DBuf> prog_dev_, iw_dev_;  // per chip: program instructions, interaction words
+};
+
+}  // namespace vhost

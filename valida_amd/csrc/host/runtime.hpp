@@ -1,0 +1,172 @@
+// Device runtime for one GPU: stream, constant tables, a caching HBM allocator (a proof allocates the
+// same few dozen buffers every time — after the first proof nothing in the timed path calls hipMalloc),
+// pinned staging memory, and the column-major device matrix type.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../kernels/launch.hpp"
+
+namespace vhost {
+using vg::Ext5;
+using vg::Fp;
+
+struct DeviceCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    vk::DeviceTables tables{};
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    size_t bytes_allocated = 0, peak_live = 0, live = 0;
+    uint32_t* table_mem = nullptr;
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+
+    explicit DeviceCtx(int dev) : device(dev) {
+        VG_HIP_CHECK(hipSetDevice(dev));
+        VG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        init_tables();
+    }
+    ~DeviceCtx() {
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(stream);
+        for (auto& kv : free_blocks) (void)hipFree(kv.second);
+        for (auto& kv : live_blocks) (void)hipFree(kv.first);
+        if (table_mem) (void)hipFree(table_mem);
+        if (pinned) (void)hipHostFree(pinned);
+        (void)hipStreamDestroy(stream);
+    }
+    DeviceCtx(const DeviceCtx&) = delete;
+
+    void* alloc(size_t bytes) {
+        if (bytes == 0) bytes = 4;
+        bytes = (bytes + 255) & ~(size_t)255;
+        auto it = free_blocks.find(bytes);
+        void* p;
+        if (it != free_blocks.end()) { p = it->second; free_blocks.erase(it); }
+        else { VG_HIP_CHECK(hipMalloc(&p, bytes)); bytes_allocated += bytes; }
+        live_blocks[p] = bytes;
+        live += bytes;
+        if (live > peak_live) peak_live = live;
+        return p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        auto it = live_blocks.find(p);
+        if (it == live_blocks.end()) throw std::runtime_error("release of unknown device block");
+        free_blocks.insert({it->second, p});
+        live -= it->second;
+        live_blocks.erase(it);
+    }
+    uint32_t* alloc_words(size_t n) { return (uint32_t*)alloc(n * 4); }
+    void* pinned_buffer(size_t bytes) {
+        if (bytes > pinned_bytes) {
+            if (pinned) VG_HIP_CHECK(hipHostFree(pinned));
+            pinned_bytes = bytes < (1u << 20) ? (1u << 20) : bytes;
+            VG_HIP_CHECK(hipHostMalloc(&pinned, pinned_bytes));
+        }
+        return pinned;
+    }
+    void sync() { VG_HIP_CHECK(hipStreamSynchronize(stream)); }
+    void check_launch(const char* what) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    }
+    // small synchronous transfers (roots, challenges, descriptors)
+    void upload(void* dst, const void* src, size_t bytes) {
+        VG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        VG_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    void download(void* dst, const void* src, size_t bytes) {
+        VG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+        VG_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    uint32_t* upload_words(const std::vector<uint32_t>& w) {
+        uint32_t* d = alloc_words(w.size());
+        upload(d, w.data(), w.size() * 4);
+        return d;
+    }
+
+  private:
+    void init_tables() {
+        std::vector<uint32_t> t(2048 * 6 + 64, 0);
+        Fp roots[28], inv_roots[28];
+        for (int i = 0; i <= 27; i++) { roots[i] = vg::two_adic_generator(i); inv_roots[i] = roots[i].inv(); }
+        for (int i = 0; i < 28; i++) { tables.roots[i] = roots[i].v; tables.inv_roots[i] = inv_roots[i].v; }
+        auto fill = [&](uint32_t* dst, int count, int first_bit, const Fp* r) {
+            for (int j = 0; j < count; j++) {
+                Fp p = Fp::one();
+                for (int b = 0; (j >> b) != 0; b++) if ((j >> b) & 1) p *= r[first_bit + b + 1];
+                dst[j] = p.v;
+            }
+        };
+        uint32_t* h = t.data();
+        fill(h, 2048, 0, roots);              // brt_lo
+        fill(h + 2048, 2048, 11, roots);      // brt_hi
+        fill(h + 4096, 32, 22, roots);        // brt_top (bits 22..26 -> roots up to index 27)
+        fill(h + 4096 + 32, 2048, 0, inv_roots);
+        fill(h + 4096 + 32 + 2048, 2048, 11, inv_roots);
+        fill(h + 4096 + 32 + 4096, 32, 22, inv_roots);
+        uint32_t* tw = h + 4096 + 32 + 4096 + 32;
+        Fp w = roots[12], wi = inv_roots[12], c = Fp::one(), ci = Fp::one();
+        for (int j = 0; j < 2048; j++) { tw[j] = c.v; tw[2048 + j] = ci.v; c *= w; ci *= wi; }
+        VG_HIP_CHECK(hipMalloc((void**)&table_mem, t.size() * 4));
+        VG_HIP_CHECK(hipMemcpy(table_mem, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        tables.brt_lo = table_mem;
+        tables.brt_hi = table_mem + 2048;
+        tables.brt_top = table_mem + 4096;
+        tables.ibrt_lo = table_mem + 4096 + 32;
+        tables.ibrt_hi = table_mem + 4096 + 32 + 2048;
+        tables.ibrt_top = table_mem + 4096 + 32 + 4096;
+        tables.tw12 = table_mem + 4096 + 32 + 4096 + 32;
+        tables.itw12 = tables.tw12 + 2048;
+    }
+};
+
+// Column-major Montgomery matrix in HBM.
+struct DMat {
+    DeviceCtx* ctx = nullptr;
+    uint32_t* data = nullptr;
+    uint64_t height = 0, width = 0;
+    DMat() {}
+    DMat(DeviceCtx* c, uint64_t h, uint64_t w) : ctx(c), data(c->alloc_words(h * w)), height(h), width(w) {}
+    DMat(DMat&& o) noexcept { *this = std::move(o); }
+    DMat& operator=(DMat&& o) noexcept {
+        if (this != &o) { reset(); ctx = o.ctx; data = o.data; height = o.height; width = o.width; o.data = nullptr; o.ctx = nullptr; }
+        return *this;
+    }
+    DMat(const DMat&) = delete;
+    DMat& operator=(const DMat&) = delete;
+    ~DMat() { reset(); }
+    void reset() { if (data && ctx) ctx->release(data); data = nullptr; }
+    vk::DMatView view() const { return vk::DMatView{data, height, width, height}; }
+    bool empty() const { return data == nullptr; }
+};
+
+// RAII device word buffer
+struct DBuf {
+    DeviceCtx* ctx = nullptr;
+    uint32_t* data = nullptr;
+    size_t words = 0;
+    DBuf() {}
+    DBuf(DeviceCtx* c, size_t n) : ctx(c), data(c->alloc_words(n)), words(n) {}
+    DBuf(DeviceCtx* c, const std::vector<uint32_t>& w) : ctx(c), data(c->upload_words(w)), words(w.size()) {}
+    DBuf(DBuf&& o) noexcept { *this = std::move(o); }
+    DBuf& operator=(DBuf&& o) noexcept {
+        if (this != &o) { reset(); ctx = o.ctx; data = o.data; words = o.words; o.data = nullptr; o.ctx = nullptr; }
+        return *this;
+    }
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf() { reset(); }
+    void reset() { if (data && ctx) ctx->release(data); data = nullptr; }
+};
+
+inline void put_ext(std::vector<uint32_t>& w, const Ext5& e) { for (int k = 0; k < 5; k++) w.push_back(e.c[k].v); }
+inline void put_ptr(std::vector<uint32_t>& w, const void* p) { uint64_t v = (uint64_t)p; w.push_back((uint32_t)v); w.push_back((uint32_t)(v >> 32)); }
+inline void put_u64(std::vector<uint32_t>& w, uint64_t v) { w.push_back((uint32_t)v); w.push_back((uint32_t)(v >> 32)); }
+
+}  // namespace vhost

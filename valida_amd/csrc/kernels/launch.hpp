@@ -1,0 +1,49 @@
+// Host-callable launchers of the gfx950 kernels (definitions in the .hip files of this directory).
+#pragma once
+#include "device_common.hpp"
+#include "../air/symbolic.hpp"
+
+namespace vk {
+
+struct QuotientArgs {
+    DMatView main_lde, perm_lde, prep_lde;  // bit-reversed LDEs (prep_lde.data may be null)
+    int log_n;                               // trace height 2^log_n; quotient domain 2^(log_n + 1)
+    const vair::Instr* prog;
+    uint32_t n_instrs, n_regs, n_air_asserts;
+    const uint32_t* iw;          // encoded interactions
+    const uint32_t* consts;      // Ext5 words: [K alpha powers][M bus alphas][max_fields betas][cumulative_sum]
+    uint32_t K;                  // total number of folded constraints = n_air_asserts + M + 3
+    uint32_t coset_shift, coset_shift_inv;      // s = 31 (Montgomery), s^-1
+    uint32_t zh_inv[2];          // 1/(s^n - 1), 1/(-s^n - 1)   (Z_H on the two cosets of the quotient domain)
+    uint32_t zh[2];              // s^n - 1, -s^n - 1
+    uint32_t g_inv;              // g_n^{-1}  (subgroup_last)
+    DMatView out;                // n x 10, row for natural i stored at position bitrev_k(i)
+};
+
+
+// layout.hip
+void launch_ingest(hipStream_t st, const uint32_t* src_dev, DMatView dst, bool bitrev);
+void launch_bitrev_rows(hipStream_t st, DMatView src, DMatView dst);
+void launch_export_rows(hipStream_t st, DMatView src, uint64_t row0, uint64_t nrows, uint32_t* dst_dev);
+// ntt.hip
+void launch_intt(hipStream_t st, DMatView m, const DeviceTables& tb);
+void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t dst_row0, Fp shift, const DeviceTables& tb);
+// merkle.hip
+void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);
+void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next);
+// perm.hip
+uint64_t perm_scratch_words(uint64_t n);
+void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,
+                       uint32_t* scratch);
+// quotient.hip
+void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& tb);
+// open.hip
+void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w);
+uint64_t col_dot_slots(uint64_t n);
+void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
+                    const uint32_t* scale5_dev, uint32_t* out_dev);
+void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out);
+void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
+void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst);
+
+}  // namespace vk

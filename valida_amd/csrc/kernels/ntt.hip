@@ -1,0 +1,208 @@
+// Column-batched radix-2 NTT / coset low-degree extension over BabyBear for gfx950.
+//
+// Realises `pcs.commit_batches` / `commit_shifted_batches`'s LDE step (basic/src/lib.rs:199,223,258,599 ->
+// Plonky3 TwoAdicFriPcs: coset_lde_batch(m, log_blowup, 31/shift_i) then bit_reverse_rows; SURVEY.md
+// App. B3/B4, kernel K2).  Per column of height N = 2^k:
+//   coefficients = iDFT_N(evals)                       (in-place DIT: bit-reversed-position in, natural out)
+//   for each coset t < b = 2^log_blowup:
+//       block bitrev_lb(t) of the LDE = DIF-NTT_N( c_i * (s * w_{bN}^t)^i )   (natural in, bit-reversed out)
+// so the committed bit-reversed LDE is produced directly, with no permutation pass.
+//
+// Sizes above 2^12 points use the two-pass ("four-step") split N = N_hi * N_lo, N_lo = 2^12:
+//   inverse: [contiguous DIT over N_lo] * w_N^{-bitrev(h) r}  ->  [strided DIT over N_hi] * 1/N
+//   forward: c * shift^i -> [strided DIF over N_hi] * w_N^{r bitrev(h')}  ->  [contiguous DIF over N_lo]
+// Every pass stages its tile in LDS (160 KiB/CU), reads/writes HBM once, twiddles come from an 8 KiB
+// L1-resident table.  No MFMA: 31-bit modular butterflies are VALU work; the passes are HBM-bound.
+#include "launch.hpp"
+
+namespace vk {
+
+// In-LDS radix-2 stages along the h dimension of a tile: element (h, c) at buf[h * LD + c], c < T = 1 << logT.
+__device__ __forceinline__ void tile_dit(uint32_t* buf, int logn, int logT, int LD, const uint32_t* __restrict__ tw) {
+    const int total = ((1 << logn) >> 1) << logT;
+    const int maskT = (1 << logT) - 1;
+    for (int s = 1; s <= logn; s++) {
+        const int half = 1 << (s - 1);
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            int c = e & maskT, p = e >> logT;
+            int j = p & (half - 1);
+            int i0 = ((p >> (s - 1)) << s) + j, i1 = i0 + half;
+            Fp w = Fp::raw(tw[j << (12 - s)]);
+            Fp u = Fp::raw(buf[i0 * LD + c]), v = Fp::raw(buf[i1 * LD + c]) * w;
+            buf[i0 * LD + c] = (u + v).v;
+            buf[i1 * LD + c] = (u - v).v;
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void tile_dif(uint32_t* buf, int logn, int logT, int LD, const uint32_t* __restrict__ tw) {
+    const int total = ((1 << logn) >> 1) << logT;
+    const int maskT = (1 << logT) - 1;
+    for (int s = logn; s >= 1; s--) {
+        const int half = 1 << (s - 1);
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            int c = e & maskT, p = e >> logT;
+            int j = p & (half - 1);
+            int i0 = ((p >> (s - 1)) << s) + j, i1 = i0 + half;
+            Fp w = Fp::raw(tw[j << (12 - s)]);
+            Fp u = Fp::raw(buf[i0 * LD + c]), v = Fp::raw(buf[i1 * LD + c]);
+            buf[i0 * LD + c] = (u + v).v;
+            buf[i1 * LD + c] = ((u - v) * w).v;
+        }
+        __syncthreads();
+    }
+}
+
+// prod_{bit i of h} table[base + i]
+__device__ __forceinline__ Fp bit_product(const uint32_t* table, int base, uint32_t h) {
+    Fp r = Fp::one();
+    for (int i = 0; h; i++, h >>= 1) if (h & 1) r *= Fp::raw(table[base + i]);
+    return r;
+}
+
+// ---- inverse, contiguous pass: grid = (N / N_lo, columns) --------------------------------------------
+// In place on `data` (column-major, height N = 2^k).  k_lo = min(k, 12) stages on each contiguous block
+// of N_lo points.  If k_hi > 0 multiplies element r of block h by w_N^{-bitrev(h) * r}; else scales by 1/N.
+__global__ void k_intt_contig(DMatView m, int k, int k_lo, DeviceTables tb, uint32_t n_inv_mont) {
+    extern __shared__ uint32_t lds[];
+    const int n_lo = 1 << k_lo, k_hi = k - k_lo;
+    uint32_t* col = m.col(blockIdx.y) + (uint64_t)blockIdx.x * n_lo;
+    for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[i] = col[i];
+    __syncthreads();
+    tile_dit(lds, k_lo, 0, 1, tb.itw12);
+    if (k_hi > 0) {
+        Fp base = bit_product(tb.inv_roots, k_lo + 1, blockIdx.x);  // w_N^{-bitrev_{k_hi}(h)}
+        Fp step = base.pow(blockDim.x), cur = base.pow(threadIdx.x);
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { col[i] = (Fp::raw(lds[i]) * cur).v; cur *= step; }
+    } else {
+        Fp ninv = Fp::raw(n_inv_mont);
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) col[i] = (Fp::raw(lds[i]) * ninv).v;
+    }
+}
+
+// ---- inverse, strided pass: grid = (N_lo / T, columns) -----------------------------------------------
+// Tile = all N_hi values of h for T consecutive r; DIT over h; scale by 1/N.
+__global__ void k_intt_strided(DMatView m, int k, int k_lo, int logT, DeviceTables tb, uint32_t n_inv_mont) {
+    extern __shared__ uint32_t lds[];
+    const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
+    const uint64_t n_lo = 1ull << k_lo;
+    uint32_t* col = m.col(blockIdx.y) + (uint64_t)blockIdx.x * T;
+    const int total = n_hi << logT;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; lds[h * LD + c] = col[h * n_lo + c]; }
+    __syncthreads();
+    tile_dit(lds, k_hi, logT, LD, tb.itw12);
+    Fp ninv = Fp::raw(n_inv_mont);
+    for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; col[h * n_lo + c] = (Fp::raw(lds[h * LD + c]) * ninv).v; }
+}
+
+// ---- forward, strided pass: grid = (N_lo / T, columns) -----------------------------------------------
+// Reads coefficients c_i (natural, column-major `src`), multiplies by shift^i, DIF over h, multiplies the
+// value at (h', r) by w_N^{r * bitrev(h')}, writes to `dst` (one N-row block of the LDE).
+__global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, int logT, DeviceTables tb,
+                              uint32_t shift_mont) {
+    extern __shared__ uint32_t lds[];
+    const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
+    const uint64_t n_lo = 1ull << k_lo, r0 = (uint64_t)blockIdx.x * T;
+    const uint32_t* in = src.col(blockIdx.y) + r0;
+    uint32_t* out = dst.col(blockIdx.y) + dst_row0 + r0;
+    const int total = n_hi << logT;
+    {
+        // element e = h*T + c has exponent i = h*N_lo + r0 + c; a thread's c is fixed when blockDim % T == 0
+        Fp shift = Fp::raw(shift_mont);
+        int c = threadIdx.x & (T - 1), h0 = threadIdx.x >> logT, hstep = blockDim.x >> logT;
+        Fp cur = shift.pow((uint64_t)h0 * n_lo + r0 + c), step = shift.pow((uint64_t)hstep * n_lo);
+        for (int h = h0; h < n_hi; h += hstep) { lds[h * LD + c] = (Fp::raw(in[h * n_lo + c]) * cur).v; cur *= step; }
+    }
+    __syncthreads();
+    tile_dif(lds, k_hi, logT, LD, tb.tw12);
+    // twiddle: thread per row h', running product over the T consecutive r
+    for (int h = threadIdx.x; h < n_hi; h += blockDim.x) {
+        Fp base = bit_product(tb.roots, k_lo + 1, (uint32_t)h);  // w_N^{bitrev_{k_hi}(h')}
+        Fp cur = base.pow(r0);
+        for (int c = 0; c < T; c++) { lds[h * LD + c] = (Fp::raw(lds[h * LD + c]) * cur).v; cur *= base; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; out[h * n_lo + c] = lds[h * LD + c]; }
+}
+
+// ---- forward, contiguous pass: grid = (N / N_lo, columns) --------------------------------------------
+// DIF over each contiguous block of N_lo points of `dst` rows [dst_row0, dst_row0 + N).  When the whole
+// transform fits one pass (k_hi == 0) the input is read from `src` and multiplied by shift^i first.
+__global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, DeviceTables tb, uint32_t shift_mont,
+                             int from_src) {
+    extern __shared__ uint32_t lds[];
+    const int n_lo = 1 << k_lo;
+    uint32_t* out = dst.col(blockIdx.y) + dst_row0 + (uint64_t)blockIdx.x * n_lo;
+    if (from_src) {
+        const uint32_t* in = src.col(blockIdx.y);
+        Fp shift = Fp::raw(shift_mont);
+        Fp cur = shift.pow(threadIdx.x), step = shift.pow(blockDim.x);
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { lds[i] = (Fp::raw(in[i]) * cur).v; cur *= step; }
+    } else {
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[i] = out[i];
+    }
+    __syncthreads();
+    tile_dif(lds, k_lo, 0, 1, tb.tw12);
+    for (int i = threadIdx.x; i < n_lo; i += blockDim.x) out[i] = lds[i];
+}
+
+// ---- host launchers -----------------------------------------------------------------------------------
+struct NttPlan { int k, k_lo, k_hi, logT; unsigned threads_contig, threads_strided; size_t lds_contig, lds_strided; };
+static NttPlan make_plan(int k) {
+    NttPlan p;
+    p.k = k; p.k_lo = k < 12 ? k : 12; p.k_hi = k - p.k_lo;
+    int t = 16384 >> p.k_hi; if (t > 64) t = 64; if (t < 8) t = 8;
+    if ((1 << p.k_lo) < t) t = 1 << p.k_lo;
+    p.logT = 0; while ((1 << p.logT) < t) p.logT++;
+    unsigned n_lo = 1u << p.k_lo;
+    p.threads_contig = n_lo / 4 < 64 ? 64 : (n_lo / 4 > 1024 ? 1024 : n_lo / 4);
+    unsigned tile = (1u << p.k_hi) << p.logT;
+    p.threads_strided = tile / 4 < 64 ? 64 : (tile / 4 > 1024 ? 1024 : tile / 4);
+    if (p.threads_strided < (1u << p.logT)) p.threads_strided = 1u << p.logT;
+    p.lds_contig = (size_t)n_lo * 4;
+    p.lds_strided = (size_t)(1u << p.k_hi) * ((1u << p.logT) + 1) * 4;
+    return p;
+}
+
+static void set_lds_limit() {
+    static bool done = false;
+    if (done) return;
+    const int lim = 160 * 1024;
+    (void)hipFuncSetAttribute((const void*)k_intt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_intt_contig, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_ntt_contig, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    done = true;
+}
+
+// In-place inverse NTT of every column of `m` (height 2^k).  Input rows must be at bit-reversed positions.
+void launch_intt(hipStream_t st, DMatView m, const DeviceTables& tb) {
+    set_lds_limit();
+    int k = (int)vg::log2_strict_u64(m.height);
+    NttPlan p = make_plan(k);
+    uint32_t ninv = Fp::from_canonical((uint32_t)(m.height % vg::P)).inv().v;
+    dim3 gc((unsigned)(m.height >> p.k_lo), (unsigned)m.width);
+    hipLaunchKernelGGL(k_intt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, m, k, p.k_lo, tb, ninv);
+    if (p.k_hi > 0) {
+        dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)m.width);
+        hipLaunchKernelGGL(k_intt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, m, k, p.k_lo, p.logT, tb, ninv);
+    }
+}
+
+// dst rows [dst_row0, dst_row0 + N) <- bit-reversed-order evaluations of the polynomials with natural
+// coefficients `coeffs` on the coset shift * H_N.
+void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t dst_row0, Fp shift, const DeviceTables& tb) {
+    set_lds_limit();
+    int k = (int)vg::log2_strict_u64(coeffs.height);
+    NttPlan p = make_plan(k);
+    dim3 gc((unsigned)(coeffs.height >> p.k_lo), (unsigned)coeffs.width);
+    if (p.k_hi > 0) {
+        dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)coeffs.width);
+        hipLaunchKernelGGL(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, shift.v);
+        hipLaunchKernelGGL(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0);
+    } else {
+        hipLaunchKernelGGL(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1);
+    }
+}
+
+}  // namespace vk

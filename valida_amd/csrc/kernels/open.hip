@@ -1,0 +1,199 @@
+// Opening-phase kernels realising `pcs.open_multi_batches`
+// (basic/src/lib.rs:611-619 -> Plonky3 TwoAdicFriPcs; conventions SURVEY.md App. B9/B10):
+//   * barycentric evaluation of every committed column at the opening points,
+//   * reduced openings per LDE height (each LDE is read ONCE for all of its points),
+//   * FRI folding,
+//   * query gathers (matrix rows + Merkle sibling paths).
+//
+// Ext5 vectors of length L (reduced openings, FRI layers) live in "pair layout": a column-major
+// (L/2) x 10 matrix whose row r holds f[2r] (columns 0-4) and f[2r+1] (columns 5-9) — exactly the
+// matrix ExtensionMmcs commits for a FRI layer (App. B10), so layer trees hash it without reshaping.
+#include "launch.hpp"
+
+namespace vk {
+
+// ---- barycentric weights --------------------------------------------------------------------------
+// The first n storage rows of a bit-reversed LDE are the evaluations on s*H_n in bit-reversed order:
+// row j <-> x_j = s * r_j, r_j = w_n^{bitrev(j)}.  p(z) = scale * sum_j y_j * r_j / (z - s r_j) with
+// scale = (z^n - s^n) / (n s^{n-1}) applied on the host.  w: 5 columns of height n (stride n).
+__global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t* __restrict__ z5, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ w) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Fp r = domain_point(tb, (uint32_t)j);
+    Ext5 z = ext_from_words(z5);
+    Ext5 d = z - Fp::raw(shift) * r;
+    store_ext(w, n, j, d.inv() * r);
+}
+
+// ---- column dot products --------------------------------------------------------------------------
+// partial[(chunk * n_waves + wave), col, point, limb] = sum over the wave's rows of M[row][col] * w_point[row].
+// grid.x = row chunks of BARY_ROWS rows; each thread owns BARY_R rows (weights kept in registers) and
+// loops over all columns; per column one wave-level butterfly reduction.
+constexpr int BARY_R = 4, BARY_THREADS = 256, BARY_ROWS = BARY_R * BARY_THREADS;
+
+__device__ __forceinline__ Fp wave_sum(Fp v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += Fp::raw((uint32_t)__shfl_xor((int)v.v, off, 64));
+    return v;
+}
+
+template <int NP>
+__global__ void __launch_bounds__(BARY_THREADS) k_col_dot(DMatView m, uint64_t n, const uint32_t* __restrict__ w0, const uint32_t* __restrict__ w1, uint32_t* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * BARY_ROWS;
+    Ext5 wt[NP][BARY_R];
+    bool valid[BARY_R];
+#pragma unroll
+    for (int i = 0; i < BARY_R; i++) {
+        uint64_t row = base + (uint64_t)i * BARY_THREADS + threadIdx.x;
+        valid[i] = row < n;
+        wt[0][i] = valid[i] ? load_ext(w0, n, row) : Ext5::zero();
+        if (NP > 1) wt[NP - 1][i] = valid[i] ? load_ext(w1, n, row) : Ext5::zero();
+    }
+    const uint64_t slot = (uint64_t)blockIdx.x * (BARY_THREADS / 64) + wave;
+    for (uint64_t c = 0; c < m.width; c++) {
+        const uint32_t* col = m.col(c);
+        Fp v[BARY_R];
+#pragma unroll
+        for (int i = 0; i < BARY_R; i++) v[i] = valid[i] ? Fp::raw(col[base + (uint64_t)i * BARY_THREADS + threadIdx.x]) : Fp::zero();
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                Fp acc = Fp::zero();
+#pragma unroll
+                for (int i = 0; i < BARY_R; i++) acc += v[i] * wt[p][i].c[k];
+                acc = wave_sum(acc);
+                if (lane == 0) partial[((slot * m.width + c) * NP + p) * 5 + k] = acc.v;
+            }
+        }
+    }
+}
+
+// out[(col * NP + p) * 5 + k] = canonical( scale_p * sum_slots partial[...] )
+__global__ void k_col_dot_finish(const uint32_t* __restrict__ partial, uint64_t n_slots, uint64_t width, int NP, const uint32_t* __restrict__ scale5 /* NP x 5 */,
+                                 uint32_t* __restrict__ out) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (col, p)
+    if (idx >= width * NP) return;
+    uint64_t c = idx / NP;
+    int p = (int)(idx % NP);
+    Ext5 acc = Ext5::zero();
+    for (uint64_t s = 0; s < n_slots; s++) acc += ext_from_words(partial + ((s * width + c) * NP + p) * 5);
+    acc = acc * ext_from_words(scale5 + 5 * p);
+    for (int k = 0; k < 5; k++) out[idx * 5 + k] = acc.c[k].canonical();
+}
+
+// ---- reduced openings -----------------------------------------------------------------------------
+// Descriptor (u32 words, uniform loads) for one LDE height:
+//   [0] n_mats  [1] n_points  [2] max_width
+//   [3 .. 3 + 5*n_points)                       distinct opening points z_p (Ext5, Montgomery)
+//   then alpha powers alpha^c, c < max_width      (5 words each)
+//   then per matrix: [col_ptr_lo] [col_ptr_hi] [stride_lo] [stride_hi] [width] [n_pts]
+//                    then n_pts x { [point slot] [coef: alpha^offset (5)] [Y = sum_c alpha^c y_c (5)] }
+// ro[j] = sum_p 1/(z_p - x_j) * sum_{(mat, p)} coef * (Y - sum_c alpha^c M[j][c])      (App. B9)
+// Output in pair layout: `out` is (L/2) x 10 column-major with stride L/2.
+constexpr int MAX_OPEN_POINTS = 4;
+
+__global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restrict__ desc, uint64_t L, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ out) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= L) return;
+    const uint32_t n_mats = desc[0], n_points = desc[1], max_w = desc[2];
+    const uint32_t* zs = desc + 3;
+    const uint32_t* apow = zs + 5 * n_points;
+    const uint32_t* md = apow + 5 * max_w;
+    Ext5 S[MAX_OPEN_POINTS];
+#pragma unroll
+    for (int p = 0; p < MAX_OPEN_POINTS; p++) S[p] = Ext5::zero();
+    for (uint32_t mi = 0; mi < n_mats; mi++) {
+        const uint32_t* colp = reinterpret_cast<const uint32_t*>(((uint64_t)md[1] << 32) | md[0]);
+        const uint64_t stride = ((uint64_t)md[3] << 32) | md[2];
+        const uint32_t width = md[4], npts = md[5];
+        md += 6;
+        Ext5 rr = Ext5::zero();
+        for (uint32_t c = 0; c < width; c++) rr += ext_from_words(apow + 5 * c) * Fp::raw(colp[(uint64_t)c * stride + j]);
+        for (uint32_t q = 0; q < npts; q++, md += 11) {
+            Ext5 t = ext_from_words(md + 1) * (ext_from_words(md + 6) - rr);
+            const uint32_t slot = md[0];
+#pragma unroll
+            for (int p = 0; p < MAX_OPEN_POINTS; p++) if ((uint32_t)p == slot) S[p] += t;
+        }
+    }
+    Fp x = Fp::raw(shift) * domain_point(tb, (uint32_t)j);
+    Ext5 ro = Ext5::zero();
+#pragma unroll
+    for (int p = 0; p < MAX_OPEN_POINTS; p++)
+        if ((uint32_t)p < n_points) ro += S[p] * (ext_from_words(zs + 5 * p) - x).inv();
+    const uint64_t half = L >> 1;
+    store_ext(out + (j & 1) * 5 * half, half, j >> 1, ro);
+}
+
+// ---- FRI fold ---------------------------------------------------------------------------------------
+// in: (L/2) x 10 pair layout (stride L/2).  out[i] = (f0 + f1)/2 + (beta/2) x_i^{-1} (f0 - f1) [+ add[i]],
+// x_i^{-1} = w_L^{-bitrev(i)} (no coset shift inside FRI), written in pair layout of length L/2.
+__global__ void __launch_bounds__(256) k_fri_fold(const uint32_t* __restrict__ in, uint64_t L, const uint32_t* __restrict__ beta5, const uint32_t* __restrict__ add,
+                           DeviceTables tb, uint32_t* __restrict__ out) {
+    const uint64_t half = L >> 1;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    Ext5 f0 = load_ext(in, half, i), f1 = load_ext(in + 5 * half, half, i);
+    Ext5 beta = ext_from_words(beta5);
+    Fp xinv = inv_domain_point(tb, (uint32_t)i);
+    Ext5 r = (f0 + f1) + beta * ((f0 - f1) * xinv);
+#pragma unroll
+    for (int k = 0; k < 5; k++) r.c[k] = r.c[k].halve();
+    const uint64_t q = half >> 1;  // rows of the output pair matrix (0 when the output has a single element)
+    if (q == 0) {                   // L == 2: single output element, stored as a 1-element "vector" in slot 0
+        if (add) r += load_ext(add, 1, 0);
+        store_ext(out, 1, 0, r);
+        return;
+    }
+    uint32_t* o = out + (i & 1) * 5 * q;
+    if (add) r += load_ext(add + (i & 1) * 5 * q, q, i >> 1);
+    store_ext(o, q, i >> 1, r);
+}
+
+// ---- gathers ----------------------------------------------------------------------------------------
+// Descriptor = 6 words: [ptr_lo] [ptr_hi] [stride_lo] [stride_hi] [count | kind << 28] [dst offset (words)]
+//   kind 0: Montgomery elements src[k * stride], k < count  -> canonical
+//   kind 1: raw words src[k * stride]                        -> copied
+__global__ void k_gather(const uint32_t* __restrict__ desc, uint64_t n_desc, uint32_t* __restrict__ dst) {
+    uint64_t d = (uint64_t)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);  // 32 lanes per descriptor
+    if (d >= n_desc) return;
+    const uint32_t* e = desc + 6 * d;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(((uint64_t)e[1] << 32) | e[0]);
+    const uint64_t stride = ((uint64_t)e[3] << 32) | e[2];
+    const uint32_t count = e[4] & 0x0fffffffu, kind = e[4] >> 28;
+    uint32_t* o = dst + e[5];
+    for (uint32_t k = threadIdx.x & 31; k < count; k += 32) {
+        uint32_t v = src[(uint64_t)k * stride];
+        o[k] = kind == 0 ? Fp::raw(v).canonical() : v;
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------
+void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w) {
+    hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, z5_dev, shift.v, tb, w);
+}
+uint64_t col_dot_slots(uint64_t n) { return ((n + BARY_ROWS - 1) / BARY_ROWS) * (BARY_THREADS / 64); }
+// m: LDE (only rows < n are read).  np = 1 or 2 points.  partial: col_dot_slots(n) * width * np * 5 words.
+void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
+                    const uint32_t* scale5_dev, uint32_t* out_dev) {
+    unsigned chunks = (unsigned)((n + BARY_ROWS - 1) / BARY_ROWS);
+    if (np == 1) hipLaunchKernelGGL(k_col_dot<1>, dim3(chunks), dim3(BARY_THREADS), 0, st, m, n, w0, w1, partial);
+    else hipLaunchKernelGGL(k_col_dot<2>, dim3(chunks), dim3(BARY_THREADS), 0, st, m, n, w0, w1, partial);
+    uint64_t items = m.width * np;
+    hipLaunchKernelGGL(k_col_dot_finish, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, partial, col_dot_slots(n), m.width, np, scale5_dev, out_dev);
+}
+void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out) {
+    hipLaunchKernelGGL(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out);
+}
+void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
+    uint64_t half = L >> 1;
+    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, L, beta5_dev, add, tb, out);
+}
+void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst) {
+    if (!n_desc) return;
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n_desc + 7) / 8)), dim3(256), 0, st, desc_dev, n_desc, dst);
+}
+
+}  // namespace vk

@@ -1,0 +1,115 @@
+// Permutation (LogUp bus) trace generation on the device, realising
+// generate_permutation_trace (machine/src/chip.rs:121-208) + reduce_row (:335-352) +
+// batch_multiplicative_inverse_allowing_zero (util/src/lib.rs:21-43):
+//   q[n][m] = 1 / (alpha_bus(m) + sum_j beta^j f_{m,j}(row n))        (0 stays 0)
+//   phi[n]  = phi[n-1] + sum_m (+/-) mult_m(row n) * q[n][m]           (+ sends, - receives)
+// Output: column-major n x 5(M+1) base matrix = flatten_to_base of the Ext5 trace, NATURAL row order.
+// The reference's row-serial prefix loop (:178-201) becomes a 3-phase block scan (Ext5 addition is five
+// independent base-field additions).  Ext5 inversion is per element (Frobenius norm -> one base pow):
+// identical values to the reference's batch inversion, exact arithmetic.
+#include "launch.hpp"
+#include "interactions.hpp"
+
+namespace vk {
+
+// chal: M x 5 words (alpha_bus per interaction) followed by max_fields x 5 words (beta^j), Montgomery.
+__global__ void __launch_bounds__(256) k_perm_recip(DMatView main, DMatView prep, const uint32_t* __restrict__ iw, const uint32_t* __restrict__ chal, DMatView perm) {
+    uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= main.height) return;
+    const uint32_t M = iw[0];
+    const uint32_t* betas = chal + 5 * M;
+    Ext5 delta = Ext5::zero();
+    for (uint32_t m = 0; m < M; m++) {
+        uint32_t pos = iw[2 + m];
+        const bool is_send = iw[pos] != 0;
+        const uint32_t nf = iw[pos + 1];
+        pos += 2;
+        Fp mult = eval_vcol(iw, pos, main.data, main.stride, prep.data, prep.stride, n);
+        Ext5 rlc = ext_from_words(chal + 5 * m);
+        for (uint32_t j = 0; j < nf; j++) {
+            Fp f = eval_vcol(iw, pos, main.data, main.stride, prep.data, prep.stride, n);
+            rlc += ext_from_words(betas + 5 * j) * f;
+        }
+        Ext5 q = rlc.inv();  // inv(0) = 0
+        store_ext(perm.data + (uint64_t)(5 * m) * perm.stride, perm.stride, n, q);
+        Ext5 term = q * mult;
+        delta = is_send ? delta + term : delta - term;
+    }
+    store_ext(perm.data + (uint64_t)(5 * M) * perm.stride, perm.stride, n, delta);
+}
+
+// ---- inclusive prefix sum of a base-field column (blockIdx.y selects the column) ----------------------
+constexpr int SCAN_ITEMS = 4, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;
+
+__device__ __forceinline__ Fp block_exclusive_scan(Fp v, uint32_t* lds, Fp* total) {
+    // Hillis-Steele over blockDim.x values
+    lds[threadIdx.x] = v.v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        Fp t = Fp::raw(lds[threadIdx.x]);
+        if ((int)threadIdx.x >= off) t += Fp::raw(lds[threadIdx.x - off]);
+        __syncthreads();
+        lds[threadIdx.x] = t.v;
+        __syncthreads();
+    }
+    *total = Fp::raw(lds[SCAN_THREADS - 1]);
+    Fp incl = Fp::raw(lds[threadIdx.x]);
+    __syncthreads();
+    return incl - v;
+}
+
+// phase 1: block sums
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_block_sums(const uint32_t* __restrict__ data, uint64_t stride, uint64_t n, uint32_t* __restrict__ sums, uint64_t n_blocks) {
+    __shared__ uint32_t lds[SCAN_THREADS];
+    const uint32_t* col = data + (uint64_t)blockIdx.y * stride;
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    Fp s = Fp::zero();
+    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += Fp::raw(col[base + i]);
+    Fp total;
+    block_exclusive_scan(s, lds, &total);
+    if (threadIdx.x == 0) sums[(uint64_t)blockIdx.y * n_blocks + blockIdx.x] = total.v;
+}
+// phase 2: exclusive scan of the block sums of one column by one block (n_blocks arbitrary)
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(uint32_t* __restrict__ sums, uint64_t n_blocks) {
+    __shared__ uint32_t lds[SCAN_THREADS];
+    uint32_t* s = sums + (uint64_t)blockIdx.y * n_blocks;
+    Fp carry = Fp::zero();
+    for (uint64_t base = 0; base < n_blocks; base += SCAN_THREADS) {
+        uint64_t i = base + threadIdx.x;
+        Fp v = i < n_blocks ? Fp::raw(s[i]) : Fp::zero();
+        Fp total;
+        Fp ex = block_exclusive_scan(v, lds, &total);
+        if (i < n_blocks) s[i] = (carry + ex).v;
+        carry += total;
+    }
+}
+// phase 3: in-block inclusive scan + block offset, in place
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(uint32_t* __restrict__ data, uint64_t stride, uint64_t n, const uint32_t* __restrict__ sums, uint64_t n_blocks) {
+    __shared__ uint32_t lds[SCAN_THREADS];
+    uint32_t* col = data + (uint64_t)blockIdx.y * stride;
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    Fp v[SCAN_ITEMS];
+    Fp s = Fp::zero();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = base + i < n ? Fp::raw(col[base + i]) : Fp::zero(); s += v[i]; }
+    Fp total;
+    Fp run = block_exclusive_scan(s, lds, &total) + Fp::raw(sums[(uint64_t)blockIdx.y * n_blocks + blockIdx.x]);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { run += v[i]; if (base + i < n) col[base + i] = run.v; }
+}
+
+uint64_t perm_scratch_words(uint64_t n) { return 5 * ((n + SCAN_BLOCK - 1) / SCAN_BLOCK); }
+
+// main/prep: natural-order column-major.  perm: n x 5(M+1), natural order.  scratch: >= 5 * ceil(n / SCAN_BLOCK) words.
+void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,
+                       uint32_t* scratch) {
+    uint64_t n = main.height;
+    hipLaunchKernelGGL(k_perm_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, main, prep, iw_dev, chal_dev, perm);
+    uint32_t* phi = perm.data + (uint64_t)(5 * M) * perm.stride;
+    uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb, 5), dim3(SCAN_THREADS), 0, st, phi, perm.stride, n, scratch, nb);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1, 5), dim3(SCAN_THREADS), 0, st, scratch, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb, 5), dim3(SCAN_THREADS), 0, st, phi, perm.stride, n, scratch, nb);
+}
+
+}  // namespace vk
