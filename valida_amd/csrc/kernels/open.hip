@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) k_fri_fold(const uint32_t* __restrict__ i
     if (i >= half) return;
     Ext5 f0 = load_ext(in, half, i), f1 = load_ext(in + 5 * half, half, i);
     Ext5 beta = ext_from_words(beta5);
-    Fp xinv = inv_domain_point(tb, (uint32_t)i);
+    Fp xinv = inv_domain_point(tb, (uint32_t)(2 * i));  // f[2i], f[2i+1] sit at +-x, x = w_L^{bitrev_L(2i)}
     Ext5 r = (f0 + f1) + beta * ((f0 - f1) * xinv);
 #pragma unroll
     for (int k = 0; k < 5; k++) r.c[k] = r.c[k].halve();
