@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Headline benchmark: proofs/sec of Machine::prove on the 2^20-row Fibonacci trace (BASELINE.json
+configs[1] = workload C2 of SURVEY.md §8), one proof per GPU per step.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete proof per rank (from HBM-resident main traces to the assembled proof words on
+the host) + one RCCL all-gather of the three 32-byte commitment roots over xGMI when N > 1 (segments are
+independent).  Rank 0 prints ONE JSON line.  Scaling is weak (one segment per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Fibonacci loop bound giving 17 + 7n = 2^20 - 1 executed cycles.
+FIB_N = {20: 149794, 19: 74895, 18: 37446, 17: 18722, 16: 9359, 14: 2338, 12: 582}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_proof(shapes, log_blowup=1):
+    """SURVEY.md §8(d) B_alg: compulsory HBM traffic of one proof, each array once per logical pass."""
+    b, q, D = 1 << log_blowup, 2, 5
+    main = sum(n * w for n, w, _ in shapes)
+    perm = sum(n * 5 * (m + 1) for n, _, m in shapes)
+    quot = sum(n * 10 for n, _, _ in shapes)
+    prep = 32 * 7 + 256
+    E = main + perm + quot
+    sum_n = sum(n for n, _, _ in shapes)
+    L = b * max(n for n, _, _ in shapes)
+    heights = sorted({n for n, _, _ in shapes})
+    total = 4 * E + 4 * b * E + 4 * b * E + 3 * (4 * 32 * L) + 4 * (main + perm) + 4 * q * (main + perm + prep) + 4 * D * q * sum_n
+    total += (4 * D * q * sum_n + 4 * quot) + 4 * b * E + 4 * D * sum(b * n for n in heights) + 2 * (4 * D * 2 * L) + 2 * (2 * (L // 2) * 32 * 2)
+    return float(total)
+
+
+def segment_loop_bound(log_rows, rank):
+    """Independent segments: rank r proves fib with a distinct loop bound and the same padded shape."""
+    n = FIB_N[log_rows] - rank
+    assert 17 + 7 * n > (1 << (log_rows - 1)), "too many ranks for this trace size"
+    return n
+
+
+def exchange_roots(dist, torch, commitments24, device):
+    """The one collective of the path: all-gather of each segment's three 8-word Merkle roots (96 B per
+    rank; RCCL over xGMI with the nccl backend, gloo in the CPU tests).  Returns a [world, 24] int64 array."""
+    world = dist.get_world_size()
+    local = torch.from_numpy(np.asarray(commitments24, dtype=np.int64)).to(device)
+    out = torch.zeros(24 * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, local)
+    return out.reshape(world, 24)
+
+
+def cpu_baseline(log_rows, rc):
+    """Oracle (CPU restatement, OpenMP) timed on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    import valida_amd as va
+
+    w = va.Workload.fib(FIB_N[log_rows])
+    prep = w.preprocessed()
+    res = po.prove_basic(w.main_traces(), prep[0][1], prep[1][1], rc)
+    # scale proofs/sec linearly in trace rows to the 2^20-row workload (n log n work: optimistic for the CPU)
+    scale = float(1 << (20 - log_rows))
+    return {
+        "value": 1.0 / (res.seconds * scale),
+        "unit": "proofs/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": "oracle (C++/OpenMP restatement, not Plonky3) proving fib with 2^%d cpu rows in %.2f s, scaled x%d to 2^20 rows" % (log_rows, res.seconds, int(scale)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-rows", type=int, default=20, help="log2 of the padded CPU-chip height (20 = the headline workload)")
+    ap.add_argument("--cpu-log-rows", type=int, default=17, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import valida_amd as va
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    rc = va.poseidon_round_constants()
+    machine = va.Machine.basic()
+    prover = va.Prover(machine, rc, device=local_rank)
+
+    # one independent segment per rank: distinct loop bounds with the same padded shape
+    n = segment_loop_bound(args.log_rows, rank)
+    t0 = time.time()
+    wl = va.Workload.fib(n)
+    t_tracegen = time.time() - t0
+    assert wl.cpu_height == 1 << args.log_rows
+    mt = wl.main_traces()
+    prep = wl.preprocessed()
+    t0 = time.time()
+    dmain = [prover.upload(m) for m in mt]
+    dprep = [(c, prover.upload(m)) for c, m in prep]
+    t_upload = time.time() - t0
+    shapes = [(m.shape[0], m.shape[1], machine.chip_info(i)["interactions"]) for i, m in enumerate(mt)]
+    upload_bytes = sum(m.nbytes for m in mt)
+
+    all_roots = [None]
+
+    def step():
+        proof = prover.prove(dmain, dprep)
+        if world > 1:
+            all_roots[0] = exchange_roots(dist, torch, proof.words[2:26], torch.device("cuda", local_rank))
+        return proof
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prover.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    phase = {}
+    for _ in range(args.steps):
+        p = step()
+        for k, v in p.phase_ms.items():
+            phase[k] = phase.get(k, 0.0) + v
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = prover.profile()
+    prover.set_profiling(False)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        # dominant kernel by accumulated HIP-event time
+        name, (launches, ms, nbytes) = max(prof.items(), key=lambda kv: kv[1][1])
+        achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        b_alg = algorithmic_bytes_per_proof(shapes, prover.log_blowup)
+        kernel_ms_total = sum(v[1] for v in prof.values()) / args.steps
+        out = {
+            "metric": "proofs/sec, 2^%d-row Fibonacci trace (BabyBear, Keccak-256 MMCS, FRI blowup 2, 40 queries)" % args.log_rows,
+            "value": value,
+            "unit": "proofs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (BabyBear mod p, Montgomery) / u64 (Keccak lanes)",
+            "data": "synthetic: fib_program(n=%d) traces generated by the in-tree VM, deterministic; Poseidon constants SplitMix64(0x56414C494441)" % n,
+            "config": {
+                "workload": "C2: Fibonacci 2^%d cpu rows (mem 2^%d), 14 chips, one proof per GPU" % (args.log_rows, args.log_rows + 2),
+                "log_blowup": prover.log_blowup, "num_queries": prover.num_queries, "pow_bits": prover.pow_bits,
+                "parallelism": "segments: one independent proof per GPU + all-gather of 3 roots" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "launches_per_step": launches / args.steps, "avg_launch_ms": ms / launches if launches else None,
+                "algorithmic_bytes_per_launch": nbytes / launches if launches else None,
+            },
+            "proof_roofline": {"algorithmic_bytes_per_proof": b_alg, "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "phase_ms": {k: v / args.steps for k, v in phase.items()},
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+            "kernel_GBs": {k: (v[2] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in prof.items()},
+            "kernel_ms_total_per_step": kernel_ms_total,
+            "outside_timed_region": {"tracegen_s": t_tracegen, "h2d_upload_s": t_upload, "h2d_bytes": upload_bytes},
+            "proof_words": int(p.words.size),
+            "hbm_pool_peak_bytes": prover.memory()[1],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_log_rows, rc)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

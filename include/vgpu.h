@@ -116,6 +116,11 @@ void vgpu_prover_destroy(vgpu_prover_t* p);
 /* bytes currently held / peak in the HBM pool */
 void vgpu_prover_memory(const vgpu_prover_t* p, uint64_t* live_bytes, uint64_t* peak_bytes);
 
+/* per-kernel HIP-event timing (bench): switch on/off (resets the accumulators); the profile is text,
+ * one line per kernel: "name launches total_ms total_algorithmic_bytes".  Returns the size needed. */
+void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on);
+int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap);
+
 /* H2D of a host RowMajorMatrix (the reference passes these by value, basic/src/lib.rs:223) */
 int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t height, uint64_t width, vgpu_trace_t** out);
 void vgpu_trace_free(vgpu_trace_t* t);

@@ -108,6 +108,27 @@ void oracle_mmcs_root(uint64_t n_mats, const uint32_t* const* mats, const uint64
     MerkleTree t = mmcs_commit(std::move(ms));
     for (int i = 0; i < 8; i++) root8[i] = t.root()[i].v;
 }
+// Direct instantiation of chip `chip`'s Air::eval on one row pair: the asserted values, in order.
+// Returns the number of constraints (out may be null to query it).
+uint32_t oracle_eval_constraints(uint32_t chip, const uint32_t* local, const uint32_t* next, const uint32_t* prep_local, const uint32_t* prep_next,
+                                 uint32_t is_first, uint32_t is_last, uint32_t is_transition, uint32_t* out, uint32_t cap) {
+    struct Rec {
+        using Expr = Fp;
+        const uint32_t *l, *n, *pl, *pn;
+        Fp first, last, trans;
+        std::vector<Fp> vals;
+        Fp constant(uint32_t k) const { return Fp(k); }
+        Fp main(int c, bool nx) const { return Fp((nx ? n : l)[c]); }
+        Fp preprocessed(int c, bool nx) const { return Fp((nx ? pn : pl)[c]); }
+        Fp is_first_row() const { return first; }
+        Fp is_last_row() const { return last; }
+        Fp is_transition() const { return trans; }
+        void assert_zero(const Fp& x) { vals.push_back(x); }
+    } b{local, next, prep_local, prep_next, Fp(is_first), Fp(is_last), Fp(is_transition), {}};
+    vchips::eval_chip((int)chip, b);
+    if (out) for (size_t i = 0; i < b.vals.size() && i < cap; i++) out[i] = b.vals[i].v;
+    return (uint32_t)b.vals.size();
+}
 uint32_t oracle_log_quotient_degree(uint32_t chip) { return log_quotient_degree(MachineDesc::basic().chips[chip]); }
 uint32_t oracle_num_interactions(uint32_t chip) { return (uint32_t)MachineDesc::basic().chips[chip].interactions.size(); }
 // generate_permutation_trace of BasicMachine chip `chip`; out is height x 5(M+1), row-major (flatten_to_base).

@@ -137,6 +137,21 @@ def perm_trace(chip, main, challenges15):
     return out
 
 
+def eval_constraints(chip, local, nxt, prep_local=None, prep_next=None, is_first=0, is_last=0, is_transition=1):
+    a, ap = _u32(local)
+    b, bp = _u32(nxt)
+    c, cp = _u32(prep_local if prep_local is not None else np.zeros(8, dtype=np.uint32))
+    d, dp = _u32(prep_next if prep_next is not None else np.zeros(8, dtype=np.uint32))
+    L = lib()
+    L.oracle_eval_constraints.restype = ctypes.c_uint32
+    n = L.oracle_eval_constraints(ctypes.c_uint32(chip), ap, bp, cp, dp, ctypes.c_uint32(is_first), ctypes.c_uint32(is_last), ctypes.c_uint32(is_transition), None,
+                                  ctypes.c_uint32(0))
+    out = np.zeros(max(1, n), dtype=np.uint32)
+    L.oracle_eval_constraints(ctypes.c_uint32(chip), ap, bp, cp, dp, ctypes.c_uint32(is_first), ctypes.c_uint32(is_last), ctypes.c_uint32(is_transition),
+                              out.ctypes.data_as(c_u32p), ctypes.c_uint32(out.size))
+    return out[:n]
+
+
 def fri_fold(f, beta5):
     a, ap = _u32(f)
     b, bp = _u32(beta5)

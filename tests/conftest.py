@@ -16,10 +16,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Both libraries are built in-tree before any test runs (hipcc cross-compiles without a GPU)."""
+    from oracle import build as obuild
     from valida_amd import build
 
     build.build_vgpu()
-    build.build_oracle()
+    obuild.build_oracle()
 
 
 @pytest.fixture(scope="session")

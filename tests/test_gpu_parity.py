@@ -137,6 +137,39 @@ def test_fib_medium_proof_bytes(prover, rc):
     assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc) is None
 
 
+@pytest.mark.parametrize("name", ["fib25_oracle.json", "fib582_oracle.json"])
+def test_gpu_proof_matches_committed_golden_fixture(prover, name):
+    import hashlib
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", name)) as f:
+        g = json.load(f)
+    w = va.Workload.fib(g["n"])
+    mt, prep = w.main_traces(), w.preprocessed()
+    assert hashlib.sha256(b"".join(m.tobytes() for m in mt)).hexdigest() == g["traces_sha256"]
+    proof = prover.prove([prover.upload(m) for m in mt], [(c, prover.upload(m)) for c, m in prep])
+    assert [int(x) for x in proof.words[2:26]] == g["commitments"]
+    assert [int(x) for x in proof.transcript] == g["transcript"]
+    assert hashlib.sha256(proof.bytes()).hexdigest() == g["proof_sha256"]
+
+
+def test_round_trip_properties_at_scale(prover, rc):
+    # size-independent properties at a size the oracle is too slow for in a unit test (cpu 2^16, mem 2^18):
+    # the oracle's restated verifier accepts the GPU proof, and a second run reproduces it bit for bit
+    w = va.Workload.fib(9359)
+    assert w.cpu_height == 1 << 16
+    mt, prep = w.main_traces(), w.preprocessed()
+    dmain = [prover.upload(m) for m in mt]
+    dprep = [(c, prover.upload(m)) for c, m in prep]
+    a = prover.prove(dmain, dprep)
+    assert po.verify_basic(prep[0][1], prep[1][1], a.words, rc) is None
+    assert prover.prove(dmain, dprep).bytes() == a.bytes()
+    bad = a.words.copy()
+    bad[a.words.size // 2] ^= 1
+    assert po.verify_basic(prep[0][1], prep[1][1], bad, rc) is not None
+
+
 def test_tampered_gpu_proof_rejected(prover, fib25, rc):
     mt = fib25.main_traces()
     prep = fib25.preprocessed()

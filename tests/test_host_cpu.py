@@ -1,0 +1,163 @@
+"""CPU tests of the product's host side (no GPU): the C ABI loads and exports what include/vgpu.h
+declares, the host transcript and the compiled constraint programs agree with the oracle, the AIR
+capture FFI works, and the product refuses to run without a device (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import valida_amd as va
+from conftest import has_gpu
+from oracle import pyoracle as po
+
+P = va.P
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vgpu.h")).read()
+    names = set(re.findall(r"\b(vgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) > 50
+    L = va.lib()
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert b"gfx950" in L.vgpu_version()
+
+
+def test_no_oracle_in_product_path():
+    # the product never imports / links the oracle
+    for base, _, files in os.walk(os.path.join(ROOT, "valida_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(base, f)).read()
+                assert "liboracle" not in src and "pyoracle" not in src and 'oracle/' not in src.replace("ORACLE", ""), os.path.join(base, f)
+    out = subprocess.run(["ldd", os.path.join(ROOT, "valida_amd", "libvgpu.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_prover_refuses_to_run_without_device(machine, rc):
+    with pytest.raises(va.VgpuError) as e:
+        va.Prover(machine, rc)
+    assert e.value.code == -3  # VGPU_ERR_HIP
+
+
+def test_poseidon_and_challenger_match_oracle(rc):
+    # product: Montgomery arithmetic + FFT-form CosetMds; oracle: canonical arithmetic + explicit matrix
+    rng = np.random.default_rng(1)
+    for _ in range(8):
+        st = rng.integers(0, P, size=16, dtype=np.uint32)
+        assert list(va.poseidon16_permute(rc, st)) == list(po.poseidon_permute(rc, st))
+    obs = rng.integers(0, P, size=37, dtype=np.uint32)
+    ch = va.Challenger(rc)
+    ch.observe(obs)
+    assert list(ch.sample(41)) == list(po.challenger_probe(rc, obs, 41))
+    ch2 = va.Challenger(rc)
+    ch2.observe(obs[:9])
+    assert ch2.grind(7) == po.grind(rc, obs[:9], 7)
+
+
+def test_sample_bits_is_low_bits_of_canonical_sample(rc):
+    a, b = va.Challenger(rc), va.Challenger(rc)
+    a.observe([1, 2, 3])
+    b.observe([1, 2, 3])
+    assert a.sample_bits(11) == int(b.sample(1)[0]) & 2047
+
+
+def test_chip_table(machine):
+    want = {  # (width, prep width, interactions, constraints)
+        0: (51, 0, 4, 53), 1: (1, 7, 0, 0), 2: (14, 0, 1, 0), 3: (16, 0, 5, 10), 4: (16, 0, 5, 7), 5: (18, 0, 1, 5), 6: (14, 0, 1, 0),
+        7: (28, 0, 2, 18), 9: (14, 0, 1, 8), 10: (79, 0, 1, 88), 11: (7, 0, 1, 3), 12: (2, 1, 1, 0), 13: (6, 0, 1, 1),
+    }
+    assert machine.num_chips == 14
+    for chip, (w, pw, m, k) in want.items():
+        info = machine.chip_info(chip)
+        assert (info["width"], info["preprocessed_width"], info["interactions"], info["constraints"]) == (w, pw, m, k), (chip, info)
+        assert info["log_quotient_degree"] == 1 and info["max_degree"] <= 3
+    assert machine.chip_info(8)["width"] == 45 and machine.chip_info(8)["constraints"] >= 55
+
+
+@pytest.mark.parametrize("chip", [0, 3, 4, 5, 7, 8, 9, 10, 11, 13])
+def test_compiled_program_equals_direct_eval(machine, chip):
+    # the lowered register program (what the quotient kernel interprets) == direct template instantiation
+    rng = np.random.default_rng(40 + chip)
+    w = machine.chip_info(chip)["width"]
+    for trial in range(6):
+        local = rng.integers(0, P, size=w, dtype=np.uint32)
+        nxt = rng.integers(0, P, size=w, dtype=np.uint32)
+        f, l, t = [int(x) for x in rng.integers(0, P, size=3)]
+        got = machine.eval_constraints(chip, local, nxt, is_first=f, is_last=l, is_transition=t)
+        want = po.eval_constraints(chip, local, nxt, is_first=f, is_last=l, is_transition=t)
+        assert list(got) == list(want)
+
+
+def test_constraints_vanish_on_the_fibonacci_trace(machine, fib25):
+    for chip in (0, 3, 5):
+        tr = fib25.main_trace(chip)
+        n = tr.shape[0]
+        for i in range(n):
+            vals = machine.eval_constraints(chip, tr[i], tr[(i + 1) % n], is_first=int(i == 0), is_last=int(i == n - 1), is_transition=int(i != n - 1))
+            assert not vals.any(), (chip, i, np.nonzero(vals)[0][:4])
+
+
+def test_air_capture_ffi_roundtrip():
+    """A host builds an AIR through the C ABI exactly as a Rust SymbolicAirBuilder shim would."""
+    L = va.lib()
+    air = ctypes.c_void_p()
+    assert L.vgpu_air_new(b"toy", ctypes.c_uint32(3), ctypes.c_uint32(0), ctypes.byref(air)) == 0
+    u = ctypes.c_uint32
+    a = L.vgpu_air_variable(air, u(0), u(0), u(0))
+    b = L.vgpu_air_variable(air, u(0), u(1), u(0))
+    c_next = L.vgpu_air_variable(air, u(0), u(2), u(1))
+    seven = L.vgpu_air_constant(air, u(7))
+    # assert a*b - 7 = 0 ; when_transition: c' - (a + b) = 0 ; assert_bool(a)
+    L.vgpu_air_assert_zero(air, u(L.vgpu_air_sub(air, u(L.vgpu_air_mul(air, u(a), u(b))), u(seven))))
+    tr = L.vgpu_air_is_transition(air)
+    L.vgpu_air_assert_zero(air, u(L.vgpu_air_mul(air, u(tr), u(L.vgpu_air_sub(air, u(c_next), u(L.vgpu_air_add(air, u(a), u(b))))))))
+    one = L.vgpu_air_constant(air, u(1))
+    L.vgpu_air_assert_zero(air, u(L.vgpu_air_mul(air, u(a), u(L.vgpu_air_sub(air, u(a), u(one))))))
+    m = ctypes.c_void_p()
+    assert L.vgpu_machine_new(ctypes.byref(m)) == 0
+    assert L.vgpu_machine_push_air(m, air) == 0
+    mach = va.Machine(m)
+    info = mach.chip_info(0)
+    assert info["constraints"] == 3 and info["max_degree"] == 2 and info["log_quotient_degree"] == 1
+    vals = mach.eval_constraints(0, np.array([3, 5, 0], dtype=np.uint32), np.array([0, 0, 9], dtype=np.uint32), is_transition=2)
+    assert list(vals) == [8, 2, 6]  # 3*5-7 ; 2*(9-8) ; 3*2
+    L.vgpu_air_free(air)
+
+
+def test_status_codes_and_error_messages():
+    L = va.lib()
+    assert L.vgpu_machine_chip_info(va.Machine.basic()._h, ctypes.c_uint32(99), (ctypes.c_uint32 * 8)()) == -1
+    assert b"chip" in L.vgpu_last_error()
+    assert L.vgpu_workload_fib(ctypes.c_uint32(5), None) == -1
+
+
+def test_workload_shapes_follow_the_survey_formulas():
+    for n in (1, 25, 100):
+        w = va.Workload.fib(n)
+        assert w.cycles == 17 + 7 * n and w.add_ops == 4 * n + 5 and w.mem_ops == 15 * n + 26
+        hs = [m.shape[0] for m in w.main_traces()]
+        assert all(h & (h - 1) == 0 for h in hs)
+        assert hs[5] == 1024 and hs[12] == 256
+    prep = va.Workload.fib(25).preprocessed()
+    assert [c for c, _ in prep] == [1, 12] and prep[0][1].shape == (32, 7) and prep[1][1].shape == (256, 1)
+    assert list(prep[1][1][:, 0]) == list(range(256))
+
+
+def test_bench_algorithmic_bytes_matches_survey():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    ms = [4, 0, 1, 5, 5, 1, 1, 2, 1, 1, 1, 1, 1, 1]
+    widths = [51, 1, 14, 16, 16, 18, 14, 28, 45, 14, 79, 7, 2, 6]
+    heights = [1 << 20, 32, 1 << 22, 1 << 20, 1, 1024, 1, 1, 1, 1, 1, 1, 256, 1]
+    b = bench.algorithmic_bytes_per_proof(list(zip(heights, widths, ms)))
+    assert abs(b / 1e9 - 16.84) < 0.02  # C2 = 16.84 GB
+    for k, n in bench.FIB_N.items():
+        assert (1 << (k - 1)) < 17 + 7 * n <= (1 << k)

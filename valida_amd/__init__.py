@@ -56,6 +56,7 @@ def lib():
         L.vgpu_challenger_sample_bits.restype = ctypes.c_uint64
         L.vgpu_proof_debug_perm_trace.restype = ctypes.c_int64
         L.vgpu_proof_debug_quotient.restype = ctypes.c_int64
+        L.vgpu_prover_profile.restype = ctypes.c_int64
         for name in ("vgpu_air_constant", "vgpu_air_variable", "vgpu_air_is_first_row", "vgpu_air_is_last_row", "vgpu_air_is_transition", "vgpu_air_add",
                      "vgpu_air_sub", "vgpu_air_mul", "vgpu_air_neg", "vgpu_machine_num_chips", "vgpu_challenger_grind"):
             getattr(L, name).restype = ctypes.c_uint32
@@ -111,7 +112,7 @@ class Workload:
     def main_trace(self, chip):
         data, h, w = c_u32p(), ctypes.c_uint64(), ctypes.c_uint64()
         _check(lib().vgpu_workload_main_trace(self._h, ctypes.c_uint32(chip), ctypes.byref(data), ctypes.byref(h), ctypes.byref(w)))
-        return np.ctypeslib.as_array(data, shape=(h.value, w.value))
+        return np.ctypeslib.as_array(data, shape=(h.value, w.value)).copy()  # the workload owns the buffer
 
     def main_traces(self):
         return [self.main_trace(i) for i in range(NUM_CHIPS)]
@@ -122,7 +123,7 @@ class Workload:
         for k in range(2):
             chip, data, h, w = ctypes.c_uint32(), c_u32p(), ctypes.c_uint64(), ctypes.c_uint64()
             _check(lib().vgpu_workload_preprocessed(self._h, ctypes.c_uint32(k), ctypes.byref(chip), ctypes.byref(data), ctypes.byref(h), ctypes.byref(w)))
-            out.append((chip.value, np.ctypeslib.as_array(data, shape=(h.value, w.value))))
+            out.append((chip.value, np.ctypeslib.as_array(data, shape=(h.value, w.value)).copy()))
         return out
 
     def __del__(self):
@@ -334,6 +335,20 @@ class Prover:
         _check(lib().vgpu_prove(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)), ctypes.c_uint32(1 if debug else 0),
                                 ctypes.byref(h)))
         return Proof(h)
+
+    def set_profiling(self, on):
+        lib().vgpu_prover_set_profiling(self._h, ctypes.c_uint32(1 if on else 0))
+
+    def profile(self):
+        """{kernel: (launches, total_ms, algorithmic_bytes)} accumulated since set_profiling(True)."""
+        n = lib().vgpu_prover_profile(self._h, None, ctypes.c_uint64(0))
+        buf = ctypes.create_string_buffer(int(n) + 16)
+        lib().vgpu_prover_profile(self._h, buf, ctypes.c_uint64(int(n) + 16))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, launches, ms, nbytes = line.split()
+            out[name] = (int(launches), float(ms), float(nbytes))
+        return out
 
     def memory(self):
         live, peak = ctypes.c_uint64(), ctypes.c_uint64()

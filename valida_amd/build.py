@@ -1,4 +1,4 @@
-"""Build libvgpu.so (HIP/gfx950 kernels + host prover + C ABI) in-tree, and the oracle library.
+"""Build libvgpu.so (HIP/gfx950 kernels + host prover + C ABI) in-tree.
 
 hipcc cross-compiles for gfx950 without a GPU.  Objects go to build/, the shared library next to this
 file (git-ignored, but shipped to the GPU box by gpurun).
@@ -12,8 +12,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "valida_amd", "csrc")
 BUILD = os.path.join(ROOT, "build")
 LIB = os.path.join(ROOT, "valida_amd", "libvgpu.so")
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 
 SOURCES = [
     "kernels/ntt.hip",
@@ -71,18 +69,5 @@ def build_vgpu(force=False):
     return LIB
 
 
-def build_oracle(force=False):
-    deps = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".hpp", ".cpp"))]
-    deps += [os.path.join(CSRC, "chips", "basic_machine.hpp"), os.path.join(CSRC, "air", "builder.hpp")]
-    if not force and _newer_than(ORACLE_LIB, deps):
-        return ORACLE_LIB
-    r = subprocess.run(["make", "-C", ORACLE_DIR, "-B"], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("oracle build failed:\n" + r.stderr)
-    return ORACLE_LIB
-
-
 if __name__ == "__main__":
-    force = "--force" in sys.argv
-    print(build_vgpu(force))
-    print(build_oracle(force))
+    print(build_vgpu("--force" in sys.argv))

@@ -162,6 +162,22 @@ void vgpu_prover_memory(const vgpu_prover_t* p, uint64_t* live, uint64_t* peak) 
     if (live) *live = c.live;
     if (peak) *peak = c.peak_live;
 }
+void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on) {
+    auto& c = p->p->ctx();
+    c.profiler.reset();
+    c.profiler.enabled = on != 0;
+}
+// "name launches total_ms total_algorithmic_bytes\n" per kernel, accumulated since profiling was switched on
+int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap) {
+    std::string s;
+    for (auto& kv : p->p->ctx().profiler.stats) {
+        char line[256];
+        snprintf(line, sizeof line, "%s %llu %.6f %.0f\n", kv.first.c_str(), (unsigned long long)kv.second.launches, kv.second.ms, kv.second.bytes);
+        s += line;
+    }
+    if (out && cap > s.size()) memcpy(out, s.c_str(), s.size() + 1);
+    return (int64_t)s.size() + 1;
+}
 int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t height, uint64_t width, vgpu_trace_t** out) {
     VG_TRY({
         if (!p || !data || !out || !height || !width) throw std::invalid_argument("bad trace");

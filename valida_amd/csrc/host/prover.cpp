@@ -63,6 +63,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
                                     PhaseTimes* times, ProveDebugOut* dbg) {
     DeviceCtx& c = *ctx_;
     VG_HIP_CHECK(hipSetDevice(c.device));
+    vk::g_profiler = &c.profiler;
     const size_t NC = machine_.airs.size();
     if (main.size() != NC) throw std::invalid_argument("prove: need one main trace per chip");
     const Fp s = Fp::from_canonical(vg::GENERATOR);  // pcs.coset_shift()
@@ -395,7 +396,9 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         for (auto& kv : groups) {
             uint64_t L = 1ull << kv.first;
             ro[kv.first] = DBuf(&c, (size_t)(5 * L));
-            vk::launch_reduce_openings(c.stream, pool_dev.data + off[kv.first], L, s, c.tables, ro[kv.first].data);
+            uint64_t total_width = 0;
+            for (auto& me : kv.second.mats) total_width += me.lde->width;
+            vk::launch_reduce_openings(c.stream, pool_dev.data + off[kv.first], L, s, c.tables, ro[kv.first].data, total_width);
             log_max = std::max(log_max, kv.first);
         }
         c.check_launch("reduce openings");
@@ -532,6 +535,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             }
         }
         tm.queries = ms_since(t0);
+        c.profiler.collect();
         tm.total = ms_since(t_total);
         if (times) *times = tm;
         if (dbg) {

@@ -10,7 +10,7 @@
 
 namespace vhost {
 
-constexpr uint32_t PROOF_MAGIC = 0x31465056u;  // "VPF1" flat wire format, see DESIGN.md / oracle/proof_io.hpp
+constexpr uint32_t PROOF_MAGIC = 0x31465056u;  // "VPF1" flat wire format, see DESIGN.md "Proof wire format"
 
 struct HostMatrix {  // canonical row-major, host memory (the reference's RowMajorMatrix<Val>)
     const uint32_t* data;

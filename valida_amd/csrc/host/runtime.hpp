@@ -24,6 +24,7 @@ struct DeviceCtx {
     uint32_t* table_mem = nullptr;
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    vk::Profiler profiler;
 
     explicit DeviceCtx(int dev) : device(dev) {
         VG_HIP_CHECK(hipSetDevice(dev));

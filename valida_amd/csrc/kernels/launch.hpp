@@ -1,6 +1,7 @@
 // Host-callable launchers of the gfx950 kernels (definitions in the .hip files of this directory).
 #pragma once
 #include "device_common.hpp"
+#include "profiler.hpp"
 #include "../air/symbolic.hpp"
 
 namespace vk {
@@ -42,7 +43,7 @@ void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp 
 uint64_t col_dot_slots(uint64_t n);
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
                     const uint32_t* scale5_dev, uint32_t* out_dev);
-void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out);
+void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width);
 void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst);
 

@@ -137,10 +137,12 @@ __global__ void __launch_bounds__(256) k_keccak_compress(const uint32_t* __restr
 
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
+    ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0));
     hipLaunchKernelGGL(k_keccak_leaves, dim3(blocks), dim3(256), 0, st, cols_dev, n_elems, n_rows, digests);
 }
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
     unsigned blocks = (unsigned)((n_out + 255) / 256);
+    ProfScope ps("k_keccak_compress", st, (double)n_out * (96.0 + 4.0 * n_elems));
     hipLaunchKernelGGL(k_keccak_compress, dim3(blocks), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
 }
 

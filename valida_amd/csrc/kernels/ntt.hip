@@ -182,9 +182,12 @@ void launch_intt(hipStream_t st, DMatView m, const DeviceTables& tb) {
     NttPlan p = make_plan(k);
     uint32_t ninv = Fp::from_canonical((uint32_t)(m.height % vg::P)).inv().v;
     dim3 gc((unsigned)(m.height >> p.k_lo), (unsigned)m.width);
-    hipLaunchKernelGGL(k_intt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, m, k, p.k_lo, tb, ninv);
+    const double pass_bytes = 8.0 * m.height * m.width;
+    { ProfScope ps("k_intt_contig", st, pass_bytes);
+    hipLaunchKernelGGL(k_intt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, m, k, p.k_lo, tb, ninv); }
     if (p.k_hi > 0) {
         dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)m.width);
+        ProfScope ps("k_intt_strided", st, pass_bytes);
         hipLaunchKernelGGL(k_intt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, m, k, p.k_lo, p.logT, tb, ninv);
     }
 }
@@ -196,11 +199,15 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
     int k = (int)vg::log2_strict_u64(coeffs.height);
     NttPlan p = make_plan(k);
     dim3 gc((unsigned)(coeffs.height >> p.k_lo), (unsigned)coeffs.width);
+    const double pass_bytes = 8.0 * coeffs.height * coeffs.width;
     if (p.k_hi > 0) {
         dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)coeffs.width);
-        hipLaunchKernelGGL(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, shift.v);
+        { ProfScope ps("k_ntt_strided", st, pass_bytes);
+        hipLaunchKernelGGL(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, shift.v); }
+        ProfScope ps("k_ntt_contig", st, pass_bytes);
         hipLaunchKernelGGL(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0);
     } else {
+        ProfScope ps("k_ntt_contig", st, pass_bytes);
         hipLaunchKernelGGL(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1);
     }
 }

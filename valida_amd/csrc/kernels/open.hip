@@ -172,6 +172,7 @@ __global__ void k_gather(const uint32_t* __restrict__ desc, uint64_t n_desc, uin
 
 // ---- launchers ----------------------------------------------------------------------------------------
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w) {
+    ProfScope ps("k_bary_weights", st, 20.0 * n);
     hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, z5_dev, shift.v, tb, w);
 }
 uint64_t col_dot_slots(uint64_t n) { return ((n + BARY_ROWS - 1) / BARY_ROWS) * (BARY_THREADS / 64); }
@@ -179,20 +180,24 @@ uint64_t col_dot_slots(uint64_t n) { return ((n + BARY_ROWS - 1) / BARY_ROWS) * 
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
                     const uint32_t* scale5_dev, uint32_t* out_dev) {
     unsigned chunks = (unsigned)((n + BARY_ROWS - 1) / BARY_ROWS);
+    ProfScope ps("k_col_dot", st, 4.0 * n * (m.width + 5.0 * np));
     if (np == 1) hipLaunchKernelGGL(k_col_dot<1>, dim3(chunks), dim3(BARY_THREADS), 0, st, m, n, w0, w1, partial);
     else hipLaunchKernelGGL(k_col_dot<2>, dim3(chunks), dim3(BARY_THREADS), 0, st, m, n, w0, w1, partial);
     uint64_t items = m.width * np;
     hipLaunchKernelGGL(k_col_dot_finish, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, partial, col_dot_slots(n), m.width, np, scale5_dev, out_dev);
 }
-void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out) {
+void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width) {
+    ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + 5.0));
     hipLaunchKernelGGL(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out);
 }
 void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
     uint64_t half = L >> 1;
+    ProfScope ps("k_fri_fold", st, 20.0 * L + 20.0 * half * (add ? 2 : 1));
     hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, L, beta5_dev, add, tb, out);
 }
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst) {
     if (!n_desc) return;
+    ProfScope ps("k_gather", st, 0.0);
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((n_desc + 7) / 8)), dim3(256), 0, st, desc_dev, n_desc, dst);
 }
 

@@ -104,7 +104,9 @@ uint64_t perm_scratch_words(uint64_t n) { return 5 * ((n + SCAN_BLOCK - 1) / SCA
 void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,
                        uint32_t* scratch) {
     uint64_t n = main.height;
-    hipLaunchKernelGGL(k_perm_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, main, prep, iw_dev, chal_dev, perm);
+    { ProfScope ps("k_perm_recip", st, 4.0 * n * (main.width + perm.width));
+    hipLaunchKernelGGL(k_perm_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, main, prep, iw_dev, chal_dev, perm); }
+    ProfScope ps("k_scan", st, 3.0 * 20.0 * n);
     uint32_t* phi = perm.data + (uint64_t)(5 * M) * perm.stride;
     uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb, 5), dim3(SCAN_THREADS), 0, st, phi, perm.stride, n, scratch, nb);

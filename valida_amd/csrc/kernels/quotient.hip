@@ -130,6 +130,7 @@ void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& 
     while (threads > 64 && (size_t)a.n_regs * threads * 4 > 64 * 1024) threads >>= 1;
     size_t lds = (size_t)(a.n_regs ? a.n_regs : 1) * threads * 4;
     uint64_t n = 1ull << a.log_n;
+    ProfScope ps("k_quotient", st, 4.0 * n * (2.0 * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 10.0));
     hipLaunchKernelGGL(k_quotient, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), lds, st, a, tb);
 }
 
