@@ -56,15 +56,25 @@ struct DeviceTree {
         layer_len.push_back(maxh);
         vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
+        vk::KeccakTopArgs top{};
         for (uint64_t len = maxh / 2; len >= 1; len /= 2) {
             layers.emplace_back(c, (size_t)len * 8);
             layer_len.push_back(len);
             const Group* inj = (gi < groups.size() && groups[gi].height == len) ? &groups[gi] : nullptr;
-            vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
-                                       layers.back().data);
+            if (len > 1024) {
+                vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
+                                           layers.back().data);
+            } else {  // the last <= 11 layers go into one launch
+                if (top.levels == 0) { top.prev = layers[layers.size() - 2].data; top.first_len = len; }
+                top.out[top.levels] = layers.back().data;
+                top.cols[top.levels] = inj ? pd + inj->first : nullptr;
+                top.n_elems[top.levels] = inj ? (int)inj->count : 0;
+                top.levels++;
+            }
             if (inj) gi++;
             if (len == 1) break;
         }
+        if (top.levels) vk::launch_keccak_top(c->stream, top);
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
         c->check_launch("mmcs build");
         c->download(root, layers.back().data, 32);  // also keeps ptr_buf alive until the kernels finished

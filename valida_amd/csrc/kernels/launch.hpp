@@ -32,6 +32,16 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
 // merkle.hip
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next);
+constexpr int KECCAK_TOP_MAX_LEVELS = 11;  // first_len <= 1024
+struct KeccakTopArgs {
+    const uint32_t* prev;  // layer with 2 * first_len digests
+    uint64_t first_len;    // parents in the first computed layer (power of two <= 1024)
+    int levels;            // layers computed: first_len, first_len/2, ..., 1
+    uint32_t* out[KECCAK_TOP_MAX_LEVELS];
+    const uint32_t* const* cols[KECCAK_TOP_MAX_LEVELS];  // injected matrices' columns per layer (or null)
+    int n_elems[KECCAK_TOP_MAX_LEVELS];
+};
+void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a);
 // perm.hip
 uint64_t perm_scratch_words(uint64_t n);
 void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,

@@ -12,42 +12,71 @@
 
 namespace vk {
 
-__constant__ uint64_t KECCAK_RC[24] = {
-    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
-    0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
-    0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
-    0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
-    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+// Keccak-f[1600] on 32-bit halves.  gfx950 VALU is 32-bit: 64-bit xors are two ops anyway, but 64-bit
+// SHIFTS are slow multi-pass instructions, so every lane is kept as (lo, hi) and rotated with
+// v_alignbit_b32 (2 per rotation); chi and theta's column parity use gfx950's v_bitop3_b32 (any 3-input
+// boolean function: one op per half for chi, two for a 5-way xor).  ~200 full-rate VALU instructions per round.
+__constant__ uint32_t KECCAK_RC_LO[24] = {0x00000001u, 0x00008082u, 0x0000808au, 0x80008000u, 0x0000808bu, 0x80000001u, 0x80008081u, 0x00008009u,
+                                          0x0000008au, 0x00000088u, 0x80008009u, 0x8000000au, 0x8000808bu, 0x0000008bu, 0x00008089u, 0x00008003u,
+                                          0x00008002u, 0x00000080u, 0x0000800au, 0x8000000au, 0x80008081u, 0x00008080u, 0x80000001u, 0x80008008u};
+__constant__ uint32_t KECCAK_RC_HI[24] = {0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u,
+                                          0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x80000000u,
+                                          0x80000000u, 0x80000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x00000000u, 0x80000000u};
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return n == 0 ? x : (x << n) | (x >> (64 - n)); }
+struct KState { uint32_t lo[25], hi[25]; };
 
 // rotation offsets r[x][y], index x + 5*y
 __device__ __forceinline__ constexpr int keccak_rot(int i) {
     constexpr int R[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     return R[i];
 }
+// (lo, hi) rotated left by the compile-time constant N
+template <int N> __device__ __forceinline__ void rotl_pair(uint32_t lo, uint32_t hi, uint32_t& olo, uint32_t& ohi) {
+    if (N == 0) { olo = lo; ohi = hi; }
+    else if (N == 32) { olo = hi; ohi = lo; }
+    else if (N < 32) { ohi = __builtin_amdgcn_alignbit(hi, lo, 32 - N); olo = __builtin_amdgcn_alignbit(lo, hi, 32 - N); }
+    else { ohi = __builtin_amdgcn_alignbit(lo, hi, 64 - N); olo = __builtin_amdgcn_alignbit(hi, lo, 64 - N); }
+}
+// gfx950 v_bitop3_b32: any 3-input boolean function in one instruction (truth table over a=0xF0, b=0xCC, c=0xAA)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t chi32(uint32_t b0, uint32_t b1, uint32_t b2) { return __builtin_amdgcn_bitop3_b32(b0, b1, b2, 0xD2); }  // b0 ^ (~b1 & b2)
 
-__device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25]) {
-#pragma unroll 1
+template <int X, int Y> __device__ __forceinline__ void rho_pi(const KState& a, KState& b) {
+    constexpr int src = X + 5 * Y, dst = Y + 5 * ((2 * X + 3 * Y) % 5);
+    rotl_pair<keccak_rot(src)>(a.lo[src], a.hi[src], b.lo[dst], b.hi[dst]);
+}
+template <int X> __device__ __forceinline__ void rho_pi_col(const KState& a, KState& b) {
+    rho_pi<X, 0>(a, b); rho_pi<X, 1>(a, b); rho_pi<X, 2>(a, b); rho_pi<X, 3>(a, b); rho_pi<X, 4>(a, b);
+}
+
+__device__ __forceinline__ void keccak_f1600(KState& a) {
+#pragma unroll 2
     for (int round = 0; round < 24; round++) {
-        uint64_t c[5], b[25];
-#pragma unroll
-        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        uint32_t cl[5], ch[5];
+        KState b;
 #pragma unroll
         for (int x = 0; x < 5; x++) {
-            uint64_t d = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
-#pragma unroll
-            for (int y = 0; y < 5; y++) a[x + 5 * y] ^= d;
+            cl[x] = xor3(xor3(a.lo[x], a.lo[x + 5], a.lo[x + 10]), a.lo[x + 15], a.lo[x + 20]);
+            ch[x] = xor3(xor3(a.hi[x], a.hi[x + 5], a.hi[x + 10]), a.hi[x + 15], a.hi[x + 20]);
         }
 #pragma unroll
-        for (int x = 0; x < 5; x++)
+        for (int x = 0; x < 5; x++) {
+            uint32_t rl, rh;
+            rotl_pair<1>(cl[(x + 1) % 5], ch[(x + 1) % 5], rl, rh);
+            uint32_t dl = cl[(x + 4) % 5] ^ rl, dh = ch[(x + 4) % 5] ^ rh;
 #pragma unroll
-            for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(a[x + 5 * y], keccak_rot(x + 5 * y));
+            for (int y = 0; y < 5; y++) { a.lo[x + 5 * y] ^= dl; a.hi[x + 5 * y] ^= dh; }
+        }
+        rho_pi_col<0>(a, b); rho_pi_col<1>(a, b); rho_pi_col<2>(a, b); rho_pi_col<3>(a, b); rho_pi_col<4>(a, b);
 #pragma unroll
         for (int y = 0; y < 5; y++)
 #pragma unroll
-            for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-        a[0] ^= KECCAK_RC[round];
+            for (int x = 0; x < 5; x++) {
+                a.lo[x + 5 * y] = chi32(b.lo[x + 5 * y], b.lo[(x + 1) % 5 + 5 * y], b.lo[(x + 2) % 5 + 5 * y]);
+                a.hi[x + 5 * y] = chi32(b.hi[x + 5 * y], b.hi[(x + 1) % 5 + 5 * y], b.hi[(x + 2) % 5 + 5 * y]);
+            }
+        a.lo[0] ^= KECCAK_RC_LO[round];
+        a.hi[0] ^= KECCAK_RC_HI[round];
     }
 }
 
@@ -57,13 +86,21 @@ __device__ __forceinline__ uint32_t wrap_mod_p(uint32_t w) {  // from_wrapped_u3
     return w;
 }
 
-__device__ __forceinline__ void absorb_word(uint64_t (&a)[25], int k, uint32_t w) { a[k >> 1] ^= (uint64_t)w << (32 * (k & 1)); }
+// 32-bit word k of the rate (k < 34): even words are the low halves of lane k/2
+__device__ __forceinline__ void absorb_word(KState& a, int k, uint32_t w) { if (k & 1) a.hi[k >> 1] ^= w; else a.lo[k >> 1] ^= w; }
+__device__ __forceinline__ void kstate_zero(KState& a) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) { a.lo[i] = 0; a.hi[i] = 0; }
+}
+__device__ __forceinline__ void squeeze_digest(const KState& a, uint32_t (&out)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { out[2 * i] = wrap_mod_p(a.lo[i]); out[2 * i + 1] = wrap_mod_p(a.hi[i]); }
+}
 
 // Hash of one row of the column list `cols` (n_elems Montgomery columns, element r of each).
 __device__ __forceinline__ void hash_row(const uint32_t* const* __restrict__ cols, int n_elems, uint64_t r, uint32_t (&out)[8]) {
-    uint64_t a[25];
-#pragma unroll
-    for (int i = 0; i < 25; i++) a[i] = 0;
+    KState a;
+    kstate_zero(a);
     int base = 0;
     for (; base + 34 <= n_elems; base += 34) {
 #pragma unroll
@@ -78,22 +115,19 @@ __device__ __forceinline__ void hash_row(const uint32_t* const* __restrict__ col
     }
     absorb_word(a, 33, 0x80000000u);
     keccak_f1600(a);
-#pragma unroll
-    for (int i = 0; i < 4; i++) { out[2 * i] = wrap_mod_p((uint32_t)a[i]); out[2 * i + 1] = wrap_mod_p((uint32_t)(a[i] >> 32)); }
+    squeeze_digest(a, out);
 }
 
 // C(l, r): 16 canonical words, one block.
 __device__ __forceinline__ void compress2(const uint32_t (&l)[8], const uint32_t (&r)[8], uint32_t (&out)[8]) {
-    uint64_t a[25];
+    KState a;
+    kstate_zero(a);
 #pragma unroll
-    for (int i = 0; i < 25; i++) a[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { a[i] = (uint64_t)l[2 * i] | ((uint64_t)l[2 * i + 1] << 32); a[4 + i] = (uint64_t)r[2 * i] | ((uint64_t)r[2 * i + 1] << 32); }
-    a[8] = 0x01ull;
-    a[16] ^= 0x8000000000000000ull;
+    for (int i = 0; i < 4; i++) { a.lo[i] = l[2 * i]; a.hi[i] = l[2 * i + 1]; a.lo[4 + i] = r[2 * i]; a.hi[4 + i] = r[2 * i + 1]; }
+    a.lo[8] = 0x01u;
+    a.hi[16] ^= 0x80000000u;
     keccak_f1600(a);
-#pragma unroll
-    for (int i = 0; i < 4; i++) { out[2 * i] = wrap_mod_p((uint32_t)a[i]); out[2 * i + 1] = wrap_mod_p((uint32_t)(a[i] >> 32)); }
+    squeeze_digest(a, out);
 }
 
 __device__ __forceinline__ void load_digest(const uint32_t* p, uint32_t (&d)[8]) {
@@ -133,6 +167,41 @@ __global__ void __launch_bounds__(256) k_keccak_compress(const uint32_t* __restr
     } else {
         store_digest(next + 8 * i, d);
     }
+}
+
+// Top of a tree in ONE launch: a single 1024-thread workgroup walks the last `levels` layers
+// (first_len <= 1024 parents down to the root), one barrier per layer, instead of one ~10 us launch per
+// layer — there are ~25 trees per proof (3 commitment rounds + one per FRI layer).
+__global__ void __launch_bounds__(1024) k_keccak_top(KeccakTopArgs a) {
+    const uint32_t* prev = a.prev;
+    for (int l = 0; l < a.levels; l++) {
+        const uint64_t len = a.first_len >> l;
+        if (threadIdx.x < len) {
+            const uint64_t i = threadIdx.x;
+            uint32_t lft[8], rgt[8], d[8];
+            load_digest(prev + 16 * i, lft);
+            load_digest(prev + 16 * i + 8, rgt);
+            compress2(lft, rgt, d);
+            if (a.n_elems[l] > 0) {
+                uint32_t h[8], d2[8];
+                hash_row(a.cols[l], a.n_elems[l], i, h);
+                compress2(d, h, d2);
+                store_digest(a.out[l] + 8 * i, d2);
+            } else {
+                store_digest(a.out[l] + 8 * i, d);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        prev = a.out[l];
+    }
+}
+
+void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
+    double bytes = 0;
+    for (int l = 0; l < a.levels; l++) bytes += (double)(a.first_len >> l) * (96.0 + 4.0 * a.n_elems[l]);
+    ProfScope ps("k_keccak_top", st, bytes);
+    hipLaunchKernelGGL(k_keccak_top, dim3(1), dim3(1024), 0, st, a);
 }
 
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {

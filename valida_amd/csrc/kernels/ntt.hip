@@ -11,46 +11,83 @@
 // Sizes above 2^12 points use the two-pass ("four-step") split N = N_hi * N_lo, N_lo = 2^12:
 //   inverse: [contiguous DIT over N_lo] * w_N^{-bitrev(h) r}  ->  [strided DIT over N_hi] * 1/N
 //   forward: c * shift^i -> [strided DIF over N_hi] * w_N^{r bitrev(h')}  ->  [contiguous DIF over N_lo]
-// Every pass stages its tile in LDS (160 KiB/CU), reads/writes HBM once, twiddles come from an 8 KiB
-// L1-resident table.  No MFMA: 31-bit modular butterflies are VALU work; the passes are HBM-bound.
+// Every pass stages its tile in LDS (160 KiB/CU) and reads/writes HBM once.  Inside LDS the radix-2
+// stages are grouped into ROUNDS of up to 4 stages executed in registers (16 points per work item:
+// 32 butterflies between one LDS read and one LDS write, one barrier per round instead of per stage);
+// the twiddles of a round come from per-stage compact tables staged in LDS (broadcast / conflict-free
+// reads).  No MFMA: 31-bit modular butterflies are VALU work; the passes are HBM/VALU balanced.
 #include "launch.hpp"
 
 namespace vk {
 
-// In-LDS radix-2 stages along the h dimension of a tile: element (h, c) at buf[h * LD + c], c < T = 1 << logT.
-__device__ __forceinline__ void tile_dit(uint32_t* buf, int logn, int logT, int LD, const uint32_t* __restrict__ tw) {
-    const int total = ((1 << logn) >> 1) << logT;
-    const int maskT = (1 << logT) - 1;
-    for (int s = 1; s <= logn; s++) {
-        const int half = 1 << (s - 1);
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
-            int c = e & maskT, p = e >> logT;
-            int j = p & (half - 1);
-            int i0 = ((p >> (s - 1)) << s) + j, i1 = i0 + half;
-            Fp w = Fp::raw(tw[j << (12 - s)]);
-            Fp u = Fp::raw(buf[i0 * LD + c]), v = Fp::raw(buf[i1 * LD + c]) * w;
-            buf[i0 * LD + c] = (u + v).v;
-            buf[i1 * LD + c] = (u - v).v;
+// Contiguous tiles (T = 1) are stored padded: word i at i + (i >> 4), so the stride-16 accesses of the
+// last round are bank-conflict free.  Strided tiles use element (h, c) at h * LD + c with LD = T + 1.
+template <bool PAD> __device__ __forceinline__ int tile_addr(int i, int c, int LD) { return PAD ? i + (i >> 4) : i * LD + c; }
+
+// One round = stages s_lo .. s_lo + R - 1 of the radix-2 network on a tile of 2^logn points x 2^logT columns.
+// tw: compact tables in LDS, stage s at offset 2^(s-1) - 1: tw[off + j] = w_{2^s}^{+-j}, j < 2^(s-1).
+template <int R, bool DIT, bool PAD>
+__device__ __forceinline__ void ntt_round(uint32_t* buf, const uint32_t* tw, int logn, int s_lo, int logT, int LD) {
+    constexpr int G = 1 << R;
+    const int n_items = (1 << (logn - R)) << logT;
+    const int maskT = (1 << logT) - 1, lowbits = s_lo - 1, lowmask = (1 << lowbits) - 1;
+    for (int w = threadIdx.x; w < n_items; w += blockDim.x) {
+        const int c = w & maskT, q = w >> logT;
+        const int low = q & lowmask, base = ((q >> lowbits) << (lowbits + R)) | low;
+        Fp x[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) x[g] = Fp::raw(buf[tile_addr<PAD>(base | (g << lowbits), c, LD)]);
+#pragma unroll
+        for (int step = 0; step < R; step++) {
+            const int st = DIT ? step : R - 1 - step;  // stage s = s_lo + st pairs g differing in bit st
+            const int half = 1 << st;
+            const uint32_t* t = tw + ((1 << (lowbits + st)) - 1) + low;
+            Fp wv[G / 2];
+#pragma unroll
+            for (int k = 0; k < G / 2; k++)
+                if (k < half) wv[k] = Fp::raw(t[k << lowbits]);
+#pragma unroll
+            for (int p = 0; p < G / 2; p++) {
+                const int g0 = ((p >> st) << (st + 1)) | (p & (half - 1)), g1 = g0 | half;
+                const Fp wk = wv[p & (half - 1)];
+                if (DIT) { Fp u = x[g0], v = x[g1] * wk; x[g0] = u + v; x[g1] = u - v; }
+                else { Fp u = x[g0], v = x[g1]; x[g0] = u + v; x[g1] = (u - v) * wk; }
+            }
         }
-        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; g++) buf[tile_addr<PAD>(base | (g << lowbits), c, LD)] = x[g].v;
+    }
+    __syncthreads();
+}
+
+template <bool DIT, bool PAD>
+__device__ __forceinline__ void ntt_round_dispatch(int R, uint32_t* buf, const uint32_t* tw, int logn, int s_lo, int logT, int LD) {
+    switch (R) {
+        case 1: ntt_round<1, DIT, PAD>(buf, tw, logn, s_lo, logT, LD); break;
+        case 2: ntt_round<2, DIT, PAD>(buf, tw, logn, s_lo, logT, LD); break;
+        case 3: ntt_round<3, DIT, PAD>(buf, tw, logn, s_lo, logT, LD); break;
+        default: ntt_round<4, DIT, PAD>(buf, tw, logn, s_lo, logT, LD); break;
     }
 }
-__device__ __forceinline__ void tile_dif(uint32_t* buf, int logn, int logT, int LD, const uint32_t* __restrict__ tw) {
-    const int total = ((1 << logn) >> 1) << logT;
-    const int maskT = (1 << logT) - 1;
-    for (int s = logn; s >= 1; s--) {
-        const int half = 1 << (s - 1);
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
-            int c = e & maskT, p = e >> logT;
-            int j = p & (half - 1);
-            int i0 = ((p >> (s - 1)) << s) + j, i1 = i0 + half;
-            Fp w = Fp::raw(tw[j << (12 - s)]);
-            Fp u = Fp::raw(buf[i0 * LD + c]), v = Fp::raw(buf[i1 * LD + c]);
-            buf[i0 * LD + c] = (u + v).v;
-            buf[i1 * LD + c] = ((u - v) * w).v;
-        }
-        __syncthreads();
+
+// All logn stages, split into ceil(logn / 4) rounds of near-equal size.
+// DIT: bit-reversed-position input -> natural output (inverse tables); DIF: natural -> bit-reversed.
+template <bool DIT, bool PAD>
+__device__ __forceinline__ void tile_transform(uint32_t* buf, const uint32_t* tw, int logn, int logT, int LD) {
+    if (logn == 0) return;
+    const int rounds = (logn + 3) >> 2, small = logn / rounds, extra = logn - small * rounds;
+    if (DIT) {
+        int s_lo = 1;
+        for (int i = 0; i < rounds; i++) { int R = small + (i < extra ? 1 : 0); ntt_round_dispatch<true, PAD>(R, buf, tw, logn, s_lo, logT, LD); s_lo += R; }
+    } else {
+        int s_top = logn;
+        for (int i = 0; i < rounds; i++) { int R = small + (i < extra ? 1 : 0); ntt_round_dispatch<false, PAD>(R, buf, tw, logn, s_top - R + 1, logT, LD); s_top -= R; }
     }
+}
+
+__device__ __forceinline__ void stage_twiddles(uint32_t* dst, const uint32_t* __restrict__ compact, int logn) {
+    const int count = (1 << logn) - 1;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = compact[i];
 }
 
 // prod_{bit i of h} table[base + i]
@@ -60,23 +97,27 @@ __device__ __forceinline__ Fp bit_product(const uint32_t* table, int base, uint3
     return r;
 }
 
+__host__ __device__ inline int padded_words(int n) { return n + (n >> 4); }
+
 // ---- inverse, contiguous pass: grid = (N / N_lo, columns) --------------------------------------------
 // In place on `data` (column-major, height N = 2^k).  k_lo = min(k, 12) stages on each contiguous block
 // of N_lo points.  If k_hi > 0 multiplies element r of block h by w_N^{-bitrev(h) * r}; else scales by 1/N.
 __global__ void k_intt_contig(DMatView m, int k, int k_lo, DeviceTables tb, uint32_t n_inv_mont) {
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo, k_hi = k - k_lo;
+    uint32_t* tw = lds + padded_words(n_lo);
     uint32_t* col = m.col(blockIdx.y) + (uint64_t)blockIdx.x * n_lo;
-    for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[i] = col[i];
+    for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[tile_addr<true>(i, 0, 0)] = col[i];
+    stage_twiddles(tw, tb.itwc, k_lo);
     __syncthreads();
-    tile_dit(lds, k_lo, 0, 1, tb.itw12);
+    tile_transform<true, true>(lds, tw, k_lo, 0, 0);
     if (k_hi > 0) {
         Fp base = bit_product(tb.inv_roots, k_lo + 1, blockIdx.x);  // w_N^{-bitrev_{k_hi}(h)}
         Fp step = base.pow(blockDim.x), cur = base.pow(threadIdx.x);
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { col[i] = (Fp::raw(lds[i]) * cur).v; cur *= step; }
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { col[i] = (Fp::raw(lds[tile_addr<true>(i, 0, 0)]) * cur).v; cur *= step; }
     } else {
         Fp ninv = Fp::raw(n_inv_mont);
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) col[i] = (Fp::raw(lds[i]) * ninv).v;
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) col[i] = (Fp::raw(lds[tile_addr<true>(i, 0, 0)]) * ninv).v;
     }
 }
 
@@ -86,11 +127,13 @@ __global__ void k_intt_strided(DMatView m, int k, int k_lo, int logT, DeviceTabl
     extern __shared__ uint32_t lds[];
     const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
     const uint64_t n_lo = 1ull << k_lo;
+    uint32_t* tw = lds + n_hi * LD;
     uint32_t* col = m.col(blockIdx.y) + (uint64_t)blockIdx.x * T;
     const int total = n_hi << logT;
     for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; lds[h * LD + c] = col[h * n_lo + c]; }
+    stage_twiddles(tw, tb.itwc, k_hi);
     __syncthreads();
-    tile_dit(lds, k_hi, logT, LD, tb.itw12);
+    tile_transform<true, false>(lds, tw, k_hi, logT, LD);
     Fp ninv = Fp::raw(n_inv_mont);
     for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; col[h * n_lo + c] = (Fp::raw(lds[h * LD + c]) * ninv).v; }
 }
@@ -103,6 +146,7 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
     extern __shared__ uint32_t lds[];
     const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
     const uint64_t n_lo = 1ull << k_lo, r0 = (uint64_t)blockIdx.x * T;
+    uint32_t* tw = lds + n_hi * LD;
     const uint32_t* in = src.col(blockIdx.y) + r0;
     uint32_t* out = dst.col(blockIdx.y) + dst_row0 + r0;
     const int total = n_hi << logT;
@@ -113,8 +157,9 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
         Fp cur = shift.pow((uint64_t)h0 * n_lo + r0 + c), step = shift.pow((uint64_t)hstep * n_lo);
         for (int h = h0; h < n_hi; h += hstep) { lds[h * LD + c] = (Fp::raw(in[h * n_lo + c]) * cur).v; cur *= step; }
     }
+    stage_twiddles(tw, tb.twc, k_hi);
     __syncthreads();
-    tile_dif(lds, k_hi, logT, LD, tb.tw12);
+    tile_transform<false, false>(lds, tw, k_hi, logT, LD);
     // twiddle: thread per row h', running product over the T consecutive r
     for (int h = threadIdx.x; h < n_hi; h += blockDim.x) {
         Fp base = bit_product(tb.roots, k_lo + 1, (uint32_t)h);  // w_N^{bitrev_{k_hi}(h')}
@@ -132,18 +177,20 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
                              int from_src) {
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo;
+    uint32_t* tw = lds + padded_words(n_lo);
     uint32_t* out = dst.col(blockIdx.y) + dst_row0 + (uint64_t)blockIdx.x * n_lo;
     if (from_src) {
         const uint32_t* in = src.col(blockIdx.y);
         Fp shift = Fp::raw(shift_mont);
         Fp cur = shift.pow(threadIdx.x), step = shift.pow(blockDim.x);
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { lds[i] = (Fp::raw(in[i]) * cur).v; cur *= step; }
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { lds[tile_addr<true>(i, 0, 0)] = (Fp::raw(in[i]) * cur).v; cur *= step; }
     } else {
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[i] = out[i];
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[tile_addr<true>(i, 0, 0)] = out[i];
     }
+    stage_twiddles(tw, tb.twc, k_lo);
     __syncthreads();
-    tile_dif(lds, k_lo, 0, 1, tb.tw12);
-    for (int i = threadIdx.x; i < n_lo; i += blockDim.x) out[i] = lds[i];
+    tile_transform<false, true>(lds, tw, k_lo, 0, 0);
+    for (int i = threadIdx.x; i < n_lo; i += blockDim.x) out[i] = lds[tile_addr<true>(i, 0, 0)];
 }
 
 // ---- host launchers -----------------------------------------------------------------------------------
@@ -155,12 +202,12 @@ static NttPlan make_plan(int k) {
     if ((1 << p.k_lo) < t) t = 1 << p.k_lo;
     p.logT = 0; while ((1 << p.logT) < t) p.logT++;
     unsigned n_lo = 1u << p.k_lo;
-    p.threads_contig = n_lo / 4 < 64 ? 64 : (n_lo / 4 > 1024 ? 1024 : n_lo / 4);
+    p.threads_contig = n_lo / 16 < 64 ? 64 : (n_lo / 16 > 1024 ? 1024 : n_lo / 16);
     unsigned tile = (1u << p.k_hi) << p.logT;
-    p.threads_strided = tile / 4 < 64 ? 64 : (tile / 4 > 1024 ? 1024 : tile / 4);
+    p.threads_strided = tile / 32 < 64 ? 64 : (tile / 32 > 1024 ? 1024 : tile / 32);
     if (p.threads_strided < (1u << p.logT)) p.threads_strided = 1u << p.logT;
-    p.lds_contig = (size_t)n_lo * 4;
-    p.lds_strided = (size_t)(1u << p.k_hi) * ((1u << p.logT) + 1) * 4;
+    p.lds_contig = (size_t)(padded_words((int)n_lo) + n_lo) * 4;
+    p.lds_strided = ((size_t)(1u << p.k_hi) * ((1u << p.logT) + 1) + (1u << p.k_hi)) * 4;
     return p;
 }
 
@@ -183,8 +230,10 @@ void launch_intt(hipStream_t st, DMatView m, const DeviceTables& tb) {
     uint32_t ninv = Fp::from_canonical((uint32_t)(m.height % vg::P)).inv().v;
     dim3 gc((unsigned)(m.height >> p.k_lo), (unsigned)m.width);
     const double pass_bytes = 8.0 * m.height * m.width;
-    { ProfScope ps("k_intt_contig", st, pass_bytes);
-    hipLaunchKernelGGL(k_intt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, m, k, p.k_lo, tb, ninv); }
+    {
+        ProfScope ps("k_intt_contig", st, pass_bytes);
+        hipLaunchKernelGGL(k_intt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, m, k, p.k_lo, tb, ninv);
+    }
     if (p.k_hi > 0) {
         dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)m.width);
         ProfScope ps("k_intt_strided", st, pass_bytes);
@@ -202,8 +251,10 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
     const double pass_bytes = 8.0 * coeffs.height * coeffs.width;
     if (p.k_hi > 0) {
         dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)coeffs.width);
-        { ProfScope ps("k_ntt_strided", st, pass_bytes);
-        hipLaunchKernelGGL(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, shift.v); }
+        {
+            ProfScope ps("k_ntt_strided", st, pass_bytes);
+            hipLaunchKernelGGL(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, shift.v);
+        }
         ProfScope ps("k_ntt_contig", st, pass_bytes);
         hipLaunchKernelGGL(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0);
     } else {

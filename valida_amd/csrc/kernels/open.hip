@@ -8,6 +8,8 @@
 // Ext5 vectors of length L (reduced openings, FRI layers) live in "pair layout": a column-major
 // (L/2) x 10 matrix whose row r holds f[2r] (columns 0-4) and f[2r+1] (columns 5-9) — exactly the
 // matrix ExtensionMmcs commits for a FRI layer (App. B10), so layer trees hash it without reshaping.
+#include <stdexcept>
+#include <string>
 #include "launch.hpp"
 
 namespace vk {
@@ -26,10 +28,12 @@ __global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t
 }
 
 // ---- column dot products --------------------------------------------------------------------------
-// partial[(chunk * n_waves + wave), col, point, limb] = sum over the wave's rows of M[row][col] * w_point[row].
-// grid.x = row chunks of BARY_ROWS rows; each thread owns BARY_R rows (weights kept in registers) and
-// loops over all columns; per column one wave-level butterfly reduction.
-constexpr int BARY_R = 4, BARY_THREADS = 256, BARY_ROWS = BARY_R * BARY_THREADS;
+// Y[c][p] = sum_rows M[row][c] * w_p[row]  (base x Ext5): a skinny GEMM (10 x n) * (n x C) over F_p.
+// A block stages a tile of DOT_TR rows of M (all C columns, coalesced 512-byte column segments) and of
+// the weights in LDS; thread (c, pk) then owns ONE output limb and walks the tile rows: every lane of a
+// wave reads a different column (conflict-free, row stride odd) and a broadcast weight, so there is no
+// cross-lane reduction at all.  Blocks grid-stride over row tiles and emit one partial per block.
+constexpr int DOT_THREADS = 256, DOT_TR = 128, DOT_MAX_PASSES = 4, DOT_MAX_BLOCKS = 1024;
 
 __device__ __forceinline__ Fp wave_sum(Fp v) {
 #pragma unroll
@@ -38,49 +42,67 @@ __device__ __forceinline__ Fp wave_sum(Fp v) {
 }
 
 template <int NP>
-__global__ void __launch_bounds__(BARY_THREADS) k_col_dot(DMatView m, uint64_t n, const uint32_t* __restrict__ w0, const uint32_t* __restrict__ w1, uint32_t* __restrict__ partial) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t)blockIdx.x * BARY_ROWS;
-    Ext5 wt[NP][BARY_R];
-    bool valid[BARY_R];
+__global__ void __launch_bounds__(DOT_THREADS) k_col_dot(DMatView m, uint64_t n, const uint32_t* __restrict__ w0, const uint32_t* __restrict__ w1, uint32_t* __restrict__ partial) {
+    extern __shared__ uint32_t lds[];
+    constexpr int PK = NP * 5, WLD = PK | 1;
+    const int C = (int)m.width, LD = C | 1, n_out = C * PK;
+    uint32_t* Mt = lds;                // [DOT_TR][LD]
+    uint32_t* Wt = lds + DOT_TR * LD;  // [DOT_TR][WLD]
+    Fp acc[DOT_MAX_PASSES];
 #pragma unroll
-    for (int i = 0; i < BARY_R; i++) {
-        uint64_t row = base + (uint64_t)i * BARY_THREADS + threadIdx.x;
-        valid[i] = row < n;
-        wt[0][i] = valid[i] ? load_ext(w0, n, row) : Ext5::zero();
-        if (NP > 1) wt[NP - 1][i] = valid[i] ? load_ext(w1, n, row) : Ext5::zero();
-    }
-    const uint64_t slot = (uint64_t)blockIdx.x * (BARY_THREADS / 64) + wave;
-    for (uint64_t c = 0; c < m.width; c++) {
-        const uint32_t* col = m.col(c);
-        Fp v[BARY_R];
+    for (int q = 0; q < DOT_MAX_PASSES; q++) acc[q] = Fp::zero();
+    const uint64_t n_tiles = (n + DOT_TR - 1) / DOT_TR;
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t row0 = t * DOT_TR;
+        const int rows = (int)((n - row0) < (uint64_t)DOT_TR ? (n - row0) : (uint64_t)DOT_TR);
+        for (int e = threadIdx.x; e < C * DOT_TR; e += DOT_THREADS) {
+            int r = e & (DOT_TR - 1), c = e / DOT_TR;
+            Mt[r * LD + c] = r < rows ? m.data[(uint64_t)c * m.stride + row0 + r] : 0u;
+        }
+        for (int e = threadIdx.x; e < PK * DOT_TR; e += DOT_THREADS) {
+            int r = e & (DOT_TR - 1), pk = e / DOT_TR;
+            const uint32_t* w = pk < 5 ? w0 : w1;
+            int k = pk < 5 ? pk : pk - 5;
+            Wt[r * WLD + pk] = r < rows ? w[(uint64_t)k * n + row0 + r] : 0u;
+        }
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < BARY_R; i++) v[i] = valid[i] ? Fp::raw(col[base + (uint64_t)i * BARY_THREADS + threadIdx.x]) : Fp::zero();
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                Fp acc = Fp::zero();
-#pragma unroll
-                for (int i = 0; i < BARY_R; i++) acc += v[i] * wt[p][i].c[k];
-                acc = wave_sum(acc);
-                if (lane == 0) partial[((slot * m.width + c) * NP + p) * 5 + k] = acc.v;
+        for (int q = 0; q < DOT_MAX_PASSES; q++) {
+            int idx = q * DOT_THREADS + threadIdx.x;
+            if (idx < n_out) {
+                int c = idx / PK, pk = idx - c * PK;
+                const uint32_t* mp = Mt + c;
+                const uint32_t* wp = Wt + pk;
+                Fp a = acc[q];
+#pragma unroll 8
+                for (int r = 0; r < DOT_TR; r++) a += Fp::raw(mp[r * LD]) * Fp::raw(wp[r * WLD]);
+                acc[q] = a;
             }
         }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < DOT_MAX_PASSES; q++) {
+        int idx = q * DOT_THREADS + threadIdx.x;
+        if (idx < n_out) partial[(uint64_t)blockIdx.x * n_out + idx] = acc[q].v;
     }
 }
 
-// out[(col * NP + p) * 5 + k] = canonical( scale_p * sum_slots partial[...] )
-__global__ void k_col_dot_finish(const uint32_t* __restrict__ partial, uint64_t n_slots, uint64_t width, int NP, const uint32_t* __restrict__ scale5 /* NP x 5 */,
+// One wave per (col, p): out[(col * NP + p) * 5 + k] = canonical( scale_p * sum_blocks partial[block][col][p][k] )
+__global__ void __launch_bounds__(64) k_col_dot_finish(const uint32_t* __restrict__ partial, uint64_t n_blocks, uint64_t width, int NP, const uint32_t* __restrict__ scale5 /* NP x 5 */,
                                  uint32_t* __restrict__ out) {
-    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (col, p)
-    if (idx >= width * NP) return;
-    uint64_t c = idx / NP;
-    int p = (int)(idx % NP);
+    const uint64_t idx = blockIdx.x;  // (col, p)
+    const uint64_t c = idx / NP;
+    const int p = (int)(idx % NP);
+    const uint64_t n_out = width * NP * 5;
     Ext5 acc = Ext5::zero();
-    for (uint64_t s = 0; s < n_slots; s++) acc += ext_from_words(partial + ((s * width + c) * NP + p) * 5);
-    acc = acc * ext_from_words(scale5 + 5 * p);
-    for (int k = 0; k < 5; k++) out[idx * 5 + k] = acc.c[k].canonical();
+    for (uint64_t b = threadIdx.x; b < n_blocks; b += 64) acc += ext_from_words(partial + b * n_out + (c * NP + p) * 5);
+#pragma unroll
+    for (int k = 0; k < 5; k++) acc.c[k] = wave_sum(acc.c[k]);
+    if (threadIdx.x == 0) {
+        acc = acc * ext_from_words(scale5 + 5 * p);
+        for (int k = 0; k < 5; k++) out[idx * 5 + k] = acc.c[k].canonical();
+    }
 }
 
 // ---- reduced openings -----------------------------------------------------------------------------
@@ -175,16 +197,21 @@ void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp 
     ProfScope ps("k_bary_weights", st, 20.0 * n);
     hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, z5_dev, shift.v, tb, w);
 }
-uint64_t col_dot_slots(uint64_t n) { return ((n + BARY_ROWS - 1) / BARY_ROWS) * (BARY_THREADS / 64); }
+uint64_t col_dot_slots(uint64_t n) {
+    uint64_t tiles = (n + DOT_TR - 1) / DOT_TR;
+    return tiles < (uint64_t)DOT_MAX_BLOCKS ? tiles : (uint64_t)DOT_MAX_BLOCKS;
+}
 // m: LDE (only rows < n are read).  np = 1 or 2 points.  partial: col_dot_slots(n) * width * np * 5 words.
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
                     const uint32_t* scale5_dev, uint32_t* out_dev) {
-    unsigned chunks = (unsigned)((n + BARY_ROWS - 1) / BARY_ROWS);
+    if (m.width * np * 5 > (uint64_t)DOT_MAX_PASSES * DOT_THREADS) throw std::runtime_error("col_dot: matrix too wide (width * points * 5 > 1024)");
+    unsigned blocks = (unsigned)col_dot_slots(n);
+    const int pk = np * 5;
+    size_t lds = (size_t)DOT_TR * ((m.width | 1) + (pk | 1)) * 4;
     ProfScope ps("k_col_dot", st, 4.0 * n * (m.width + 5.0 * np));
-    if (np == 1) hipLaunchKernelGGL(k_col_dot<1>, dim3(chunks), dim3(BARY_THREADS), 0, st, m, n, w0, w1, partial);
-    else hipLaunchKernelGGL(k_col_dot<2>, dim3(chunks), dim3(BARY_THREADS), 0, st, m, n, w0, w1, partial);
-    uint64_t items = m.width * np;
-    hipLaunchKernelGGL(k_col_dot_finish, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, partial, col_dot_slots(n), m.width, np, scale5_dev, out_dev);
+    if (np == 1) hipLaunchKernelGGL(k_col_dot<1>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
+    else hipLaunchKernelGGL(k_col_dot<2>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
+    hipLaunchKernelGGL(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
 }
 void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width) {
     ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + 5.0));
