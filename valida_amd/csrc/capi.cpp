@@ -263,11 +263,12 @@ int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uin
         if (!p || !f || !beta || !out || n < 4 || (n & (n - 1))) throw std::invalid_argument("fri_fold: n must be a power of two >= 4");
         DeviceCtx& c = p->p->ctx();
         uint64_t half = n / 2, q = half / 2;
-        std::vector<uint32_t> in(5 * n), bw(8, 0);
+        std::vector<uint32_t> in(5 * n);
+        vk::Ext5Arg bw;
         for (uint64_t i = 0; i < n; i++) for (int k = 0; k < 5; k++) in[((i & 1) * 5 + k) * half + (i >> 1)] = Fp::from_canonical(f[5 * i + k]).v;
-        for (int k = 0; k < 5; k++) bw[k] = Fp::from_canonical(beta[k]).v;
-        DBuf din(&c, in), db(&c, bw), dout(&c, (size_t)(5 * half));
-        vk::launch_fri_fold(c.stream, din.data, n, db.data, nullptr, c.tables, dout.data);
+        for (int k = 0; k < 5; k++) bw.w[k] = Fp::from_canonical(beta[k]).v;
+        DBuf din(&c, in), dout(&c, (size_t)(5 * half));
+        vk::launch_fri_fold(c.stream, din.data, n, bw, nullptr, c.tables, dout.data);
         c.check_launch("fri fold");
         std::vector<uint32_t> o(5 * half);
         c.download(o.data(), dout.data, o.size() * 4);

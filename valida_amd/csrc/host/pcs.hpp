@@ -45,8 +45,13 @@ struct DeviceTree {
             g.count = ptrs.size() - g.first;
             groups.push_back(g);
         }
-        DBuf ptr_buf(c, ptrs.size() * 2);
-        c->upload(ptr_buf.data, ptrs.data(), ptrs.size() * 8);
+        // a single matrix (every FRI layer tree) needs no pointer table: columns are base + k * stride
+        const bool single = mats.size() == 1;
+        DBuf ptr_buf;
+        if (!single) {
+            ptr_buf = DBuf(c, ptrs.size() * 2);
+            c->upload(ptr_buf.data, ptrs.data(), ptrs.size() * 8);
+        }
         const uint32_t* const* pd = (const uint32_t* const*)ptr_buf.data;
 
         uint64_t maxh = groups[0].height;
@@ -54,7 +59,8 @@ struct DeviceTree {
         layers.clear(); layer_len.clear();
         layers.emplace_back(c, (size_t)maxh * 8);
         layer_len.push_back(maxh);
-        vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
+        if (single) vk::launch_keccak_leaves_strided(c->stream, mats[0].data, mats[0].stride, (int)mats[0].width, maxh, layers[0].data);
+        else vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
         vk::KeccakTopArgs top{};
         for (uint64_t len = maxh / 2; len >= 1; len /= 2) {
@@ -77,7 +83,7 @@ struct DeviceTree {
         if (top.levels) vk::launch_keccak_top(c->stream, top);
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
         c->check_launch("mmcs build");
-        c->download(root, layers.back().data, 32);  // also keeps ptr_buf alive until the kernels finished
+        c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished
     }
 };
 
@@ -97,22 +103,22 @@ struct CommitInput {
 };
 
 // Returns the bit-reversed LDE on lde_shift * H_{n << log_blowup}.
-inline DMat coset_lde(DeviceCtx* c, const CommitInput& in, unsigned log_blowup, Fp lde_shift) {
+inline DMat coset_lde(DeviceCtx* c, hipStream_t st, const CommitInput& in, unsigned log_blowup, Fp lde_shift) {
     const uint64_t n = in.mat->height, b = 1ull << log_blowup;
     DMat coeffs;
     if (in.rows_bitrev && in.consume) coeffs = std::move(*in.mat);
     else {
         coeffs = DMat(c, n, in.mat->width);
-        if (in.rows_bitrev) VG_HIP_CHECK(hipMemcpyAsync(coeffs.data, in.mat->data, n * in.mat->width * 4, hipMemcpyDeviceToDevice, c->stream));
-        else vk::launch_bitrev_rows(c->stream, in.mat->view(), coeffs.view());
+        if (in.rows_bitrev) VG_HIP_CHECK(hipMemcpyAsync(coeffs.data, in.mat->data, n * in.mat->width * 4, hipMemcpyDeviceToDevice, st));
+        else vk::launch_bitrev_rows(st, in.mat->view(), coeffs.view());
     }
-    vk::launch_intt(c->stream, coeffs.view(), c->tables);
+    vk::launch_intt(st, coeffs.view(), c->tables);
     DMat lde(c, n * b, coeffs.width);
     const unsigned k = vg::log2_strict_u64(n);
     Fp w = vg::two_adic_generator(k + log_blowup), wt = Fp::one();
     for (uint64_t t = 0; t < b; t++) {
         uint64_t block = vg::reverse_bits_len((uint32_t)t, log_blowup);
-        vk::launch_coset_ntt(c->stream, coeffs.view(), lde.view(), block * n, lde_shift * wt, c->tables);
+        vk::launch_coset_ntt(st, coeffs.view(), lde.view(), block * n, lde_shift * wt, c->tables);
         wt *= w;
     }
     c->check_launch("coset_lde");
@@ -126,10 +132,12 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
                                                   const FriParams& fri) {
     auto pd = std::make_unique<ProverData>();
     Fp g = Fp::from_canonical(vg::GENERATOR);
+    Section lde_section(c);  // per-matrix LDE pipelines are independent: small ones run on the aux streams
     for (size_t i = 0; i < mats.size(); i++) {
         Fp shift = coset_shifts ? g * (*coset_shifts)[i].inv() : g;
-        pd->ldes.push_back(coset_lde(c, mats[i], fri.log_blowup, shift));
+        pd->ldes.push_back(coset_lde(c, c->stream_for(i, mats[i].mat->height), mats[i], fri.log_blowup, shift));
     }
+    lde_section.join();
     std::vector<vk::DMatView> views;
     for (auto& l : pd->ldes) views.push_back(l.view());
     pd->tree.build(c, views);

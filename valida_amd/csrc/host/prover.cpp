@@ -20,6 +20,42 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
         prog_dev_.emplace_back(ctx_.get(), pw);
         iw_dev_.emplace_back(ctx_.get(), a.interaction_words);
     }
+    // Poseidon tables for the device PoW search: round constants + circulant CosetMds coefficients
+    std::vector<uint32_t> pos(480 + 16 + 16 + 8, 0);
+    for (int i = 0; i < 480; i++) pos[i] = Fp::from_canonical(poseidon_rc480[i]).v;
+    Fp w16 = vg::two_adic_generator(4), g = Fp::from_canonical(vg::GENERATOR);
+    for (int d = 0; d < 16; d++) {
+        Fp base = g * w16.pow((uint64_t)d), acc = Fp::zero(), pw = Fp::one();
+        for (int k = 0; k < 16; k++) { acc += pw; pw *= base; }
+        pos[480 + d] = acc.v;
+    }
+    pow_pos_ = DBuf(ctx_.get(), pos);
+}
+
+// challenger.grind(bits) with the search on the device; canonical rule = smallest witness.
+uint32_t Prover::grind(Challenger& ch) {
+    DeviceCtx& c = *ctx_;
+    const unsigned bits = fri_.pow_bits;
+    if (bits == 0) { ch.check_witness(0, Fp::zero()); return 0; }
+    uint32_t st[17];
+    for (int i = 0; i < 16; i++) st[i] = ch.state[i].v;
+    for (size_t i = 0; i < ch.in.size(); i++) st[i] = ch.in[i].v;
+    st[16] = 0xffffffffu;
+    const uint32_t k_pending = (uint32_t)ch.in.size();
+    const uint32_t batch = 1u << (bits + 6 > 20 ? 20 : bits + 6);
+    uint32_t* best_dev = pow_pos_.data + 512;
+    for (uint64_t first = 0; first < vg::P; first += batch) {
+        VG_HIP_CHECK(hipMemcpyAsync(pow_pos_.data + 496, st, 17 * 4, hipMemcpyHostToDevice, c.stream));
+        uint32_t count = (uint32_t)std::min<uint64_t>(batch, vg::P - first);
+        vk::launch_pow_grind(c.stream, pow_pos_.data, k_pending, (uint32_t)first, count, bits, best_dev);
+        uint32_t best;
+        c.download_small(&best, best_dev, 4);
+        if (best != 0xffffffffu) {
+            if (!ch.check_witness(bits, Fp::from_canonical(best))) throw std::runtime_error("pow: device witness rejected by the host challenger");
+            return best;
+        }
+    }
+    throw std::runtime_error("pow: no witness found");
 }
 Prover::~Prover() {
     prog_dev_.clear();
@@ -76,13 +112,14 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     // ---------------- ingest: row-major canonical -> column-major Montgomery (natural row order)
     std::vector<unsigned> log_deg(NC);
     std::vector<DMat> main_nat(NC);
+    Section ingest_section(&c);
     for (size_t i = 0; i < NC; i++) {
         if (main[i]->width != machine_.airs[i].width) throw std::invalid_argument("prove: trace width mismatch for chip " + machine_.airs[i].name);
         uint64_t h = main[i]->height;
         if (h == 0 || (h & (h - 1))) throw std::invalid_argument("prove: trace heights must be powers of two");
         log_deg[i] = vg::log2_strict_u64(h);
         main_nat[i] = DMat(&c, h, main[i]->width);
-        vk::launch_ingest(c.stream, main[i]->raw.data, main_nat[i].view(), false);
+        vk::launch_ingest(c.stream_for(i, h), main[i]->raw.data, main_nat[i].view(), false);
     }
     std::vector<DMat> prep_nat(preprocessed.size());
     std::vector<int> prep_slot(NC, -1);
@@ -91,9 +128,10 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         int chip = preprocessed[k].first;
         if (t->width != machine_.airs[chip].prep_width || t->height != main[chip]->height) throw std::invalid_argument("prove: preprocessed trace shape mismatch");
         prep_nat[k] = DMat(&c, t->height, t->width);
-        vk::launch_ingest(c.stream, t->raw.data, prep_nat[k].view(), false);
+        vk::launch_ingest(c.stream_for(k, t->height), t->raw.data, prep_nat[k].view(), false);
         prep_slot[chip] = (int)k;
     }
+    ingest_section.join();
     c.check_launch("ingest");
     c.sync();
     tm.ingest = ms_since(t0);
@@ -144,6 +182,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         DBuf pool_dev(&c, pool);
         GatherList gl;
         std::vector<DBuf> scratch;
+        Section perm_section(&c);
         for (size_t i = 0; i < NC; i++) {
             uint32_t M = (uint32_t)machine_.airs[i].interactions.size();
             uint64_t n = main_nat[i].height;
@@ -151,9 +190,10 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             vk::DMatView pv{nullptr, 0, 0, 0};
             if (prep_slot[i] >= 0) pv = prep_nat[prep_slot[i]].view();
             scratch.emplace_back(&c, (size_t)vk::perm_scratch_words(n));
-            vk::launch_perm_trace(c.stream, main_nat[i].view(), pv, iw_dev_[i].data, pool_dev.data + off[i], M, perm_nat[i].view(), scratch.back().data);
+            vk::launch_perm_trace(c.stream_for(i, n), main_nat[i].view(), pv, iw_dev_[i].data, pool_dev.data + off[i], M, perm_nat[i].view(), scratch.back().data);
             gl.add(perm_nat[i].data + (uint64_t)(5 * M) * n + (n - 1), n, 5, 0);  // cumulative sum = last row, last column (lib.rs:247-250)
         }
+        perm_section.join();
         c.check_launch("perm trace");
         DBuf gd(&c, gl.desc), gout(&c, gl.next_dst);
         vk::launch_gather(c.stream, gd.data, gl.n(), gout.data);
@@ -208,6 +248,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             put_ext(pool, cumulative_sums[i]);
         }
         DBuf pool_dev(&c, pool);
+        Section quotient_section(&c);
         for (size_t i = 0; i < NC; i++) {
             auto& air = machine_.airs[i];
             vk::QuotientArgs a{};
@@ -231,9 +272,10 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             a.g_inv = vg::two_adic_generator(log_deg[i]).inv().v;
             quot[i] = DMat(&c, 1ull << log_deg[i], 10);
             a.out = quot[i].view();
-            vk::launch_quotient(c.stream, a, c.tables);
+            vk::launch_quotient(c.stream_for(i, 1ull << log_deg[i]), a, c.tables);
             quot_shifts[i] = s.exp_power_of_2(air.log_quotient_degree);  // lib.rs:593-596
         }
+        quotient_section.join();
         c.check_launch("quotient");
         c.sync();
     }
@@ -320,13 +362,16 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         }
         DBuf out_dev(&c, out_words);
         std::vector<DBuf> partials;
+        Section open_section(&c);
+        size_t job_idx = 0;
         for (auto& j : jobs) {
             const DMat& lde = rounds[j.r]->ldes[j.i];
             uint64_t n = lde.height >> lb;
             partials.emplace_back(&c, (size_t)(vk::col_dot_slots(n) * lde.width * j.np * 5));
-            vk::launch_col_dot(c.stream, lde.view(), n, j.np, wlist[j.w[0]].buf.data, wlist[j.w[j.np - 1]].buf.data, partials.back().data,
+            vk::launch_col_dot(c.stream_for(job_idx++, n), lde.view(), n, j.np, wlist[j.w[0]].buf.data, wlist[j.w[j.np - 1]].buf.data, partials.back().data,
                                pool_dev.data + j.scale_off, out_dev.data + j.out_off);
         }
+        open_section.join();
         c.check_launch("opened values");
         std::vector<uint32_t> out(out_words);
         c.download(out.data(), out_dev.data, out_words * 4);
@@ -393,14 +438,17 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             }
         }
         DBuf pool_dev(&c, pool);
+        Section reduce_section(&c);
+        size_t grp_idx = 0;
         for (auto& kv : groups) {
             uint64_t L = 1ull << kv.first;
             ro[kv.first] = DBuf(&c, (size_t)(5 * L));
             uint64_t total_width = 0;
             for (auto& me : kv.second.mats) total_width += me.lde->width;
-            vk::launch_reduce_openings(c.stream, pool_dev.data + off[kv.first], L, s, c.tables, ro[kv.first].data, total_width);
+            vk::launch_reduce_openings(c.stream_for(grp_idx++, L), pool_dev.data + off[kv.first], L, s, c.tables, ro[kv.first].data, total_width);
             log_max = std::max(log_max, kv.first);
         }
+        reduce_section.join();
         c.check_launch("reduce openings");
         c.sync();
     }
@@ -411,7 +459,6 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     std::vector<DBuf> layer_bufs;          // layer i vector (length 2^(log_max - i)), pair layout
     std::vector<DeviceTree> layer_trees;
     std::vector<std::array<uint32_t, 8>> commit_phase_commits;
-    DBuf beta_dev(&c, 8);
     {
         DBuf cur = std::move(ro[log_max]);
         ro.erase(log_max);
@@ -424,12 +471,11 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             commit_phase_commits.push_back(root);
             ch.observe_digest(root.data());
             Ext5 beta = ch.sample_ext();
-            uint32_t bw[5];
-            for (int k = 0; k < 5; k++) bw[k] = beta.c[k].v;
-            c.upload(beta_dev.data, bw, 20);
+            vk::Ext5Arg bw;
+            for (int k = 0; k < 5; k++) bw.w[k] = beta.c[k].v;
             DBuf next(&c, (size_t)(5 * half));
             auto it = ro.find(lf);
-            vk::launch_fri_fold(c.stream, cur.data, L, beta_dev.data, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);
+            vk::launch_fri_fold(c.stream, cur.data, L, bw, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);
             layer_bufs.push_back(std::move(cur));
             cur = std::move(next);
         }
@@ -448,7 +494,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         uint32_t fpw[5];
         ext_to_canonical(fp0, fpw);
         if (fri_.observe_final_poly) ch.observe_ext(fp0);
-        uint32_t pow_witness = ch.grind(fri_.pow_bits);
+        uint32_t pow_witness = grind(ch);
         tm.fri = ms_since(t0);
 
         // ---------------- queries

@@ -57,6 +57,8 @@ class Prover {
     FriParams fri_;
     Poseidon16 perm16_;
     std::vector<DBuf> prog_dev_, iw_dev_;  // per chip: program instructions, interaction words
+    DBuf pow_pos_;                         // [480 rc][16 mds coefficients][16 state][1 best] for k_pow_grind
+    uint32_t grind(Challenger& ch);
 };
 
 }  // namespace vhost

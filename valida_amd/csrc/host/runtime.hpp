@@ -25,15 +25,29 @@ struct DeviceCtx {
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
     vk::Profiler profiler;
+    // Auxiliary streams for fork/join sections: independent per-chip pipelines (tiny matrices are
+    // latency-bound single-block launches) overlap with the big chips' kernels on the main stream.
+    static constexpr int NUM_AUX = 3;
+    hipStream_t aux[NUM_AUX] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[NUM_AUX] = {nullptr, nullptr, nullptr};
+    bool in_section = false;
+    std::vector<void*> deferred;  // blocks released inside a section return to the pool at the join
 
     explicit DeviceCtx(int dev) : device(dev) {
         VG_HIP_CHECK(hipSetDevice(dev));
         VG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (int i = 0; i < NUM_AUX; i++) {
+            VG_HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+            VG_HIP_CHECK(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
+        }
+        VG_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
         init_tables();
     }
     ~DeviceCtx() {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
+        for (int i = 0; i < NUM_AUX; i++) { (void)hipStreamSynchronize(aux[i]); (void)hipStreamDestroy(aux[i]); (void)hipEventDestroy(join_ev[i]); }
+        (void)hipEventDestroy(fork_ev);
         for (auto& kv : free_blocks) (void)hipFree(kv.second);
         for (auto& kv : live_blocks) (void)hipFree(kv.first);
         if (table_mem) (void)hipFree(table_mem);
@@ -54,8 +68,32 @@ struct DeviceCtx {
         if (live > peak_live) peak_live = live;
         return p;
     }
+    // Fork: aux streams wait for everything enqueued so far on the main stream.
+    void fork() {
+        if (in_section) throw std::runtime_error("nested fork");
+        VG_HIP_CHECK(hipEventRecord(fork_ev, stream));
+        for (int i = 0; i < NUM_AUX; i++) VG_HIP_CHECK(hipStreamWaitEvent(aux[i], fork_ev, 0));
+        in_section = true;
+    }
+    // Join: the main stream waits for all aux work; blocks released meanwhile become reusable.
+    void join() {
+        for (int i = 0; i < NUM_AUX; i++) {
+            VG_HIP_CHECK(hipEventRecord(join_ev[i], aux[i]));
+            VG_HIP_CHECK(hipStreamWaitEvent(stream, join_ev[i], 0));
+        }
+        in_section = false;
+        std::vector<void*> d;
+        d.swap(deferred);
+        for (void* p : d) release(p);
+    }
+    // Stream for independent work item `i` of estimated size `rows`: big items stay on the main stream.
+    hipStream_t stream_for(size_t i, uint64_t rows) const {
+        if (!in_section || rows >= (1ull << 16)) return stream;
+        return aux[i % NUM_AUX];
+    }
     void release(void* p) {
         if (!p) return;
+        if (in_section) { deferred.push_back(p); return; }
         auto it = live_blocks.find(p);
         if (it == live_blocks.end()) throw std::runtime_error("release of unknown device block");
         free_blocks.insert({it->second, p});
@@ -84,6 +122,13 @@ struct DeviceCtx {
     void download(void* dst, const void* src, size_t bytes) {
         VG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
         VG_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    // small D2H through pinned memory (a pageable destination makes hipMemcpyAsync take the slow staged path)
+    void download_small(void* dst, const void* src, size_t bytes) {
+        void* pin = pinned_buffer(bytes);
+        VG_HIP_CHECK(hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, stream));
+        VG_HIP_CHECK(hipStreamSynchronize(stream));
+        memcpy(dst, pin, bytes);
     }
     uint32_t* upload_words(const std::vector<uint32_t>& w) {
         uint32_t* d = alloc_words(w.size());
@@ -134,6 +179,17 @@ struct DeviceCtx {
         tables.twc = tables.tw12 + 4096;
         tables.itwc = tables.twc + 4096;
     }
+};
+
+// RAII fork/join: joins on scope exit (also on exceptions) unless join() was called explicitly.
+struct Section {
+    DeviceCtx* c;
+    bool open;
+    explicit Section(DeviceCtx* ctx) : c(ctx), open(true) { c->fork(); }
+    void join() { if (open) { open = false; c->join(); } }
+    ~Section() { if (open) { try { c->join(); } catch (...) { c->in_section = false; } } }
+    Section(const Section&) = delete;
+    Section& operator=(const Section&) = delete;
 };
 
 // Column-major Montgomery matrix in HBM.

@@ -31,6 +31,7 @@ void launch_intt(hipStream_t st, DMatView m, const DeviceTables& tb);
 void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t dst_row0, Fp shift, const DeviceTables& tb);
 // merkle.hip
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);
+void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests);
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next);
 constexpr int KECCAK_TOP_MAX_LEVELS = 11;  // first_len <= 1024
 struct KeccakTopArgs {
@@ -54,7 +55,9 @@ uint64_t col_dot_slots(uint64_t n);
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
                     const uint32_t* scale5_dev, uint32_t* out_dev);
 void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width);
-void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
+struct Ext5Arg { uint32_t w[5]; };  // an extension element passed by value as a kernel argument (Montgomery words)
+void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, Ext5Arg beta, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
+void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev);
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst);
 
 }  // namespace vk

@@ -98,7 +98,17 @@ __device__ __forceinline__ void squeeze_digest(const KState& a, uint32_t (&out)[
 }
 
 // Hash of one row of the column list `cols` (n_elems Montgomery columns, element r of each).
-__device__ __forceinline__ void hash_row(const uint32_t* const* __restrict__ cols, int n_elems, uint64_t r, uint32_t (&out)[8]) {
+struct PtrCols {  // arbitrary column list (mixed matrices of one height)
+    const uint32_t* const* p;
+    __device__ __forceinline__ const uint32_t* operator[](int k) const { return p[k]; }
+};
+struct StridedCols {  // one column-major matrix: no pointer table needed (FRI layer trees)
+    const uint32_t* base;
+    uint64_t stride;
+    __device__ __forceinline__ const uint32_t* operator[](int k) const { return base + (uint64_t)k * stride; }
+};
+template <class Cols>
+__device__ __forceinline__ void hash_row(const Cols cols, int n_elems, uint64_t r, uint32_t (&out)[8]) {
     KState a;
     kstate_zero(a);
     int base = 0;
@@ -142,7 +152,8 @@ __device__ __forceinline__ void store_digest(uint32_t* p, const uint32_t (&d)[8]
 }
 
 // leaf layer: digests[r] = H(row r)
-__global__ void __launch_bounds__(256) k_keccak_leaves(const uint32_t* const* __restrict__ cols, int n_elems, uint64_t n_rows, uint32_t* __restrict__ digests) {
+template <class Cols>
+__global__ void __launch_bounds__(256) k_keccak_leaves(const Cols cols, int n_elems, uint64_t n_rows, uint32_t* __restrict__ digests) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     uint32_t d[8];
@@ -161,7 +172,7 @@ __global__ void __launch_bounds__(256) k_keccak_compress(const uint32_t* __restr
     compress2(l, r, d);
     if (n_elems > 0) {
         uint32_t h[8], d2[8];
-        hash_row(cols, n_elems, i, h);
+        hash_row(PtrCols{cols}, n_elems, i, h);
         compress2(d, h, d2);
         store_digest(next + 8 * i, d2);
     } else {
@@ -184,7 +195,7 @@ __global__ void __launch_bounds__(1024) k_keccak_top(KeccakTopArgs a) {
             compress2(lft, rgt, d);
             if (a.n_elems[l] > 0) {
                 uint32_t h[8], d2[8];
-                hash_row(a.cols[l], a.n_elems[l], i, h);
+                hash_row(PtrCols{a.cols[l]}, a.n_elems[l], i, h);
                 compress2(d, h, d2);
                 store_digest(a.out[l] + 8 * i, d2);
             } else {
@@ -207,7 +218,12 @@ void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
     ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0));
-    hipLaunchKernelGGL(k_keccak_leaves, dim3(blocks), dim3(256), 0, st, cols_dev, n_elems, n_rows, digests);
+    hipLaunchKernelGGL(k_keccak_leaves<PtrCols>, dim3(blocks), dim3(256), 0, st, PtrCols{cols_dev}, n_elems, n_rows, digests);
+}
+void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests) {
+    unsigned blocks = (unsigned)((n_rows + 255) / 256);
+    ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0));
+    hipLaunchKernelGGL(k_keccak_leaves<StridedCols>, dim3(blocks), dim3(256), 0, st, StridedCols{base, stride}, n_elems, n_rows, digests);
 }
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
     unsigned blocks = (unsigned)((n_out + 255) / 256);

@@ -152,13 +152,13 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
 // ---- FRI fold ---------------------------------------------------------------------------------------
 // in: (L/2) x 10 pair layout (stride L/2).  out[i] = (f0 + f1)/2 + (beta/2) x_i^{-1} (f0 - f1) [+ add[i]],
 // x_i^{-1} = w_L^{-bitrev(i)} (no coset shift inside FRI), written in pair layout of length L/2.
-__global__ void __launch_bounds__(256) k_fri_fold(const uint32_t* __restrict__ in, uint64_t L, const uint32_t* __restrict__ beta5, const uint32_t* __restrict__ add,
+__global__ void __launch_bounds__(256) k_fri_fold(const uint32_t* __restrict__ in, uint64_t L, Ext5Arg beta_arg, const uint32_t* __restrict__ add,
                            DeviceTables tb, uint32_t* __restrict__ out) {
     const uint64_t half = L >> 1;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     Ext5 f0 = load_ext(in, half, i), f1 = load_ext(in + 5 * half, half, i);
-    Ext5 beta = ext_from_words(beta5);
+    Ext5 beta = ext_from_words(beta_arg.w);
     Fp xinv = inv_domain_point(tb, (uint32_t)(2 * i));  // f[2i], f[2i+1] sit at +-x, x = w_L^{bitrev_L(2i)}
     Ext5 r = (f0 + f1) + beta * ((f0 - f1) * xinv);
 #pragma unroll
@@ -192,6 +192,54 @@ __global__ void k_gather(const uint32_t* __restrict__ desc, uint64_t n_desc, uin
     }
 }
 
+// ---- proof-of-work grinding ---------------------------------------------------------
+// check_witness(w): observe(w) then sample_bits(bits) == 0.  With k values pending in the input buffer the
+// duplexing overwrites state[0..k] with (pending, w), permutes, and the sample is state[15].  Thread t
+// tries w = first + t; the smallest passing witness is kept with atomicMin (canonical rule: smallest).
+// pos: [480 round constants][16 circulant MDS coefficients m[d] = sum_k (31 w16^d)^k][16 base state], Montgomery.
+__global__ void __launch_bounds__(256) k_pow_grind(const uint32_t* __restrict__ pos, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t mask,
+                                                   uint32_t* __restrict__ best) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t* rc = pos;
+    const uint32_t* mds = pos + 480;
+    const uint32_t* base = pos + 496;
+    Fp st[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) st[i] = Fp::raw(base[i]);
+    const Fp wit = Fp::from_canonical(first + t);
+#pragma unroll
+    for (int i = 0; i < 16; i++) if ((uint32_t)i == k_pending) st[i] = wit;
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) st[i] += Fp::raw(rc[r * 16 + i]);
+        if (r < 4 || r >= 26) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) { Fp x2 = st[i] * st[i]; st[i] = x2 * x2 * st[i]; }
+        } else {
+            Fp x2 = st[0] * st[0];
+            st[0] = x2 * x2 * st[0];
+        }
+        Fp out[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            Fp acc = Fp::zero();
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc += Fp::raw(mds[(j - i) & 15]) * st[i];
+            out[j] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) st[i] = out[i];
+    }
+    if ((st[15].canonical() & mask) == 0) atomicMin(best, first + t);
+}
+
+void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev) {
+    ProfScope ps("k_pow_grind", st, 0.0);
+    hipLaunchKernelGGL(k_pow_grind, dim3((count + 255) / 256), dim3(256), 0, st, pos_dev, k_pending, first, count, (1u << bits) - 1u, best_dev);
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w) {
     ProfScope ps("k_bary_weights", st, 20.0 * n);
@@ -217,10 +265,10 @@ void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L
     ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + 5.0));
     hipLaunchKernelGGL(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out);
 }
-void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
+void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, Ext5Arg beta, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
     uint64_t half = L >> 1;
     ProfScope ps("k_fri_fold", st, 20.0 * L + 20.0 * half * (add ? 2 : 1));
-    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, L, beta5_dev, add, tb, out);
+    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, L, beta, add, tb, out);
 }
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst) {
     if (!n_desc) return;
