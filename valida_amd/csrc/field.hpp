@@ -38,8 +38,9 @@ VG_HD uint32_t monty_reduce(uint64_t t) {
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t m = lo * 0x88000001u;         // lo * p^{-1} mod 2^32
     uint32_t u = mul_hi_u32(m, P);         // (m * p) >> 32 ; low word of m*p equals lo
-    uint32_t r = hi - u;
-    return hi < u ? r + P : r;
+    uint32_t r = hi - u;  // in (-p, p): the wrapped value is huge when negative, so min picks the corrected one
+    uint32_t r2 = r + P;
+    return r < r2 ? r : r2;
 }
 
 struct Fp {
@@ -52,8 +53,9 @@ struct Fp {
     VG_HD bool is_zero() const { return v == 0; }
     VG_HD bool operator==(const Fp& o) const { return v == o.v; }
     VG_HD bool operator!=(const Fp& o) const { return v != o.v; }
-    VG_HD Fp operator+(const Fp& o) const { uint32_t s = v + o.v; return raw(s >= P ? s - P : s); }
-    VG_HD Fp operator-(const Fp& o) const { uint32_t d = v - o.v; return raw(v < o.v ? d + P : d); }
+    // branch-free via unsigned min (v_min_u32): 3 VALU instructions each
+    VG_HD Fp operator+(const Fp& o) const { uint32_t s = v + o.v, t = s - P; return raw(s < t ? s : t); }
+    VG_HD Fp operator-(const Fp& o) const { uint32_t d = v - o.v, t = d + P; return raw(d < t ? d : t); }
     VG_HD Fp operator-() const { return raw(v ? P - v : 0); }
     VG_HD Fp operator*(const Fp& o) const { return raw(monty_reduce((uint64_t)v * o.v)); }
     VG_HD Fp& operator+=(const Fp& o) { *this = *this + o; return *this; }
@@ -118,16 +120,22 @@ struct Ext5 {
         return r;
     }
     VG_HD Ext5 exp_power_of_2(unsigned k) const { Ext5 r = *this; for (unsigned i = 0; i < k; i++) r *= r; return r; }
-    // Frobenius x -> x^p acts on X^i by multiplying with z^i, z = 2^((p-1)/5) (canonical 815036133).
-    VG_HD Ext5 frobenius() const {
-        const Fp z1 = Fp::from_canonical(815036133u);
-        const Fp z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
-        Ext5 r; r.c[0] = c[0]; r.c[1] = c[1] * z1; r.c[2] = c[2] * z2; r.c[3] = c[3] * z3; r.c[4] = c[4] * z4;
+    // Frobenius^K: x -> x^(p^K) multiplies the X^i coefficient by z^(iK), z = 2^((p-1)/5) (canonical 815036133).
+    // Constants below are z^j in Montgomery form, j = 1..4.
+    template <int K> VG_HD Ext5 frobenius_k() const {
+        constexpr uint32_t Z[5] = {0, 1079828539u, 847078768u, 1597816133u, 233372948u};
+        Ext5 r;
+        r.c[0] = c[0];
+        r.c[1] = c[1] * Fp::raw(Z[(1 * K) % 5]);
+        r.c[2] = c[2] * Fp::raw(Z[(2 * K) % 5]);
+        r.c[3] = c[3] * Fp::raw(Z[(3 * K) % 5]);
+        r.c[4] = c[4] * Fp::raw(Z[(4 * K) % 5]);
         return r;
     }
+    VG_HD Ext5 frobenius() const { return frobenius_k<1>(); }
     // a^{-1} = (prod_{k=1..4} frob^k(a)) / Norm(a), Norm(a) = a * prod in the base field.  0 -> 0.
     VG_HD Ext5 inv() const {
-        Ext5 f1 = frobenius(), f2 = f1.frobenius(), f3 = f2.frobenius(), f4 = f3.frobenius();
+        Ext5 f1 = frobenius_k<1>(), f2 = frobenius_k<2>(), f3 = frobenius_k<3>(), f4 = frobenius_k<4>();
         Ext5 prod = (f1 * f2) * (f3 * f4);
         // only the constant coefficient of a*prod is needed
         Fp hi = c[1] * prod.c[4] + c[2] * prod.c[3] + c[3] * prod.c[2] + c[4] * prod.c[1];

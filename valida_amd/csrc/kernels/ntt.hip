@@ -99,25 +99,31 @@ __device__ __forceinline__ Fp bit_product(const uint32_t* table, int base, uint3
 
 __host__ __device__ inline int padded_words(int n) { return n + (n >> 4); }
 
-// ---- inverse, contiguous pass: grid = (N / N_lo, columns) --------------------------------------------
+// ---- inverse, contiguous pass: persistent blocks over (N / N_lo) x columns tiles ----------------------
 // In place on `data` (column-major, height N = 2^k).  k_lo = min(k, 12) stages on each contiguous block
 // of N_lo points.  If k_hi > 0 multiplies element r of block h by w_N^{-bitrev(h) * r}; else scales by 1/N.
+// Blocks grid-stride over tiles so the compact twiddle tables are staged into LDS once per block.
 __global__ void k_intt_contig(DMatView m, int k, int k_lo, DeviceTables tb, uint32_t n_inv_mont) {
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo, k_hi = k - k_lo;
     uint32_t* tw = lds + padded_words(n_lo);
-    uint32_t* col = m.col(blockIdx.y) + (uint64_t)blockIdx.x * n_lo;
-    for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[tile_addr<true>(i, 0, 0)] = col[i];
     stage_twiddles(tw, tb.itwc, k_lo);
-    __syncthreads();
-    tile_transform<true, true>(lds, tw, k_lo, 0, 0);
-    if (k_hi > 0) {
-        Fp base = bit_product(tb.inv_roots, k_lo + 1, blockIdx.x);  // w_N^{-bitrev_{k_hi}(h)}
-        Fp step = base.pow(blockDim.x), cur = base.pow(threadIdx.x);
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { col[i] = (Fp::raw(lds[tile_addr<true>(i, 0, 0)]) * cur).v; cur *= step; }
-    } else {
-        Fp ninv = Fp::raw(n_inv_mont);
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) col[i] = (Fp::raw(lds[tile_addr<true>(i, 0, 0)]) * ninv).v;
+    const uint64_t tiles_per_col = m.height >> k_lo, total = tiles_per_col * m.width;
+    for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint64_t cidx = t / tiles_per_col, h = t - cidx * tiles_per_col;
+        uint32_t* col = m.col(cidx) + h * n_lo;
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[tile_addr<true>(i, 0, 0)] = col[i];
+        __syncthreads();
+        tile_transform<true, true>(lds, tw, k_lo, 0, 0);
+        if (k_hi > 0) {
+            Fp base = bit_product(tb.inv_roots, k_lo + 1, (uint32_t)h);  // w_N^{-bitrev_{k_hi}(h)}
+            Fp step = base.pow(blockDim.x), cur = base.pow(threadIdx.x);
+            for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { col[i] = (Fp::raw(lds[tile_addr<true>(i, 0, 0)]) * cur).v; cur *= step; }
+        } else {
+            Fp ninv = Fp::raw(n_inv_mont);
+            for (int i = threadIdx.x; i < n_lo; i += blockDim.x) col[i] = (Fp::raw(lds[tile_addr<true>(i, 0, 0)]) * ninv).v;
+        }
+        __syncthreads();
     }
 }
 
@@ -170,7 +176,7 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
     for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; out[h * n_lo + c] = lds[h * LD + c]; }
 }
 
-// ---- forward, contiguous pass: grid = (N / N_lo, columns) --------------------------------------------
+// ---- forward, contiguous pass: persistent blocks over (N / N_lo) x columns tiles ----------------------
 // DIF over each contiguous block of N_lo points of `dst` rows [dst_row0, dst_row0 + N).  When the whole
 // transform fits one pass (k_hi == 0) the input is read from `src` and multiplied by shift^i first.
 __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, DeviceTables tb, uint32_t shift_mont,
@@ -178,19 +184,25 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo;
     uint32_t* tw = lds + padded_words(n_lo);
-    uint32_t* out = dst.col(blockIdx.y) + dst_row0 + (uint64_t)blockIdx.x * n_lo;
-    if (from_src) {
-        const uint32_t* in = src.col(blockIdx.y);
-        Fp shift = Fp::raw(shift_mont);
-        Fp cur = shift.pow(threadIdx.x), step = shift.pow(blockDim.x);
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { lds[tile_addr<true>(i, 0, 0)] = (Fp::raw(in[i]) * cur).v; cur *= step; }
-    } else {
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[tile_addr<true>(i, 0, 0)] = out[i];
-    }
     stage_twiddles(tw, tb.twc, k_lo);
-    __syncthreads();
-    tile_transform<false, true>(lds, tw, k_lo, 0, 0);
-    for (int i = threadIdx.x; i < n_lo; i += blockDim.x) out[i] = lds[tile_addr<true>(i, 0, 0)];
+    const uint64_t tiles_per_col = src.height >> k_lo, total = tiles_per_col * src.width;
+    Fp cur0 = Fp::one(), step = Fp::one();
+    if (from_src) { Fp shift = Fp::raw(shift_mont); cur0 = shift.pow(threadIdx.x); step = shift.pow(blockDim.x); }
+    for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint64_t cidx = t / tiles_per_col, h = t - cidx * tiles_per_col;
+        uint32_t* out = dst.col(cidx) + dst_row0 + h * n_lo;
+        if (from_src) {  // single-pass transform: tiles_per_col == 1
+            const uint32_t* in = src.col(cidx);
+            Fp cur = cur0;
+            for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { lds[tile_addr<true>(i, 0, 0)] = (Fp::raw(in[i]) * cur).v; cur *= step; }
+        } else {
+            for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[tile_addr<true>(i, 0, 0)] = out[i];
+        }
+        __syncthreads();
+        tile_transform<false, true>(lds, tw, k_lo, 0, 0);
+        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) out[i] = lds[tile_addr<true>(i, 0, 0)];
+        __syncthreads();
+    }
 }
 
 // ---- host launchers -----------------------------------------------------------------------------------
@@ -228,7 +240,8 @@ void launch_intt(hipStream_t st, DMatView m, const DeviceTables& tb) {
     int k = (int)vg::log2_strict_u64(m.height);
     NttPlan p = make_plan(k);
     uint32_t ninv = Fp::from_canonical((uint32_t)(m.height % vg::P)).inv().v;
-    dim3 gc((unsigned)(m.height >> p.k_lo), (unsigned)m.width);
+    const uint64_t tiles_c = (m.height >> p.k_lo) * m.width;
+    dim3 gc((unsigned)(tiles_c < 4096 ? tiles_c : 4096));
     const double pass_bytes = 8.0 * m.height * m.width;
     {
         ProfScope ps("k_intt_contig", st, pass_bytes);
@@ -247,7 +260,8 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
     set_lds_limit();
     int k = (int)vg::log2_strict_u64(coeffs.height);
     NttPlan p = make_plan(k);
-    dim3 gc((unsigned)(coeffs.height >> p.k_lo), (unsigned)coeffs.width);
+    const uint64_t tiles_c = (coeffs.height >> p.k_lo) * coeffs.width;
+    dim3 gc((unsigned)(tiles_c < 4096 ? tiles_c : 4096));
     const double pass_bytes = 8.0 * coeffs.height * coeffs.width;
     if (p.k_hi > 0) {
         dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)coeffs.width);
