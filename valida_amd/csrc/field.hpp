@@ -43,6 +43,19 @@ VG_HD uint32_t monty_reduce(uint64_t t) {
     return r < r2 ? r : r2;
 }
 
+// Montgomery reduction of a lazily accumulated sum of up to FOUR products of values < p
+// (t < 4 p^2 < 2^64, high word < 2p): one conditional subtraction of p * 2^32 first, then as above.
+// 7 VALU instructions for 4 multiply-adds that each cost one v_mad_u64_u32.
+VG_HD uint32_t monty_reduce_wide(uint64_t t) {
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t h2 = hi - P;
+    hi = hi < h2 ? hi : h2;
+    uint32_t m = lo * 0x88000001u;
+    uint32_t u = mul_hi_u32(m, P);
+    uint32_t r = hi - u, r2 = r + P;
+    return r < r2 ? r : r2;
+}
+
 struct Fp {
     uint32_t v;  // Montgomery representation, < p
     VG_HD static Fp raw(uint32_t m) { Fp r; r.v = m; return r; }

@@ -26,17 +26,29 @@ template <bool PAD> __device__ __forceinline__ int tile_addr(int i, int c, int L
 
 // One round = stages s_lo .. s_lo + R - 1 of the radix-2 network on a tile of 2^logn points x 2^logT columns.
 // tw: compact tables in LDS, stage s at offset 2^(s-1) - 1: tw[off + j] = w_{2^s}^{+-j}, j < 2^(s-1).
-template <int R, bool DIT, bool PAD>
+// LB >= 0 fixes s_lo - 1 at compile time (the 2^12-point contiguous tile: every LDS address of the 16
+// points and 15 twiddles becomes base + immediate offset, no per-access address arithmetic).
+template <int R, bool DIT, bool PAD, int LB>
 __device__ __forceinline__ void ntt_round(uint32_t* buf, const uint32_t* tw, int logn, int s_lo, int logT, int LD) {
     constexpr int G = 1 << R;
     const int n_items = (1 << (logn - R)) << logT;
-    const int maskT = (1 << logT) - 1, lowbits = s_lo - 1, lowmask = (1 << lowbits) - 1;
+    const int maskT = (1 << logT) - 1, lowbits = LB >= 0 ? LB : s_lo - 1, lowmask = (1 << lowbits) - 1;
+    // the 16 points of a work item are base | (g << lowbits); in both layouts their addresses are linear in g
+    // unless a padded tile has the g bits straddling bit 4
+    const bool linear = !PAD || lowbits >= 4 || lowbits + R <= 4;
+    const int gs = PAD ? (lowbits >= 4 ? (1 << lowbits) + (1 << (lowbits - 4)) : (1 << lowbits)) : (LD << lowbits);
     for (int w = threadIdx.x; w < n_items; w += blockDim.x) {
         const int c = w & maskT, q = w >> logT;
         const int low = q & lowmask, base = ((q >> lowbits) << (lowbits + R)) | low;
+        uint32_t* p0 = buf + tile_addr<PAD>(base, c, LD);
         Fp x[G];
+        if (linear) {
 #pragma unroll
-        for (int g = 0; g < G; g++) x[g] = Fp::raw(buf[tile_addr<PAD>(base | (g << lowbits), c, LD)]);
+            for (int g = 0; g < G; g++) x[g] = Fp::raw(p0[g * gs]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; g++) x[g] = Fp::raw(buf[tile_addr<PAD>(base | (g << lowbits), c, LD)]);
+        }
 #pragma unroll
         for (int step = 0; step < R; step++) {
             const int st = DIT ? step : R - 1 - step;  // stage s = s_lo + st pairs g differing in bit st
@@ -51,11 +63,21 @@ __device__ __forceinline__ void ntt_round(uint32_t* buf, const uint32_t* tw, int
                 const int g0 = ((p >> st) << (st + 1)) | (p & (half - 1)), g1 = g0 | half;
                 const Fp wk = wv[p & (half - 1)];
                 if (DIT) { Fp u = x[g0], v = x[g1] * wk; x[g0] = u + v; x[g1] = u - v; }
-                else { Fp u = x[g0], v = x[g1]; x[g0] = u + v; x[g1] = (u - v) * wk; }
+                else {
+                    // (u - v) * w with the difference left unreduced in (0, 2p): the Montgomery product only needs a * b < p * 2^32
+                    Fp u = x[g0], v = x[g1];
+                    x[g0] = u + v;
+                    x[g1] = Fp::raw(vg::monty_reduce((uint64_t)(u.v + (vg::P - v.v)) * wk.v));
+                }
             }
         }
+        if (linear) {
 #pragma unroll
-        for (int g = 0; g < G; g++) buf[tile_addr<PAD>(base | (g << lowbits), c, LD)] = x[g].v;
+            for (int g = 0; g < G; g++) p0[g * gs] = x[g].v;
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; g++) buf[tile_addr<PAD>(base | (g << lowbits), c, LD)] = x[g].v;
+        }
     }
     __syncthreads();
 }
@@ -63,10 +85,10 @@ __device__ __forceinline__ void ntt_round(uint32_t* buf, const uint32_t* tw, int
 template <bool DIT, bool PAD>
 __device__ __forceinline__ void ntt_round_dispatch(int R, uint32_t* buf, const uint32_t* tw, int logn, int s_lo, int logT, int LD) {
     switch (R) {
-        case 1: ntt_round<1, DIT, PAD>(buf, tw, logn, s_lo, logT, LD); break;
-        case 2: ntt_round<2, DIT, PAD>(buf, tw, logn, s_lo, logT, LD); break;
-        case 3: ntt_round<3, DIT, PAD>(buf, tw, logn, s_lo, logT, LD); break;
-        default: ntt_round<4, DIT, PAD>(buf, tw, logn, s_lo, logT, LD); break;
+        case 1: ntt_round<1, DIT, PAD, -1>(buf, tw, logn, s_lo, logT, LD); break;
+        case 2: ntt_round<2, DIT, PAD, -1>(buf, tw, logn, s_lo, logT, LD); break;
+        case 3: ntt_round<3, DIT, PAD, -1>(buf, tw, logn, s_lo, logT, LD); break;
+        default: ntt_round<4, DIT, PAD, -1>(buf, tw, logn, s_lo, logT, LD); break;
     }
 }
 
@@ -75,6 +97,18 @@ __device__ __forceinline__ void ntt_round_dispatch(int R, uint32_t* buf, const u
 template <bool DIT, bool PAD>
 __device__ __forceinline__ void tile_transform(uint32_t* buf, const uint32_t* tw, int logn, int logT, int LD) {
     if (logn == 0) return;
+    if (PAD && logn == 12) {  // the hot case: three radix-16 rounds with compile-time strides
+        if (DIT) {
+            ntt_round<4, true, PAD, 0>(buf, tw, 12, 1, 0, LD);
+            ntt_round<4, true, PAD, 4>(buf, tw, 12, 5, 0, LD);
+            ntt_round<4, true, PAD, 8>(buf, tw, 12, 9, 0, LD);
+        } else {
+            ntt_round<4, false, PAD, 8>(buf, tw, 12, 9, 0, LD);
+            ntt_round<4, false, PAD, 4>(buf, tw, 12, 5, 0, LD);
+            ntt_round<4, false, PAD, 0>(buf, tw, 12, 1, 0, LD);
+        }
+        return;
+    }
     const int rounds = (logn + 3) >> 2, small = logn / rounds, extra = logn - small * rounds;
     if (DIT) {
         int s_lo = 1;

@@ -74,8 +74,15 @@ __global__ void __launch_bounds__(DOT_THREADS) k_col_dot(DMatView m, uint64_t n,
                 const uint32_t* mp = Mt + c;
                 const uint32_t* wp = Wt + pk;
                 Fp a = acc[q];
-#pragma unroll 8
-                for (int r = 0; r < DOT_TR; r++) a += Fp::raw(mp[r * LD]) * Fp::raw(wp[r * WLD]);
+                // lazy accumulation: four raw 64-bit products (one v_mad_u64_u32 each) per Montgomery reduction
+#pragma unroll 4
+                for (int r = 0; r < DOT_TR; r += 4) {
+                    uint64_t t = (uint64_t)mp[r * LD] * wp[r * WLD];
+                    t += (uint64_t)mp[(r + 1) * LD] * wp[(r + 1) * WLD];
+                    t += (uint64_t)mp[(r + 2) * LD] * wp[(r + 2) * WLD];
+                    t += (uint64_t)mp[(r + 3) * LD] * wp[(r + 3) * WLD];
+                    a += Fp::raw(vg::monty_reduce_wide(t));
+                }
                 acc[q] = a;
             }
         }
@@ -131,8 +138,20 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
         const uint64_t stride = ((uint64_t)md[3] << 32) | md[2];
         const uint32_t width = md[4], npts = md[5];
         md += 6;
+        // reduced row sum_c alpha^c * M[j][c], lazily: 4 columns per Montgomery reduction and limb
         Ext5 rr = Ext5::zero();
-        for (uint32_t c = 0; c < width; c++) rr += ext_from_words(apow + 5 * c) * Fp::raw(colp[(uint64_t)c * stride + j]);
+        uint32_t c = 0;
+        for (; c + 4 <= width; c += 4) {
+            const uint32_t v0 = colp[(uint64_t)c * stride + j], v1 = colp[(uint64_t)(c + 1) * stride + j];
+            const uint32_t v2 = colp[(uint64_t)(c + 2) * stride + j], v3 = colp[(uint64_t)(c + 3) * stride + j];
+            const uint32_t* a0 = apow + 5 * c;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                uint64_t t = (uint64_t)a0[k] * v0 + (uint64_t)a0[5 + k] * v1 + (uint64_t)a0[10 + k] * v2 + (uint64_t)a0[15 + k] * v3;
+                rr.c[k] += Fp::raw(vg::monty_reduce_wide(t));
+            }
+        }
+        for (; c < width; c++) rr += ext_from_words(apow + 5 * c) * Fp::raw(colp[(uint64_t)c * stride + j]);
         for (uint32_t q = 0; q < npts; q++, md += 11) {
             Ext5 t = ext_from_words(md + 1) * (ext_from_words(md + 6) - rr);
             const uint32_t slot = md[0];
@@ -141,10 +160,18 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
         }
     }
     Fp x = Fp::raw(shift) * domain_point(tb, (uint32_t)j);
-    Ext5 ro = Ext5::zero();
+    // 1/(z_p - x) for all points with ONE Ext5 inversion (Montgomery's trick); denominators are nonzero
+    // (x lies on the coset 31*H, the z_p are out-of-domain challenges)
+    Ext5 d[MAX_OPEN_POINTS], pre[MAX_OPEN_POINTS];
+    Ext5 run = Ext5::one();
 #pragma unroll
     for (int p = 0; p < MAX_OPEN_POINTS; p++)
-        if ((uint32_t)p < n_points) ro += S[p] * (ext_from_words(zs + 5 * p) - x).inv();
+        if ((uint32_t)p < n_points) { d[p] = ext_from_words(zs + 5 * p) - x; pre[p] = run; run = run * d[p]; }
+    Ext5 inv_run = run.inv();
+    Ext5 ro = Ext5::zero();
+#pragma unroll
+    for (int p = MAX_OPEN_POINTS - 1; p >= 0; p--)
+        if ((uint32_t)p < n_points) { ro += S[p] * (inv_run * pre[p]); inv_run = inv_run * d[p]; }
     const uint64_t half = L >> 1;
     store_ext(out + (j & 1) * 5 * half, half, j >> 1, ro);
 }
