@@ -124,7 +124,7 @@ inline unsigned log2_ceil_u(unsigned n) { unsigned k = 0; while ((1u << k) < n) 
 inline unsigned log_quotient_degree_from(int max_constraint_degree) { return log2_ceil_u((unsigned)std::max(max_constraint_degree, 3) - 1); }
 
 // ---- device constraint program -------------------------------------------------------------------
-enum OpCode : uint8_t { OP_CONST = 0, OP_LOAD_MAIN, OP_LOAD_PREP, OP_SEL_FIRST, OP_SEL_LAST, OP_SEL_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_ASSERT };
+enum OpCode : uint8_t { OP_CONST = 0, OP_LOAD_MAIN, OP_LOAD_PREP, OP_SEL_FIRST, OP_SEL_LAST, OP_SEL_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_ASSERT, OP_NOP };
 
 struct Instr {  // 8 bytes
     uint8_t op, flag;  // flag: is_next for loads
@@ -222,6 +222,7 @@ inline Program compile(const Dag& dag) {
         if (last_use[e] < 0) { free_regs.push_back(dst); reg_of[e] = -1; }  // unreachable in practice
     }
     p.num_regs = next_reg;
+    while (p.instrs.size() % 4) p.instrs.push_back({OP_NOP, 0, 0, 0, 0});  // the device interpreter fetches 4 instructions at a time
     return p;
 }
 
@@ -246,6 +247,7 @@ struct HostEval {
                 case OP_MUL: regs[in.dst] = regs[in.a] * regs[in.b]; break;
                 case OP_NEG: regs[in.dst] = -regs[in.a]; break;
                 case OP_ASSERT: out.push_back(regs[in.a]); break;
+                case OP_NOP: break;
             }
         }
         return out;

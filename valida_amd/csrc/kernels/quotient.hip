@@ -26,28 +26,64 @@ struct PointCtx {
     Fp is_first, is_last, is_trans;
 };
 
+// Register file of the interpreter.  Register indices come from the program (wave-uniform), so a
+// VGPR-resident 32-lane vector indexed through s_set_gpr_idx (no LDS round trip, no scratch) holds the
+// registers: one bank for programs with <= 32 registers, two for <= 64; larger programs fall back to an
+// LDS file (slot-major reg[slot][thread], conflict-free).
+typedef uint32_t v32u __attribute__((ext_vector_type(32)));
+
+#define VG_INTERP_BODY(GET, SET)                                                                                                        \
+    switch (in.op) {                                                                                                                    \
+        case vair::OP_CONST: SET(in.dst, (uint32_t)in.a | ((uint32_t)in.b << 16)); break;                                               \
+        case vair::OP_LOAD_MAIN: SET(in.dst, a.main_lde.data[(uint64_t)in.a * a.main_lde.stride + (in.flag ? p.next_row : p.row)]); break; \
+        case vair::OP_LOAD_PREP: SET(in.dst, a.prep_lde.data[(uint64_t)in.a * a.prep_lde.stride + (in.flag ? p.next_row : p.row)]); break; \
+        case vair::OP_SEL_FIRST: SET(in.dst, p.is_first.v); break;                                                                      \
+        case vair::OP_SEL_LAST: SET(in.dst, p.is_last.v); break;                                                                        \
+        case vair::OP_SEL_TRANS: SET(in.dst, p.is_trans.v); break;                                                                      \
+        case vair::OP_ADD: { uint32_t x = GET(in.a), y = GET(in.b); SET(in.dst, (Fp::raw(x) + Fp::raw(y)).v); } break;                  \
+        case vair::OP_SUB: { uint32_t x = GET(in.a), y = GET(in.b); SET(in.dst, (Fp::raw(x) - Fp::raw(y)).v); } break;                  \
+        case vair::OP_MUL: { uint32_t x = GET(in.a), y = GET(in.b); SET(in.dst, (Fp::raw(x) * Fp::raw(y)).v); } break;                  \
+        case vair::OP_NEG: { uint32_t x = GET(in.a); SET(in.dst, (-Fp::raw(x)).v); } break;                                             \
+        case vair::OP_ASSERT: { uint32_t x = GET(in.a); acc += ext_from_words(a.consts + 5 * k) * Fp::raw(x); k++; } break;             \
+        default: break; /* OP_NOP padding */                                                                                            \
+    }
+
 // Interpret the chip program at one point; returns sum_k alpha_pow[k] * c_k over the chip's constraints.
-__device__ __forceinline__ Ext5 run_program(const QuotientArgs& a, const PointCtx& p, uint32_t* regs /* LDS, slot stride = blockDim.x */) {
+// Instructions are fetched four at a time (programs are padded with NOPs to a multiple of 4).
+template <int NB>
+__device__ __forceinline__ Ext5 run_program_vgpr(const QuotientArgs& a, const PointCtx& p) {
     Ext5 acc = Ext5::zero();
-    const uint32_t S = blockDim.x;
-    uint32_t* r = regs + threadIdx.x;
     uint32_t k = 0;
-    for (uint32_t pc = 0; pc < a.n_instrs; pc++) {
-        const vair::Instr in = a.prog[pc];
-        switch (in.op) {
-            case vair::OP_CONST: r[in.dst * S] = (uint32_t)in.a | ((uint32_t)in.b << 16); break;
-            case vair::OP_LOAD_MAIN: r[in.dst * S] = a.main_lde.data[(uint64_t)in.a * a.main_lde.stride + (in.flag ? p.next_row : p.row)]; break;
-            case vair::OP_LOAD_PREP: r[in.dst * S] = a.prep_lde.data[(uint64_t)in.a * a.prep_lde.stride + (in.flag ? p.next_row : p.row)]; break;
-            case vair::OP_SEL_FIRST: r[in.dst * S] = p.is_first.v; break;
-            case vair::OP_SEL_LAST: r[in.dst * S] = p.is_last.v; break;
-            case vair::OP_SEL_TRANS: r[in.dst * S] = p.is_trans.v; break;
-            case vair::OP_ADD: r[in.dst * S] = (Fp::raw(r[in.a * S]) + Fp::raw(r[in.b * S])).v; break;
-            case vair::OP_SUB: r[in.dst * S] = (Fp::raw(r[in.a * S]) - Fp::raw(r[in.b * S])).v; break;
-            case vair::OP_MUL: r[in.dst * S] = (Fp::raw(r[in.a * S]) * Fp::raw(r[in.b * S])).v; break;
-            case vair::OP_NEG: r[in.dst * S] = (-Fp::raw(r[in.a * S])).v; break;
-            case vair::OP_ASSERT: acc += ext_from_words(a.consts + 5 * k) * Fp::raw(r[in.a * S]); k++; break;
+    v32u r0 = {}, r1 = {};
+#define VG_GET(i) (NB == 1 ? r0[(i) & 31] : ((i) < 32 ? r0[(i) & 31] : r1[(i) & 31]))
+#define VG_SET(i, val) do { uint32_t _v = (val); if (NB == 1 || (i) < 32) r0[(i) & 31] = _v; else r1[(i) & 31] = _v; } while (0)
+    for (uint32_t pc = 0; pc < a.n_instrs; pc += 4) {
+        vair::Instr quad[4];
+        __builtin_memcpy(quad, a.prog + pc, 32);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const vair::Instr in = quad[u];
+            VG_INTERP_BODY(VG_GET, VG_SET)
         }
     }
+#undef VG_GET
+#undef VG_SET
+    return acc;
+}
+
+__device__ __forceinline__ Ext5 run_program_lds(const QuotientArgs& a, const PointCtx& p, uint32_t* regs /* LDS, slot stride = blockDim.x */) {
+    Ext5 acc = Ext5::zero();
+    uint32_t k = 0;
+    const uint32_t S = blockDim.x;
+    uint32_t* r = regs + threadIdx.x;
+#define VG_GET(i) (r[(uint32_t)(i) * S])
+#define VG_SET(i, val) (r[(uint32_t)(i) * S] = (val))
+    for (uint32_t pc = 0; pc < a.n_instrs; pc++) {
+        const vair::Instr in = a.prog[pc];
+        VG_INTERP_BODY(VG_GET, VG_SET)
+    }
+#undef VG_GET
+#undef VG_SET
     return acc;
 }
 
@@ -87,7 +123,8 @@ __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const Po
     return acc;
 }
 
-__global__ void k_quotient(QuotientArgs a, DeviceTables tb) {
+template <int RFKIND>  // 0: LDS file, 1: one VGPR bank (<= 32 registers), 2: two banks (<= 64)
+__global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables tb) {
     extern __shared__ uint32_t regs[];
     const uint64_t n = 1ull << a.log_n;
     const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,8 +148,16 @@ __global__ void k_quotient(QuotientArgs a, DeviceTables tb) {
     p1.row = j1; p1.next_row = vg::reverse_bits_len((i1 + 2u) & Qmask, (unsigned)kq);
     p0.is_trans = d01; p0.is_first = Fp::raw(a.zh[par0]) * id00; p0.is_last = Fp::raw(a.zh[par0]) * id01;
     p1.is_trans = d11; p1.is_first = Fp::raw(a.zh[par1]) * id10; p1.is_last = Fp::raw(a.zh[par1]) * id11;
-    Ext5 q0 = (run_program(a, p0, regs) + perm_constraints(a, p0)) * Fp::raw(a.zh_inv[par0]);
-    Ext5 q1 = (run_program(a, p1, regs) + perm_constraints(a, p1)) * Fp::raw(a.zh_inv[par1]);
+    Ext5 q0, q1;
+    if (RFKIND == 0) {
+        q0 = run_program_lds(a, p0, regs);
+        q1 = run_program_lds(a, p1, regs);
+    } else {
+        q0 = run_program_vgpr<RFKIND>(a, p0);
+        q1 = run_program_vgpr<RFKIND>(a, p1);
+    }
+    q0 = (q0 + perm_constraints(a, p0)) * Fp::raw(a.zh_inv[par0]);
+    q1 = (q1 + perm_constraints(a, p1)) * Fp::raw(a.zh_inv[par1]);
     // decompose (App. B11): even = (a+b)/2, odd = (a-b)/(2 x0)
     Fp x0_inv = Fp::raw(a.coset_shift_inv) * inv_domain_point(tb, j0);
     Ext5 sum = q0 + q1, diff = (q0 - q1) * x0_inv;
@@ -125,13 +170,20 @@ __global__ void k_quotient(QuotientArgs a, DeviceTables tb) {
 
 void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& tb) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_quotient, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    unsigned threads = 256;
-    while (threads > 64 && (size_t)a.n_regs * threads * 4 > 64 * 1024) threads >>= 1;
-    size_t lds = (size_t)(a.n_regs ? a.n_regs : 1) * threads * 4;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     uint64_t n = 1ull << a.log_n;
     ProfScope ps("k_quotient", st, 4.0 * n * (2.0 * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 10.0));
-    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), lds, st, a, tb);
+    if (a.n_regs <= 64) {
+        const unsigned threads = 256;
+        dim3 grid((unsigned)((n + threads - 1) / threads));
+        if (a.n_regs <= 32) hipLaunchKernelGGL(k_quotient<1>, grid, dim3(threads), 0, st, a, tb);
+        else hipLaunchKernelGGL(k_quotient<2>, grid, dim3(threads), 0, st, a, tb);
+        return;
+    }
+    unsigned threads = 256;
+    while (threads > 64 && (size_t)a.n_regs * threads * 4 > 64 * 1024) threads >>= 1;
+    size_t lds = (size_t)a.n_regs * threads * 4;
+    hipLaunchKernelGGL(k_quotient<0>, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), lds, st, a, tb);
 }
 
 }  // namespace vk
