@@ -161,6 +161,8 @@ void vgpu_proof_free(vgpu_proof_t* pr);
 typedef struct vgpu_workload vgpu_workload_t;
 /* fib_program (basic/tests/test_prover.rs:35-188) with loop bound n, fp = 0x1000, run to STOP, traces generated */
 int32_t vgpu_workload_fib(uint32_t n, vgpu_workload_t** out);
+/* ALU-heavy loop (SURVEY.md §8 workload C4): add, sub, xor, and, or, lt, addi, addi, bne per iteration */
+int32_t vgpu_workload_alu(uint32_t iters, vgpu_workload_t** out);
 void vgpu_workload_free(vgpu_workload_t* w);
 /* stats: [cycles, cpu ops, memory ops, add ops, result word (u32 at fp+4), program length, padded cpu height] */
 void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]);

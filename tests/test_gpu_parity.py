@@ -187,3 +187,35 @@ def test_repeated_proofs_are_identical(prover, fib25):
     a = prover.prove(dmain, dprep)
     b = prover.prove(dmain, dprep)
     assert a.bytes() == b.bytes()
+
+
+# ---- other BASELINE configs as parity cases: C4 (ALU-heavy, multi-chip) and C3's 4x blowup ---------------------
+def test_alu_workload_proof_bytes(prover, rc):
+    w = va.Workload.alu(100)  # add / sub / bitwise / lt chips populated, range bus busy
+    assert w.cpu_height == 1024
+    proof, ref, prep = _prove_both(prover, w, rc)
+    for chip in range(va.NUM_CHIPS):
+        assert first_mismatch(proof.debug_quotient(chip), ref.quotient(chip)) is None, "quotient chunks of chip %d (%s)" % (chip, va.CHIP_NAMES[chip])
+    assert first_mismatch(proof.words, ref.words) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc) is None
+
+
+@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(40), lambda: va.Workload.fib(582)])
+def test_blowup4_proof_bytes(machine, rc, make):
+    p4 = va.Prover(machine, rc, log_blowup=2)
+    w = make()
+    mt, prep = w.main_traces(), w.preprocessed()
+    proof = p4.prove([p4.upload(m) for m in mt], [(c, p4.upload(m)) for c, m in prep])
+    ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc, log_blowup=2)
+    assert first_mismatch(proof.words, ref.words) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc, log_blowup=2) is None
+
+
+def test_lde_blowup4_matches_oracle(machine, rc):
+    p4 = va.Prover(machine, rc, log_blowup=2)
+    rng = np.random.default_rng(77)
+    for log_h, w in [(0, 2), (5, 3), (13, 2)]:
+        m = rand_matrix(rng, 1 << log_h, w)
+        pd = p4.commit_batches([p4.upload(m)])
+        assert first_mismatch(pd.lde(0), po.committed_lde(m, 2, 31)) is None
+        assert first_mismatch(pd.root, po.commit_root([m], log_blowup=2)) is None

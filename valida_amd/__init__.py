@@ -109,6 +109,13 @@ class Workload:
         _check(lib().vgpu_workload_fib(ctypes.c_uint32(n), ctypes.byref(h)))
         return cls(h)
 
+    @classmethod
+    def alu(cls, iters):
+        """ALU-heavy loop (workload C4): 4 + 9 * iters + 1 cycles, exercising add / sub / bitwise / lt chips."""
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_workload_alu(ctypes.c_uint32(iters), ctypes.byref(h)))
+        return cls(h)
+
     def main_trace(self, chip):
         data, h, w = c_u32p(), ctypes.c_uint64(), ctypes.c_uint64()
         _check(lib().vgpu_workload_main_trace(self._h, ctypes.c_uint32(chip), ctypes.byref(data), ctypes.byref(h), ctypes.byref(w)))

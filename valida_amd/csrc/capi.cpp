@@ -327,6 +327,20 @@ int32_t vgpu_workload_fib(uint32_t n, vgpu_workload_t** out) {
         *out = w.release();
     })
 }
+int32_t vgpu_workload_alu(uint32_t iters, vgpu_workload_t** out) {
+    VG_TRY({
+        if (!out || !iters) throw std::invalid_argument("bad argument");
+        auto w = std::make_unique<vgpu_workload>();
+        w->vm.reset(new vwork::BasicVm(vwork::alu_program(iters)));
+        w->vm->run();
+        w->main = w->vm->main_traces();
+        w->prep_program = w->vm->program_preprocessed();
+        w->prep_range = vwork::BasicVm::range_preprocessed();
+        auto it = w->vm->cells.find(0x1000 - 4);
+        w->result = it == w->vm->cells.end() ? 0 : it->second;
+        *out = w.release();
+    })
+}
 void vgpu_workload_free(vgpu_workload_t* w) { delete w; }
 void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]) {
     out[0] = w->vm->clock; out[1] = w->vm->cpu_ops.size(); out[2] = w->vm->mem_ops.size(); out[3] = w->vm->add_ops.size();

@@ -432,4 +432,32 @@ inline std::vector<InstructionWord> fib_program(uint32_t n) {
     };
 }
 
+// Synthetic ALU-heavy loop (workload C4 of SURVEY.md §8): 9 instructions per iteration
+//   add, sub, xor, and, or, lt, addi, addi, bne
+// exercising the add / sub / bitwise / lt chips and the range bus.  The subtraction is 0xFFFFFFFF - t, which
+// never borrows: the reference's Sub32 witness (alu_u32/src/sub/mod.rs:104-112) ignores incoming borrows,
+// so only borrow-free subtractions satisfy its own AIR.
+inline std::vector<InstructionWord> alu_program(uint32_t iters) {
+    const int32_t B = BYTES_PER_INSTR, loop = 4 * B;
+    auto b = [](uint32_t v, int i) { return (int32_t)((v >> (24 - 8 * i)) & 255); };
+    const uint32_t x0 = 0x01234567u, y0 = 0x9E3779B9u;
+    return {
+        {OP_IMM32, {-4, b(x0, 0), b(x0, 1), b(x0, 2), b(x0, 3)}},    // x
+        {OP_IMM32, {-8, b(y0, 0), b(y0, 1), b(y0, 2), b(y0, 3)}},    // y
+        {OP_IMM32, {-12, 0, 0, 0, 0}},                               // i
+        {OP_IMM32, {-16, 255, 255, 255, 255}},                       // ones
+        // loop:
+        {OP_ADD32, {-20, -4, -8, 0, 0}},    // t1 = x + y
+        {OP_SUB32, {-24, -16, -20, 0, 0}},  // t2 = ~t1
+        {OP_XOR32, {-28, -20, -24, 0, 0}},  // t3 = t1 ^ t2
+        {OP_AND32, {-32, -28, -8, 0, 0}},   // t4 = t3 & y
+        {OP_OR32, {-36, -32, -4, 0, 0}},    // t5 = t4 | x
+        {OP_LT32, {-40, -36, -20, 0, 0}},   // t6 = t5 < t1
+        {OP_ADD32, {-4, -20, 12345, 0, 1}}, // x = t1 + 12345
+        {OP_ADD32, {-12, -12, 1, 0, 1}},    // i += 1
+        {OP_BNE, {loop, -12, (int32_t)iters, 0, 1}},
+        {OP_STOP, {0, 0, 0, 0, 0}},
+    };
+}
+
 }  // namespace vwork
