@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Fibonacci loop bound giving 17 + 7n = 2^20 - 1 executed cycles.
-FIB_N = {20: 149794, 19: 74895, 18: 37446, 17: 18722, 16: 9359, 14: 2338, 12: 582}
+FIB_N = {22: 599183, 20: 149794, 19: 74895, 18: 37446, 17: 18722, 16: 9359, 14: 2338, 12: 582}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--log-rows", type=int, default=20, help="log2 of the padded CPU-chip height (20 = the headline workload)")
     ap.add_argument("--cpu-log-rows", type=int, default=17, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+                    help="SURVEY.md §8 config: c2 = Fibonacci (headline), c3 = Fibonacci 2^22 rows with 4x blowup, c4 = ALU/range-heavy loop")
     args = ap.parse_args()
 
     import torch
@@ -108,12 +110,22 @@ def main():
 
     rc = va.poseidon_round_constants()
     machine = va.Machine.basic()
-    prover = va.Prover(machine, rc, device=local_rank)
+    if args.workload == "c3":
+        args.log_rows = 22
+    prover = va.Prover(machine, rc, log_blowup=2 if args.workload == "c3" else 1, device=local_rank)
 
     # one independent segment per rank: distinct loop bounds with the same padded shape
-    n = segment_loop_bound(args.log_rows, rank)
     t0 = time.time()
-    wl = va.Workload.fib(n)
+    if args.workload == "c4":
+        n = ((1 << args.log_rows) - 8) // 9 - rank  # 4 + 9n + 1 cycles
+        wl = va.Workload.alu(n)
+        wl_name = "C4: ALU/range-heavy loop (add, sub, xor, and, or, lt, addi, addi, bne), 2^%d cpu rows, mem 2^%d" % (args.log_rows, args.log_rows + 2)
+        data = "alu_program(iters=%d)" % n
+    else:
+        n = segment_loop_bound(args.log_rows, rank)
+        wl = va.Workload.fib(n)
+        wl_name = "%s: Fibonacci 2^%d cpu rows (mem 2^%d)" % (args.workload.upper(), args.log_rows, args.log_rows + 2)
+        data = "fib_program(n=%d)" % n
     t_tracegen = time.time() - t0
     assert wl.cpu_height == 1 << args.log_rows
     mt = wl.main_traces()
@@ -168,7 +180,7 @@ def main():
         b_alg = algorithmic_bytes_per_proof(shapes, prover.log_blowup)
         kernel_ms_total = sum(v[1] for v in prof.values()) / args.steps
         out = {
-            "metric": "proofs/sec, 2^%d-row Fibonacci trace (BabyBear, Keccak-256 MMCS, FRI blowup 2, 40 queries)" % args.log_rows,
+            "metric": "proofs/sec, 2^%d-row %s trace (BabyBear, Keccak-256 MMCS, FRI blowup %d, 40 queries)" % (args.log_rows, "ALU-loop" if args.workload == "c4" else "Fibonacci", 1 << prover.log_blowup),
             "value": value,
             "unit": "proofs/s",
             "n_gpus": world,
@@ -179,9 +191,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32 (BabyBear mod p, Montgomery) / u64 (Keccak lanes)",
-            "data": "synthetic: fib_program(n=%d) traces generated by the in-tree VM, deterministic; Poseidon constants SplitMix64(0x56414C494441)" % n,
+            "data": "synthetic: %s traces generated by the in-tree VM, deterministic; Poseidon constants SplitMix64(0x56414C494441)" % data,
             "config": {
-                "workload": "C2: Fibonacci 2^%d cpu rows (mem 2^%d), 14 chips, one proof per GPU" % (args.log_rows, args.log_rows + 2),
+                "workload": wl_name + ", 14 chips, one proof per GPU",
                 "log_blowup": prover.log_blowup, "num_queries": prover.num_queries, "pow_bits": prover.pow_bits,
                 "parallelism": "segments: one independent proof per GPU + all-gather of 3 roots" if world > 1 else "single GPU",
             },

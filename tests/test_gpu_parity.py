@@ -219,3 +219,38 @@ def test_lde_blowup4_matches_oracle(machine, rc):
         pd = p4.commit_batches([p4.upload(m)])
         assert first_mismatch(pd.lde(0), po.committed_lde(m, 2, 31)) is None
         assert first_mismatch(pd.root, po.commit_root([m], log_blowup=2)) is None
+
+
+# ---- BASELINE.json's full sizes: size-independent properties (the oracle's prover would take minutes here;
+# its restated Machine::verify is O(queries * log n) and needs only the preprocessed traces) ----------------
+def _full_size_round_trip(p, w, rc, log_blowup):
+    mt, prep = w.main_traces(), w.preprocessed()
+    dmain = [p.upload(m) for m in mt]
+    dprep = [(c, p.upload(m)) for c, m in prep]
+    a = p.prove(dmain, dprep)
+    assert po.verify_basic(prep[0][1], prep[1][1], a.words, rc, log_blowup=log_blowup) is None
+    assert p.prove(dmain, dprep).bytes() == a.bytes()  # deterministic: no atomics-order dependence at scale
+    for pos in (40, a.words.size // 3, a.words.size - 7):
+        bad = a.words.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        assert po.verify_basic(prep[0][1], prep[1][1], bad, rc, log_blowup=log_blowup) is not None
+
+
+def test_full_size_c2_fib_2_20(prover, rc):
+    w = va.Workload.fib(149794)
+    assert w.cpu_height == 1 << 20 and w.main_trace(2).shape[0] == 1 << 22
+    _full_size_round_trip(prover, w, rc, 1)
+
+
+def test_full_size_c4_alu_2_20(prover, rc):
+    w = va.Workload.alu(116507)
+    assert w.cycles == 1048568 and w.cpu_height == 1 << 20
+    heights = [m.shape[0] for m in w.main_traces()]
+    assert [heights[i] for i in (3, 4, 8, 10)] == [1 << 19, 1 << 17, 1 << 17, 1 << 19]
+    _full_size_round_trip(prover, w, rc, 1)
+
+
+def test_full_size_c3_fib_2_22_blowup4(machine, rc):
+    w = va.Workload.fib(599183)
+    assert w.cpu_height == 1 << 22 and w.main_trace(2).shape[0] == 1 << 24
+    _full_size_round_trip(va.Prover(machine, rc, log_blowup=2), w, rc, 2)
