@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--log-rows", type=int, default=20, help="log2 of the padded CPU-chip height (20 = the headline workload)")
     ap.add_argument("--cpu-log-rows", type=int, default=17, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="proofs in flight per GPU: M host threads, each with its own prover context and HIP streams, share the K steps "
+                         "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="SURVEY.md §8 config: c2 = Fibonacci (headline), c3 = Fibonacci 2^22 rows with 4x blowup, c4 = ALU/range-heavy loop")
     args = ap.parse_args()
@@ -112,7 +115,8 @@ def main():
     machine = va.Machine.basic()
     if args.workload == "c3":
         args.log_rows = 22
-    prover = va.Prover(machine, rc, log_blowup=2 if args.workload == "c3" else 1, device=local_rank)
+    provers = [va.Prover(machine, rc, log_blowup=2 if args.workload == "c3" else 1, device=local_rank) for _ in range(max(1, args.inflight))]
+    prover = provers[0]
 
     # one independent segment per rank: distinct loop bounds with the same padded shape
     t0 = time.time()
@@ -134,16 +138,42 @@ def main():
     dmain = [prover.upload(m) for m in mt]
     dprep = [(c, prover.upload(m)) for c, m in prep]
     t_upload = time.time() - t0
+    inputs = [(dmain, dprep)] + [([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep]) for p in provers[1:]]
     shapes = [(m.shape[0], m.shape[1], machine.chip_info(i)["interactions"]) for i, m in enumerate(mt)]
     upload_bytes = sum(m.nbytes for m in mt)
 
     all_roots = [None]
 
-    def step():
-        proof = prover.prove(dmain, dprep)
-        if world > 1:
+    def step(slot=0):
+        proof = provers[slot].prove(*inputs[slot])
+        if world > 1 and slot == 0:
             all_roots[0] = exchange_roots(dist, torch, proof.words[2:26], torch.device("cuda", local_rank))
         return proof
+
+    def run_steps(k):
+        """k proofs; with --inflight M > 1, M host threads pull steps from a shared counter (ctypes releases the GIL)."""
+        if len(provers) == 1:
+            return [step() for _ in range(k)]
+        import threading
+
+        done, lock, nxt = [], threading.Lock(), [0]
+
+        def worker(slot):
+            while True:
+                with lock:
+                    if nxt[0] >= k:
+                        return
+                    nxt[0] += 1
+                pr = step(slot)
+                with lock:
+                    done.append(pr)
+
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(provers))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return done
 
     def fence():
         torch.cuda.synchronize()
@@ -151,20 +181,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    prover.set_profiling(True)
+    for slot in range(len(provers)):
+        for _ in range(max(1, args.warmup // len(provers)) if args.warmup else 0):
+            step(slot)
+    for p_ in provers:
+        p_.set_profiling(True)
     fence()
     t0 = time.perf_counter()
     phase = {}
-    for _ in range(args.steps):
-        p = step()
+    for p in run_steps(args.steps):
         for k, v in p.phase_ms.items():
             phase[k] = phase.get(k, 0.0) + v
     fence()
     elapsed = time.perf_counter() - t0
-    prof = prover.profile()
-    prover.set_profiling(False)
+    prof = {}
+    for p_ in provers:
+        for k, v in p_.profile().items():
+            a = prof.get(k, (0, 0.0, 0.0))
+            prof[k] = (a[0] + v[0], a[1] + v[1], a[2] + v[2])
+        p_.set_profiling(False)
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -196,6 +231,7 @@ def main():
                 "workload": wl_name + ", 14 chips, one proof per GPU",
                 "log_blowup": prover.log_blowup, "num_queries": prover.num_queries, "pow_bits": prover.pow_bits,
                 "parallelism": "segments: one independent proof per GPU + all-gather of 3 roots" if world > 1 else "single GPU",
+                "proofs_in_flight_per_gpu": len(provers),
             },
             "roofline": {
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -209,7 +245,7 @@ def main():
             "kernel_ms_total_per_step": kernel_ms_total,
             "outside_timed_region": {"tracegen_s": t_tracegen, "h2d_upload_s": t_upload, "h2d_bytes": upload_bytes},
             "proof_words": int(p.words.size),
-            "hbm_pool_peak_bytes": prover.memory()[1],
+            "hbm_pool_peak_bytes": sum(p_.memory()[1] for p_ in provers),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_rows, rc)

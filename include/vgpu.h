@@ -49,6 +49,8 @@ typedef struct vgpu_config {
     uint32_t hash_kind;            /* VGPU_HASH_KECCAK256 */
     uint32_t observe_final_poly;   /* convention switch, default 0 */
     uint32_t poseidon_rc[480];     /* Poseidon<_,CosetMds<16>,16,5> round constants (test_prover.rs:418-422), canonical */
+    uint32_t interpret_air;        /* 0: BasicMachine chips run their ahead-of-time compiled eval kernels; 1: every AIR, in-tree
+                                      or captured through vgpu_air_*, runs as an interpreted register program (same values) */
 } vgpu_config_t;
 
 /* ---- AIR capture: the FFI image of SymbolicAirBuilder (machine/src/symbolic/symbolic_builder.rs:57-154).

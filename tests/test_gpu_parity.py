@@ -254,3 +254,15 @@ def test_full_size_c3_fib_2_22_blowup4(machine, rc):
     w = va.Workload.fib(599183)
     assert w.cpu_height == 1 << 22 and w.main_trace(2).shape[0] == 1 << 24
     _full_size_round_trip(va.Prover(machine, rc, log_blowup=2), w, rc, 2)
+
+
+# ---- the two realisations of Chip::eval on the device: ahead-of-time compiled chip kernels (default for the
+# in-tree BasicMachine) and the interpreted register program (AIRs captured at run time) -----------------------
+@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(100)])
+def test_interpreted_air_path_matches_oracle(machine, rc, make):
+    pi = va.Prover(machine, rc, interpret_air=True)
+    w = make()
+    proof, ref, prep = _prove_both(pi, w, rc)
+    for chip in range(va.NUM_CHIPS):
+        assert first_mismatch(proof.debug_quotient(chip), ref.quotient(chip)) is None, "quotient chunks of chip %d (%s)" % (chip, va.CHIP_NAMES[chip])
+    assert first_mismatch(proof.words, ref.words) is None

@@ -36,6 +36,7 @@ class VgpuConfig(ctypes.Structure):
         ("hash_kind", ctypes.c_uint32),
         ("observe_final_poly", ctypes.c_uint32),
         ("poseidon_rc", ctypes.c_uint32 * 480),
+        ("interpret_air", ctypes.c_uint32),
     ]
 
 
@@ -287,10 +288,10 @@ class Proof:
 class Prover:
     """One MI355X: StarkConfig + Machine -> prove().  Mirrors machine.prove(&config)."""
 
-    def __init__(self, machine, rc, device=0, log_blowup=1, num_queries=40, pow_bits=8, observe_final_poly=False):
+    def __init__(self, machine, rc, device=0, log_blowup=1, num_queries=40, pow_bits=8, observe_final_poly=False, interpret_air=False):
         cfg = VgpuConfig()
         cfg.device, cfg.log_blowup, cfg.num_queries, cfg.pow_bits = device, log_blowup, num_queries, pow_bits
-        cfg.hash_kind, cfg.observe_final_poly = 0, int(observe_final_poly)
+        cfg.hash_kind, cfg.observe_final_poly, cfg.interpret_air = 0, int(observe_final_poly), int(interpret_air)
         rc = np.ascontiguousarray(rc, dtype=np.uint32)
         assert rc.size == 480
         ctypes.memmove(cfg.poseidon_rc, rc.ctypes.data, 480 * 4)

@@ -20,27 +20,35 @@
 #include <cstdint>
 #include <vector>
 
+// Chip `eval` templates and the sugar below are compiled for the host (symbolic capture, the CPU checker's
+// folders) AND, unchanged, for gfx950 (kernels/quotient.hip instantiates them over a device folder).
+#if defined(__HIPCC__)
+#define VAIR_HD __host__ __device__
+#else
+#define VAIR_HD
+#endif
+
 namespace vair {
 
 template <class AB>
 struct When {
     AB& b;
     typename AB::Expr cond;
-    When<AB> when(const typename AB::Expr& c) const { return When<AB>{b, cond * c}; }
-    When<AB> when_ne(const typename AB::Expr& x, const typename AB::Expr& y) const { return when(x - y); }
-    void assert_zero(const typename AB::Expr& x) const { b.assert_zero(cond * x); }
-    void assert_eq(const typename AB::Expr& x, const typename AB::Expr& y) const { assert_zero(x - y); }
-    void assert_one(const typename AB::Expr& x) const { assert_zero(x - b.constant(1)); }
+    VAIR_HD When<AB> when(const typename AB::Expr& c) const { return When<AB>{b, cond * c}; }
+    VAIR_HD When<AB> when_ne(const typename AB::Expr& x, const typename AB::Expr& y) const { return when(x - y); }
+    VAIR_HD void assert_zero(const typename AB::Expr& x) const { b.assert_zero(cond * x); }
+    VAIR_HD void assert_eq(const typename AB::Expr& x, const typename AB::Expr& y) const { assert_zero(x - y); }
+    VAIR_HD void assert_one(const typename AB::Expr& x) const { assert_zero(x - b.constant(1)); }
 };
 
-template <class AB> When<AB> when(AB& b, const typename AB::Expr& c) { return When<AB>{b, c}; }
-template <class AB> When<AB> when_ne(AB& b, const typename AB::Expr& x, const typename AB::Expr& y) { return When<AB>{b, x - y}; }
-template <class AB> When<AB> when_first_row(AB& b) { return When<AB>{b, b.is_first_row()}; }
-template <class AB> When<AB> when_last_row(AB& b) { return When<AB>{b, b.is_last_row()}; }
-template <class AB> When<AB> when_transition(AB& b) { return When<AB>{b, b.is_transition()}; }
-template <class AB> void assert_eq(AB& b, const typename AB::Expr& x, const typename AB::Expr& y) { b.assert_zero(x - y); }
-template <class AB> void assert_one(AB& b, const typename AB::Expr& x) { b.assert_zero(x - b.constant(1)); }
-template <class AB> void assert_bool(AB& b, const typename AB::Expr& x) { b.assert_zero(x * (x - b.constant(1))); }
+template <class AB> VAIR_HD When<AB> when(AB& b, const typename AB::Expr& c) { return When<AB>{b, c}; }
+template <class AB> VAIR_HD When<AB> when_ne(AB& b, const typename AB::Expr& x, const typename AB::Expr& y) { return When<AB>{b, x - y}; }
+template <class AB> VAIR_HD When<AB> when_first_row(AB& b) { return When<AB>{b, b.is_first_row()}; }
+template <class AB> VAIR_HD When<AB> when_last_row(AB& b) { return When<AB>{b, b.is_last_row()}; }
+template <class AB> VAIR_HD When<AB> when_transition(AB& b) { return When<AB>{b, b.is_transition()}; }
+template <class AB> VAIR_HD void assert_eq(AB& b, const typename AB::Expr& x, const typename AB::Expr& y) { b.assert_zero(x - y); }
+template <class AB> VAIR_HD void assert_one(AB& b, const typename AB::Expr& x) { b.assert_zero(x - b.constant(1)); }
+template <class AB> VAIR_HD void assert_bool(AB& b, const typename AB::Expr& x) { b.assert_zero(x * (x - b.constant(1))); }
 
 // VirtualPairCol (p3_air) restricted to what Valida uses: an affine form over one row of
 // (preprocessed, main) columns with canonical u32 weights.

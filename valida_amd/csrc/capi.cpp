@@ -151,6 +151,7 @@ int32_t vgpu_prover_create(const vgpu_config_t* cfg, const vgpu_machine_t* machi
         if (hipGetDeviceCount(&count) != hipSuccess || count <= cfg->device) throw std::runtime_error("hip: no usable device (the product path has no CPU fallback)");
         FriParams fp;
         fp.log_blowup = cfg->log_blowup; fp.num_queries = cfg->num_queries; fp.pow_bits = cfg->pow_bits; fp.observe_final_poly = cfg->observe_final_poly != 0;
+        fp.interpret_air = cfg->interpret_air != 0;
         auto* p = new vgpu_prover();
         p->p.reset(new Prover(cfg->device, machine->desc, cfg->poseidon_rc, fp));
         *out = p;
@@ -182,6 +183,7 @@ int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t heigh
     VG_TRY({
         if (!p || !data || !out || !height || !width) throw std::invalid_argument("bad trace");
         auto* t = new vgpu_trace();
+        p->p->ctx().activate();
         t->t = p->p->upload_trace(HostMatrix{data, height, width});
         *out = t;
     })
@@ -200,6 +202,7 @@ int32_t vgpu_commit_batches(vgpu_prover_t* p, const vgpu_trace_t* const* mats, u
     VG_TRY({
         if (!p || !mats || !n_mats || !root || !out) throw std::invalid_argument("null argument");
         DeviceCtx& c = p->p->ctx();
+        c.activate();
         std::vector<DMat> nat;
         for (uint32_t i = 0; i < n_mats; i++) nat.push_back(ingest(c, *mats[i]->t));
         std::vector<CommitInput> in;
@@ -216,6 +219,7 @@ int32_t vgpu_pdata_lde(vgpu_prover_t* p, const vgpu_pdata_t* pd, uint32_t idx, u
     VG_TRY({
         if (!p || !pd || idx >= pd->pd->ldes.size() || !out) throw std::invalid_argument("bad argument");
         DeviceCtx& c = p->p->ctx();
+        c.activate();
         const DMat& l = pd->pd->ldes[idx];
         if (cap_words < l.height * l.width) throw std::invalid_argument("output buffer too small");
         DBuf tmp(&c, (size_t)(l.height * l.width));
@@ -234,6 +238,7 @@ int32_t vgpu_perm_trace(vgpu_prover_t* p, uint32_t chip, const vgpu_trace_t* mai
         const AirDesc& air = md.airs[chip];
         if (main->t->width != air.width) throw std::invalid_argument("trace width mismatch");
         DeviceCtx& c = p->p->ctx();
+        c.activate();
         DMat m = ingest(c, *main->t);
         DMat pm;
         if (prep) pm = ingest(c, *prep->t);
@@ -262,6 +267,7 @@ int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uin
     VG_TRY({
         if (!p || !f || !beta || !out || n < 4 || (n & (n - 1))) throw std::invalid_argument("fri_fold: n must be a power of two >= 4");
         DeviceCtx& c = p->p->ctx();
+        c.activate();
         uint64_t half = n / 2, q = half / 2;
         std::vector<uint32_t> in(5 * n);
         vk::Ext5Arg bw;

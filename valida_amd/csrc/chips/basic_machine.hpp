@@ -40,7 +40,7 @@ enum {
     CH_USED = 0, CH_IS_READ = 1, CH_ADDR = 2, CH_VALUE = 3, CH_STRIDE = 7,
     CLK_OR_ZERO = 50, NUM_COLS = 51
 };
-inline int ch(int i, int f) { return MEM0 + i * CH_STRIDE + f; }
+constexpr int ch(int i, int f) { return MEM0 + i * CH_STRIDE + f; }
 }  // namespace cpu
 namespace program { enum { MULTIPLICITY = 0, NUM_COLS = 1, PRE_PC = 0, PRE_OPCODE = 1, PRE_OPERANDS = 2, NUM_PRE_COLS = 7 }; }
 namespace mem {  // memory/src/columns.rs:8-39
@@ -78,7 +78,7 @@ inline const ChipInfo& chip_info(int id) {
 // ---- AIRs ------------------------------------------------------------------------------------
 
 // cpu/src/stark.rs:17-306
-template <class AB> void eval_cpu(AB& b) {
+template <class AB> VAIR_HD void eval_cpu(AB& b) {
     using E = typename AB::Expr;
     auto L = [&](int c) { return b.main(c, false); };
     auto N = [&](int c) { return b.main(c, true); };
@@ -197,7 +197,7 @@ template <class AB> void eval_cpu(AB& b) {
 }
 
 // alu_u32/src/add/stark.rs:21-54
-template <class AB> void eval_add(AB& b) {
+template <class AB> VAIR_HD void eval_add(AB& b) {
     using E = typename AB::Expr;
     auto L = [&](int c) { return b.main(c, false); };
     E one = b.constant(1), base = b.constant(1u << 8);
@@ -219,7 +219,7 @@ template <class AB> void eval_add(AB& b) {
 }
 
 // alu_u32/src/sub/stark.rs:21-51
-template <class AB> void eval_sub(AB& b) {
+template <class AB> VAIR_HD void eval_sub(AB& b) {
     using E = typename AB::Expr;
     auto L = [&](int c) { return b.main(c, false); };
     E base = b.constant(1u << 8);
@@ -234,7 +234,7 @@ template <class AB> void eval_sub(AB& b) {
 }
 
 // alu_u32/src/mul/stark.rs:23-82
-template <class AB> void eval_mul(AB& b) {
+template <class AB> VAIR_HD void eval_mul(AB& b) {
     using E = typename AB::Expr;
     auto L = [&](int c) { return b.main(c, false); };
     auto N = [&](int c) { return b.main(c, true); };
@@ -266,7 +266,7 @@ template <class AB> void eval_mul(AB& b) {
 }
 
 // alu_u32/src/shift/stark.rs:21-69
-template <class AB> void eval_shift(AB& b) {
+template <class AB> VAIR_HD void eval_shift(AB& b) {
     using E = typename AB::Expr;
     auto L = [&](int c) { return b.main(c, false); };
     E one = b.constant(1);
@@ -287,7 +287,7 @@ template <class AB> void eval_shift(AB& b) {
 }
 
 // alu_u32/src/lt/stark.rs:21-168
-template <class AB> void eval_lt(AB& b) {
+template <class AB> VAIR_HD void eval_lt(AB& b) {
     using E = typename AB::Expr;
     auto L = [&](int c) { return b.main(c, false); };
     E one = b.constant(1);
@@ -337,7 +337,7 @@ template <class AB> void eval_lt(AB& b) {
 }
 
 // alu_u32/src/com/stark.rs:21-49
-template <class AB> void eval_com(AB& b) {
+template <class AB> VAIR_HD void eval_com(AB& b) {
     using E = typename AB::Expr;
     auto L = [&](int c) { return b.main(c, false); };
     E one = b.constant(1);
@@ -355,7 +355,7 @@ template <class AB> void eval_com(AB& b) {
 }
 
 // alu_u32/src/bitwise/stark.rs:22-74
-template <class AB> void eval_bitwise(AB& b) {
+template <class AB> VAIR_HD void eval_bitwise(AB& b) {
     using E = typename AB::Expr;
     auto L = [&](int c) { return b.main(c, false); };
     for (int i = 0; i < 4; i++) {
@@ -383,7 +383,7 @@ template <class AB> void eval_bitwise(AB& b) {
 }
 
 // output/src/stark.rs:21-39
-template <class AB> void eval_output(AB& b) {
+template <class AB> VAIR_HD void eval_output(AB& b) {
     auto L = [&](int c) { return b.main(c, false); };
     auto N = [&](int c) { return b.main(c, true); };
     when_transition(b).assert_eq(L(output::DIFF), N(output::CLK) - L(output::CLK));
@@ -392,7 +392,7 @@ template <class AB> void eval_output(AB& b) {
 }
 
 // static_data/src/stark.rs:25-37
-template <class AB> void eval_static_data(AB& b) {
+template <class AB> VAIR_HD void eval_static_data(AB& b) {
     auto L = [&](int c) { return b.main(c, false); };
     auto N = [&](int c) { return b.main(c, true); };
     when_transition(b).when(L(static_data::IS_REAL) * N(static_data::IS_REAL))
@@ -401,7 +401,7 @@ template <class AB> void eval_static_data(AB& b) {
 
 // Empty AIRs: program (program/src/stark.rs:14), mem (memory/src/stark.rs:22-78, all commented out),
 // div (alu_u32/src/div/stark.rs:18-20), range (range/src/stark.rs:12-14).
-template <class AB> void eval_chip(int chip, AB& b) {
+template <class AB> VAIR_HD void eval_chip(int chip, AB& b) {
     switch (chip) {
         case CHIP_CPU: eval_cpu(b); break;
         case CHIP_ADD: eval_add(b); break;

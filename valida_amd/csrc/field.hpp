@@ -104,8 +104,8 @@ struct Ext5 {
     VG_HD Ext5 operator+(const Fp& s) const { Ext5 r = *this; r.c[0] += s; return r; }
     VG_HD Ext5 operator-(const Fp& s) const { Ext5 r = *this; r.c[0] -= s; return r; }
     // Schoolbook, X^5 = 2 folded by pre-doubling one operand: limb k = sum_i a_i * B_{k,i} with
-    // B_{k,i} = b_{k-i} (i <= k) or 2*b_{k+5-i} (i > k).  Two products (< 2 p^2 < p * 2^32) share one
-    // Montgomery reduction: 3 reductions per limb instead of 5.
+    // B_{k,i} = b_{k-i} (i <= k) or 2*b_{k+5-i} (i > k).  Four products (< 4 p^2 < 2^64) share one
+    // Montgomery reduction (monty_reduce_wide): 2 reductions per limb instead of 5.
     VG_HD Ext5 operator*(const Ext5& o) const {
         Fp d[5];
 #pragma unroll
@@ -116,10 +116,9 @@ struct Ext5 {
             uint32_t bb[5];
 #pragma unroll
             for (int i = 0; i < 5; i++) bb[i] = i <= k ? o.c[k - i].v : d[k + 5 - i].v;
-            uint64_t t01 = (uint64_t)c[0].v * bb[0] + (uint64_t)c[1].v * bb[1];
-            uint64_t t23 = (uint64_t)c[2].v * bb[2] + (uint64_t)c[3].v * bb[3];
+            uint64_t t0123 = (uint64_t)c[0].v * bb[0] + (uint64_t)c[1].v * bb[1] + (uint64_t)c[2].v * bb[2] + (uint64_t)c[3].v * bb[3];
             uint64_t t4 = (uint64_t)c[4].v * bb[4];
-            r.c[k] = Fp::raw(monty_reduce(t01)) + Fp::raw(monty_reduce(t23)) + Fp::raw(monty_reduce(t4));
+            r.c[k] = Fp::raw(monty_reduce_wide(t0123)) + Fp::raw(monty_reduce(t4));
         }
         return r;
     }

@@ -18,6 +18,9 @@ struct AirDesc {
     std::vector<uint32_t> interaction_words;  // vk::encode_interactions
     unsigned log_quotient_degree = 1;
     int max_constraint_degree = 0;
+    // vchips::ChipId when this AIR is one of the in-tree BasicMachine chips, whose eval template is also compiled
+    // into a native quotient kernel (kernels/quotient.hip); -2 = interpret `program` (run-time captured AIRs)
+    int native_chip = -2;
 };
 
 struct MachineDesc {
@@ -62,6 +65,7 @@ struct MachineDesc {
             m.airs.push_back(make_air(
                 info.name, (uint32_t)info.width, (uint32_t)info.preprocessed_width, [i](vair::SymbolicBuilder& b) { vchips::eval_chip(i, b); },
                 [i](vair::DegreeBuilder& b) { vchips::eval_chip(i, b); }, vchips::chip_interactions(i)));
+            m.airs.back().native_chip = i;
         }
         return m;
     }

@@ -15,6 +15,7 @@ namespace vhost {
 struct FriParams {
     unsigned log_blowup = 1, num_queries = 40, pow_bits = 8;
     bool observe_final_poly = false;
+    bool interpret_air = false;  // quotient: force the register-program interpreter even for the in-tree chips
 };
 
 // One Merkle tree over column-major device matrices of mixed heights (FieldMerkleTreeMmcs, App. B5).

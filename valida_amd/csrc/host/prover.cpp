@@ -98,8 +98,7 @@ struct GatherList {
 std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main, const std::vector<std::pair<int, const DeviceTrace*>>& preprocessed,
                                     PhaseTimes* times, ProveDebugOut* dbg) {
     DeviceCtx& c = *ctx_;
-    VG_HIP_CHECK(hipSetDevice(c.device));
-    vk::g_profiler = &c.profiler;
+    c.activate();
     const size_t NC = machine_.airs.size();
     if (main.size() != NC) throw std::invalid_argument("prove: need one main trace per chip");
     const Fp s = Fp::from_canonical(vg::GENERATOR);  // pcs.coset_shift()
@@ -260,6 +259,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             a.n_instrs = (uint32_t)air.program.instrs.size();
             a.n_regs = air.program.num_regs;
             a.n_air_asserts = air.program.num_asserts;
+            a.native_chip = fri_.interpret_air ? vk::QuotientArgs::INTERPRET : air.native_chip;
             a.iw = iw_dev_[i].data;
             a.consts = pool_dev.data + off[i];
             a.K = Ks[i];

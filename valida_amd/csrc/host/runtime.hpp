@@ -43,7 +43,14 @@ struct DeviceCtx {
         VG_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
         init_tables();
     }
+    // Every C-ABI entry that launches work calls this first: binds the calling thread to this context's
+    // device and points the launchers' profiler hook at this context (never at a destroyed one).
+    void activate() {
+        VG_HIP_CHECK(hipSetDevice(device));
+        vk::g_profiler = &profiler;
+    }
     ~DeviceCtx() {
+        if (vk::g_profiler == &profiler) vk::g_profiler = nullptr;
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
         for (int i = 0; i < NUM_AUX; i++) { (void)hipStreamSynchronize(aux[i]); (void)hipStreamDestroy(aux[i]); (void)hipEventDestroy(join_ev[i]); }

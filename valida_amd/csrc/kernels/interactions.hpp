@@ -52,7 +52,8 @@ __device__ __forceinline__ vg::Fp eval_vcol(const uint32_t* __restrict__ w, uint
         uint32_t cw = w[pos];
         uint32_t col = cw & 0x7fffffffu;
         vg::Fp v = (cw >> 31) ? vg::Fp::raw(prep[(uint64_t)col * pstride + row]) : vg::Fp::raw(main[(uint64_t)col * mstride + row]);
-        acc += v * vg::Fp::raw(w[pos + 1]);
+        const uint32_t wt = w[pos + 1];  // wave-uniform: almost every field is a bare column (weight 1)
+        acc += wt == vg::R_MOD_P ? v : v * vg::Fp::raw(wt);
     }
     return acc;
 }

@@ -19,6 +19,10 @@ struct QuotientArgs {
     uint32_t zh[2];              // s^n - 1, -s^n - 1
     uint32_t g_inv;              // g_n^{-1}  (subgroup_last)
     DMatView out;                // n x 10, row for natural i stored at position bitrev_k(i)
+    // BasicMachine chip whose eval template is compiled into a native kernel (vchips::ChipId), or INTERPRET for
+    // the register-program interpreter (AIRs captured at run time through vgpu_air_*)
+    static constexpr int INTERPRET = -2;
+    int native_chip;
 };
 
 

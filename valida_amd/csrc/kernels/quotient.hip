@@ -18,6 +18,7 @@
 // the inverse NTT of the following commit consumes).
 #include "launch.hpp"
 #include "interactions.hpp"
+#include "../chips/basic_machine.hpp"
 
 namespace vk {
 
@@ -87,6 +88,62 @@ __device__ __forceinline__ Ext5 run_program_lds(const QuotientArgs& a, const Poi
     return acc;
 }
 
+// ---- the chips' own `eval` templates, compiled for gfx950 ---------------------------------------------------
+// ProverConstraintFolder (machine/src/folding_builder.rs:32-125) as a device-side AirBuilder: the BasicMachine
+// chips' unchanged `eval` templates (chips/basic_machine.hpp) are instantiated over it, so every constraint
+// becomes straight-line VALU code with column loads the compiler schedules and CSEs — no interpretation.
+// assert_zero(c_k) accumulates alpha^(K-1-k) * c_k LAZILY: five v_mad_u64_u32 per constraint into 64-bit limb
+// accumulators, one Montgomery reduction per limb for every four constraints (4 p^2 < 2^64).
+struct DeviceFolder {
+    using Expr = Fp;
+    const uint32_t* __restrict__ main_p;  // main LDE column 0 at this point's local row / next row
+    const uint32_t* __restrict__ main_n;
+    uint64_t mstride;
+    const uint32_t* __restrict__ prep_p;
+    const uint32_t* __restrict__ prep_n;
+    uint64_t pstride;
+    Fp first, last, trans;
+    const uint32_t* __restrict__ apow;  // alpha powers, 5 words per constraint (wave-uniform: scalar loads)
+    uint64_t t[5];
+    Ext5 total;
+    int k, pending;
+    __device__ __forceinline__ Fp constant(uint32_t c) const { return Fp::from_canonical(c); }
+    __device__ __forceinline__ Fp main(int col, bool next) const { return Fp::raw((next ? main_n : main_p)[(uint64_t)col * mstride]); }
+    __device__ __forceinline__ Fp preprocessed(int col, bool next) const { return Fp::raw((next ? prep_n : prep_p)[(uint64_t)col * pstride]); }
+    __device__ __forceinline__ Fp is_first_row() const { return first; }
+    __device__ __forceinline__ Fp is_last_row() const { return last; }
+    __device__ __forceinline__ Fp is_transition() const { return trans; }
+    __device__ __forceinline__ void flush() {
+#pragma unroll
+        for (int c = 0; c < 5; c++) { total.c[c] += Fp::raw(vg::monty_reduce_wide(t[c])); t[c] = 0; }
+        pending = 0;
+    }
+    __device__ __forceinline__ void assert_zero(const Fp& e) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) t[c] += (uint64_t)apow[5 * k + c] * e.v;
+        k++;
+        if (++pending == 4) flush();
+    }
+};
+
+// CHIP < 0: a chip without AIR constraints (program, mem, div, range) — only the permutation constraints.
+template <int CHIP>
+__device__ __forceinline__ Ext5 run_native(const QuotientArgs& a, const PointCtx& p) {
+    if (CHIP < 0) return Ext5::zero();
+    DeviceFolder f;
+    f.main_p = a.main_lde.data + p.row; f.main_n = a.main_lde.data + p.next_row; f.mstride = a.main_lde.stride;
+    f.prep_p = a.prep_lde.data + p.row; f.prep_n = a.prep_lde.data + p.next_row; f.pstride = a.prep_lde.stride;
+    f.first = p.is_first; f.last = p.is_last; f.trans = p.is_trans;
+    f.apow = a.consts;
+    f.total = Ext5::zero();
+    f.k = 0; f.pending = 0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) f.t[c] = 0;
+    vchips::eval_chip(CHIP, f);  // CHIP is a compile-time constant: the switch folds to the one chip
+    if (f.pending) f.flush();
+    return f.total;
+}
+
 // eval_permutation_constraints at one point: M reciprocal constraints + transition/first/last.
 __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const PointCtx& p) {
     const uint32_t* iw = a.iw;
@@ -104,10 +161,18 @@ __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const Po
         uint32_t pos_n = pos;
         Fp mult_local = eval_vcol(iw, pos, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, p.row);
         Fp mult_next = eval_vcol(iw, pos_n, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, p.next_row);
+        // rlc = alpha_bus + sum_j beta^j f_j: Ext5 x base products accumulated four at a time per limb
         Ext5 rlc = ext_from_words(bus + 5 * m);
-        for (uint32_t j = 0; j < nf; j++) {
-            Fp f = eval_vcol(iw, pos, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, p.row);
-            rlc += ext_from_words(betas + 5 * j) * f;
+        for (uint32_t j0 = 0; j0 < nf; j0 += 4) {
+            uint64_t t[5] = {0, 0, 0, 0, 0};
+            const uint32_t je = nf - j0 < 4 ? nf - j0 : 4;
+            for (uint32_t j = 0; j < je; j++) {
+                Fp f = eval_vcol(iw, pos, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, p.row);
+#pragma unroll
+                for (int c = 0; c < 5; c++) t[c] += (uint64_t)betas[5 * (j0 + j) + c] * f.v;
+            }
+#pragma unroll
+            for (int c = 0; c < 5; c++) rlc.c[c] += Fp::raw(vg::monty_reduce_wide(t[c]));
         }
         const uint32_t* pcol = a.perm_lde.data + (uint64_t)(5 * m) * a.perm_lde.stride;
         Ext5 pl = load_ext(pcol, a.perm_lde.stride, p.row), pn = load_ext(pcol, a.perm_lde.stride, p.next_row);
@@ -123,7 +188,9 @@ __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const Po
     return acc;
 }
 
-template <int RFKIND>  // 0: LDS file, 1: one VGPR bank (<= 32 registers), 2: two banks (<= 64)
+// RFKIND 0: interpreter with an LDS register file, 1: one VGPR bank (<= 32 registers), 2: two banks (<= 64),
+// 3: the chip's eval template compiled natively (CHIP = vchips::ChipId, or -1 for a chip without AIR constraints)
+template <int RFKIND, int CHIP = -1>
 __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables tb) {
     extern __shared__ uint32_t regs[];
     const uint64_t n = 1ull << a.log_n;
@@ -149,7 +216,10 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
     p0.is_trans = d01; p0.is_first = Fp::raw(a.zh[par0]) * id00; p0.is_last = Fp::raw(a.zh[par0]) * id01;
     p1.is_trans = d11; p1.is_first = Fp::raw(a.zh[par1]) * id10; p1.is_last = Fp::raw(a.zh[par1]) * id11;
     Ext5 q0, q1;
-    if (RFKIND == 0) {
+    if (RFKIND == 3) {
+        q0 = run_native<CHIP>(a, p0);
+        q1 = run_native<CHIP>(a, p1);
+    } else if (RFKIND == 0) {
         q0 = run_program_lds(a, p0, regs);
         q1 = run_program_lds(a, p1, regs);
     } else {
@@ -173,6 +243,18 @@ void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& 
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     uint64_t n = 1ull << a.log_n;
     ProfScope ps("k_quotient", st, 4.0 * n * (2.0 * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 10.0));
+    if (a.native_chip != QuotientArgs::INTERPRET) {
+        // the BasicMachine chips: eval compiled ahead of time, one kernel per chip with constraints
+        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+        switch (a.native_chip) {
+#define VG_NATIVE(C) case vchips::C: hipLaunchKernelGGL((k_quotient<3, vchips::C>), grid, block, 0, st, a, tb); break;
+            VG_NATIVE(CHIP_CPU) VG_NATIVE(CHIP_ADD) VG_NATIVE(CHIP_SUB) VG_NATIVE(CHIP_MUL) VG_NATIVE(CHIP_SHIFT) VG_NATIVE(CHIP_LT)
+            VG_NATIVE(CHIP_COM) VG_NATIVE(CHIP_BITWISE) VG_NATIVE(CHIP_OUTPUT) VG_NATIVE(CHIP_STATIC_DATA)
+#undef VG_NATIVE
+            default: hipLaunchKernelGGL((k_quotient<3, -1>), grid, block, 0, st, a, tb); break;
+        }
+        return;
+    }
     if (a.n_regs <= 64) {
         const unsigned threads = 256;
         dim3 grid((unsigned)((n + threads - 1) / threads));
