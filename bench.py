@@ -40,6 +40,25 @@ def algorithmic_bytes_per_proof(shapes, log_blowup=1):
     return float(total)
 
 
+VALU_PEAK_WAVE_INSTR_S = 5.4e11  # measured integer-VALU issue peak (tools/microbench.hip; DESIGN.md "Measured hardware facts")
+
+
+def pmc_traffic_per_launch(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (profiles/rNN_pmc.json, written
+    by tools/summarize_prof.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"] if k else None
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def segment_loop_bound(log_rows, rank):
     """Independent segments: rank r proves fib with a distinct loop bound and the same padded shape."""
     n = FIB_N[log_rows] - rank
@@ -47,14 +66,15 @@ def segment_loop_bound(log_rows, rank):
     return n
 
 
-def exchange_roots(dist, torch, commitments24, device):
-    """The one collective of the path: all-gather of each segment's three 8-word Merkle roots (96 B per
-    rank; RCCL over xGMI with the nccl backend, gloo in the CPU tests).  Returns a [world, 24] int64 array."""
+def exchange_roots(dist, torch, commitments, device):
+    """The one collective of the path: all-gather of each segment's three 8-word Merkle roots (96 B per proof
+    per rank; RCCL over xGMI with the nccl backend, gloo in the CPU tests).  `commitments` holds 24 words per
+    proof this rank produced; returns a [world, len(commitments)] int64 array."""
     world = dist.get_world_size()
-    local = torch.from_numpy(np.asarray(commitments24, dtype=np.int64)).to(device)
-    out = torch.zeros(24 * world, dtype=torch.int64, device=device)
+    local = torch.from_numpy(np.ascontiguousarray(commitments, dtype=np.int64).reshape(-1)).to(device)
+    out = torch.zeros(local.numel() * world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, local)
-    return out.reshape(world, 24)
+    return out.reshape(world, local.numel())
 
 
 def cpu_baseline(log_rows, rc):
@@ -79,12 +99,12 @@ def cpu_baseline(log_rows, rc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 of the padded CPU-chip height (20 = the headline workload)")
     ap.add_argument("--cpu-log-rows", type=int, default=17, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=2,
                     help="proofs in flight per GPU: M host threads, each with its own prover context and HIP streams, share the K steps "
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
@@ -144,35 +164,32 @@ def main():
 
     all_roots = [None]
 
-    def step(slot=0):
-        proof = provers[slot].prove(*inputs[slot])
-        if world > 1 and slot == 0:
-            all_roots[0] = exchange_roots(dist, torch, proof.words[2:26], torch.device("cuda", local_rank))
-        return proof
-
-    def run_steps(k):
-        """k proofs; with --inflight M > 1, M host threads pull steps from a shared counter (ctypes releases the GIL)."""
-        if len(provers) == 1:
-            return [step() for _ in range(k)]
-        import threading
-
-        done, lock, nxt = [], threading.Lock(), [0]
+    def run_steps(k, from_host=False):
+        """k proofs on this GPU, then the path's one collective.  With --inflight M > 1, M host threads (ctypes
+        releases the GIL) take steps i, i + M, ... on their own prover context, so one proof's latency-bound
+        Merkle-top / FRI tail overlaps another's throughput-bound commits."""
+        done = [None] * k
 
         def worker(slot):
-            while True:
-                with lock:
-                    if nxt[0] >= k:
-                        return
-                    nxt[0] += 1
-                pr = step(slot)
-                with lock:
-                    done.append(pr)
+            pr = provers[slot]
+            for i in range(slot, k, len(provers)):
+                if from_host:  # the boundary handing over host buffers: H2D of the 14 main traces inside the step
+                    done[i] = pr.prove([pr.upload(m) for m in mt], inputs[slot][1])
+                else:
+                    done[i] = pr.prove(*inputs[slot])
 
-        ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(provers))]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        if len(provers) == 1:
+            worker(0)
+        else:
+            import threading
+
+            ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(provers))]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        if world > 1 and k:
+            all_roots[0] = exchange_roots(dist, torch, np.concatenate([p.words[2:26] for p in done]), torch.device("cuda", local_rank))
         return done
 
     def fence():
@@ -181,9 +198,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for slot in range(len(provers)):
-        for _ in range(max(1, args.warmup // len(provers)) if args.warmup else 0):
-            step(slot)
+    run_steps(args.warmup)
+    # prover latency with nothing else in flight (the "prover ms" half of the metric)
+    single, prof1 = None, None
+    if len(provers) > 1:
+        provers[0].set_profiling(True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            provers[0].prove(*inputs[0])
+        torch.cuda.synchronize()
+        single = (time.perf_counter() - t0) / 4 * 1e3
+        prof1 = provers[0].profile()
+        provers[0].set_profiling(False)
+    # PCIe-inclusive rate (never `value`): every step starts from the host-resident main traces
+    fence()
+    t0 = time.perf_counter()
+    run_steps(2 * len(provers), from_host=True)
+    torch.cuda.synchronize()
+    pcie_ms = (time.perf_counter() - t0) / (2 * len(provers)) * 1e3
     for p_ in provers:
         p_.set_profiling(True)
     fence()
@@ -197,8 +230,8 @@ def main():
     prof = {}
     for p_ in provers:
         for k, v in p_.profile().items():
-            a = prof.get(k, (0, 0.0, 0.0))
-            prof[k] = (a[0] + v[0], a[1] + v[1], a[2] + v[2])
+            a = prof.get(k, (0, 0.0, 0.0, 0.0))
+            prof[k] = (a[0] + v[0], a[1] + v[1], a[2] + v[2], a[3] + v[3])
         p_.set_profiling(False)
 
     if world > 1:
@@ -210,8 +243,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         # dominant kernel by accumulated HIP-event time
-        name, (launches, ms, nbytes) = max(prof.items(), key=lambda kv: kv[1][1])
+        name, (launches, ms, nbytes, valu_ops) = max(prof.items(), key=lambda kv: kv[1][1])
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        valu_rate = valu_ops / (ms * 1e-3) if ms > 0 else 0.0
+        traffic = pmc_traffic_per_launch(name)
         b_alg = algorithmic_bytes_per_proof(shapes, prover.log_blowup)
         kernel_ms_total = sum(v[1] for v in prof.values()) / args.steps
         out = {
@@ -235,8 +270,22 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "launches_per_step": launches / args.steps, "avg_launch_ms": ms / launches if launches else None,
+                "traffic": traffic, "launches_per_step": launches / args.steps, "avg_launch_ms": ms / launches if launches else None,
                 "algorithmic_bytes_per_launch": nbytes / launches if launches else None,
+            },
+            # The dominant kernel is Keccak-f[1600] over Merkle nodes: 32-bit integer VALU work, ~4200 ops per 96 B moved,
+            # so its binding roofline is the VALU issue rate, not HBM (SURVEY.md §8(d) caveat; DESIGN.md "Rooflines").
+            "valu_roofline": {
+                "kernel": name, "achieved": valu_rate, "peak": VALU_PEAK_WAVE_INSTR_S, "unit": "wave64 VALU instr/s",
+                "frac": valu_rate / VALU_PEAK_WAVE_INSTR_S, "algorithmic_valu_instr_per_launch": valu_ops / launches if launches else None,
+                "peak_source": "tools/microbench.hip on MI355X: 1 integer VALU instr / 4 cycles / SIMD, 1024 SIMDs, ~2.1 GHz sustained",
+            } if valu_ops > 0 else None,
+            # The same kernel when its proof has the GPU to itself (the 4-proof latency leg): with two proofs in flight
+            # kernels of both proofs share the CUs, so the per-launch durations above are not exclusive-use figures.
+            "roofline_one_proof_in_flight": None if not prof1 else {
+                "kernel": name, "avg_launch_ms": prof1[name][1] / prof1[name][0],
+                "hbm_achieved_GBs": prof1[name][2] / (prof1[name][1] * 1e-3) / 1e9, "hbm_frac": prof1[name][2] / (prof1[name][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "valu_achieved": prof1[name][3] / (prof1[name][1] * 1e-3), "valu_frac": prof1[name][3] / (prof1[name][1] * 1e-3) / VALU_PEAK_WAVE_INSTR_S,
             },
             "proof_roofline": {"algorithmic_bytes_per_proof": b_alg, "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "phase_ms": {k: v / args.steps for k, v in phase.items()},
@@ -244,6 +293,9 @@ def main():
             "kernel_GBs": {k: (v[2] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in prof.items()},
             "kernel_ms_total_per_step": kernel_ms_total,
             "outside_timed_region": {"tracegen_s": t_tracegen, "h2d_upload_s": t_upload, "h2d_bytes": upload_bytes},
+            "pcie_inclusive": {"ms_per_step": pcie_ms, "value": world * 1e3 / pcie_ms, "unit": "proofs/s", "h2d_bytes_per_step": upload_bytes,
+                               "note": "main traces uploaded from pageable host memory inside every step; not the headline value"},
+            "prover_ms_single_proof_in_flight": single if single is not None else ms_per_step,
             "proof_words": int(p.words.size),
             "hbm_pool_peak_bytes": sum(p_.memory()[1] for p_ in provers),
         }

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 (rocpd SQLite) outputs of tools/profile_round.sh into the small tracked summaries under
+profiles/:   python tools/summarize_prof.py r01
+  profiles/<tag>_kernel_stats_inflight{1,2}.csv   per-kernel calls / total / average duration (us)
+  profiles/<tag>_pmc.json                          per-kernel counters per launch: VALU instructions, issue
+                                                   utilisation, HBM bytes (FETCH_SIZE / WRITE_SIZE, corrected as
+                                                   /opt/skills/guides/MI355X_MICROARCH.md prescribes)
+  profiles/<tag>_bench_*.json                      the bench lines of the same session
+"""
+import glob
+import json
+import os
+import re
+import shutil
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.search(r"(k_[a-z0-9_]+)", name)
+    return m.group(1) if m else name.split("(")[0]
+
+
+def db_of(d):
+    hits = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    return hits[0] if hits else None
+
+
+def kernel_stats(db_path, out_csv, header):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    with open(out_csv, "w") as f:
+        f.write("# %s\n# from the rocpd database view top_kernels; durations in microseconds\n" % header)
+        f.write("name,total_calls,total_duration_us,average_us,percentage\n")
+        for n, c, t, a, p in rows:
+            f.write('"%s",%d,%.3f,%.3f,%.3f\n' % (n, c, t, a, p))
+    return {short(n): (c, t, a) for n, c, t, a, p in rows}
+
+
+def counters(db_path):
+    db = sqlite3.connect(db_path)
+    out = {}
+    for name, cname, n, s in db.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+        e = out.setdefault(short(name), {})
+        a = e.get(cname, (0, 0.0))
+        e[cname] = (a[0] + n, a[1] + s)  # template instances of one kernel (k_quotient<..>, k_col_dot<..>) are pooled
+    dur = {}
+    for name, n, s in db.execute("select kernel_name, count(distinct dispatch_id), 0 from counters_collection group by kernel_name"):
+        dur[short(name)] = n
+    return out, dur
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for leg, cmd in (("stats1", "python bench.py --no-cpu-baseline --inflight 1 --steps 5 --warmup 2"), ("stats2", "python bench.py --no-cpu-baseline")):
+        p = db_of(os.path.join(src, leg))
+        if p:
+            kernel_stats(p, os.path.join(dst, "%s_kernel_stats_inflight%s.csv" % (tag, leg[-1])), "rocprofv3 --kernel-trace --stats -- " + cmd + "   (MI355X)")
+    for f in ("bench_default.json", "bench_inflight1.json", "stats1.json", "stats2.json"):
+        p = os.path.join(src, f)
+        if os.path.exists(p) and os.path.getsize(p):
+            shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, f)))
+    pmc = {}
+    p = db_of(os.path.join(src, "pmc_valu"))
+    if p:
+        c, _ = counters(p)
+        for k, v in c.items():
+            n = v["SQ_WAVES"][0]
+            e = pmc.setdefault(k, {"launches_sampled": n})
+            waves = v["SQ_WAVES"][1]
+            e["waves_per_launch"] = waves / n
+            e["valu_wave_instr_per_launch"] = v["SQ_INSTS_VALU"][1] / n
+            e["valu_instr_per_wave"] = v["SQ_INSTS_VALU"][1] / waves if waves else 0
+            e["salu_instr_per_wave"] = v["SQ_INSTS_SALU"][1] / waves if waves else 0
+            wc = v["SQ_WAVE_CYCLES"][1]
+            if wc:
+                e["frac_wave_cycles_valu_active"] = v["SQ_ACTIVE_INST_VALU"][1] / wc
+                e["frac_wave_cycles_wait_any"] = v["SQ_WAIT_ANY"][1] / wc
+                e["frac_wave_cycles_wait_inst_any"] = v["SQ_WAIT_INST_ANY"][1] / wc
+                e["frac_wave_cycles_active_inst_any"] = v["SQ_ACTIVE_INST_ANY"][1] / wc
+    for leg, cname, key in (("pmc_fetch", "FETCH_SIZE", "hbm_read_bytes_per_launch"), ("pmc_write", "WRITE_SIZE", "hbm_write_bytes_per_launch")):
+        p = db_of(os.path.join(src, leg))
+        if p:
+            c, _ = counters(p)
+            for k, v in c.items():
+                n, s = v[cname]
+                # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B
+                # for wide coalesced reads (MI355X_MICROARCH.md, HBM section): doubled here, raw value kept beside it
+                raw = s / n * 1024.0
+                e = pmc.setdefault(k, {})
+                e[key + "_raw"] = raw
+                e[key] = raw * (2.0 if cname == "FETCH_SIZE" else 1.0)
+    if pmc:
+        with open(os.path.join(dst, tag + "_pmc.json"), "w") as f:
+            json.dump({"source": "tools/profile_round.sh passes pmc_valu / pmc_fetch / pmc_write (one proof in flight, 1 warmup + 2 timed proofs + setup)",
+                       "notes": "SQ_* cycle counters are in quad-cycles; FETCH_SIZE doubled per the gfx950 correction, *_raw = as reported",
+                       "kernels": pmc}, f, indent=1, sort_keys=True)
+    print("wrote", sorted(os.listdir(dst)))
+
+
+if __name__ == "__main__":
+    main()

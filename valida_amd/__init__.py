@@ -348,14 +348,14 @@ class Prover:
         lib().vgpu_prover_set_profiling(self._h, ctypes.c_uint32(1 if on else 0))
 
     def profile(self):
-        """{kernel: (launches, total_ms, algorithmic_bytes)} accumulated since set_profiling(True)."""
+        """{kernel: (launches, total_ms, algorithmic_bytes, algorithmic_valu_ops)} accumulated since set_profiling(True)."""
         n = lib().vgpu_prover_profile(self._h, None, ctypes.c_uint64(0))
         buf = ctypes.create_string_buffer(int(n) + 16)
         lib().vgpu_prover_profile(self._h, buf, ctypes.c_uint64(int(n) + 16))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, launches, ms, nbytes = line.split()
-            out[name] = (int(launches), float(ms), float(nbytes))
+            name, launches, ms, nbytes, ops = line.split()
+            out[name] = (int(launches), float(ms), float(nbytes), float(ops))
         return out
 
     def memory(self):

@@ -168,12 +168,13 @@ void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on) {
     c.profiler.reset();
     c.profiler.enabled = on != 0;
 }
-// "name launches total_ms total_algorithmic_bytes\n" per kernel, accumulated since profiling was switched on
+// "name launches total_ms total_algorithmic_bytes total_algorithmic_valu_ops\n" per kernel, accumulated since profiling was switched on
 int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap) {
     std::string s;
     for (auto& kv : p->p->ctx().profiler.stats) {
         char line[256];
-        snprintf(line, sizeof line, "%s %llu %.6f %.0f\n", kv.first.c_str(), (unsigned long long)kv.second.launches, kv.second.ms, kv.second.bytes);
+        snprintf(line, sizeof line, "%s %llu %.6f %.0f %.0f\n", kv.first.c_str(), (unsigned long long)kv.second.launches, kv.second.ms, kv.second.bytes,
+                 kv.second.valu_ops);
         s += line;
     }
     if (out && cap > s.size()) memcpy(out, s.c_str(), s.size() + 1);

@@ -249,26 +249,35 @@ __global__ void __launch_bounds__(1024) k_keccak_top(KeccakTopArgs a) {
     }
 }
 
+// Algorithmic VALU work of the Keccak kernels, in wave64 instructions: permutations x (23 full rounds of 178 ops +
+// the 58-op digest-only last round) / 64 lanes.  A row of n field elements absorbs floor(n / 34) + 1 blocks.
+constexpr double KECCAK_VALU_PER_PERM = 23 * 178.0 + 58.0;
+static double row_perms(int n_elems) { return (double)(n_elems / 34 + 1); }
+static double node_perms(int n_inject) { return n_inject > 0 ? 2.0 + row_perms(n_inject) : 1.0; }
+
 void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
-    double bytes = 0;
-    for (int l = 0; l < a.levels; l++) bytes += (double)(a.first_len >> l) * (96.0 + 4.0 * a.n_elems[l]);
-    ProfScope ps("k_keccak_top", st, bytes);
+    double bytes = 0, perms = 0;
+    for (int l = 0; l < a.levels; l++) {
+        bytes += (double)(a.first_len >> l) * (96.0 + 4.0 * a.n_elems[l]);
+        perms += (double)(a.first_len >> l) * node_perms(a.n_elems[l]);
+    }
+    ProfScope ps("k_keccak_top", st, bytes, perms * KECCAK_VALU_PER_PERM / 64.0);
     hipLaunchKernelGGL(k_keccak_top, dim3(1), dim3(1024), 0, st, a);
 }
 
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
-    ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0));
+    ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
     hipLaunchKernelGGL(k_keccak_leaves<PtrCols>, dim3(blocks), dim3(256), 0, st, PtrCols{cols_dev}, n_elems, n_rows, digests);
 }
 void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
-    ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0));
+    ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
     hipLaunchKernelGGL(k_keccak_leaves<StridedCols>, dim3(blocks), dim3(256), 0, st, StridedCols{base, stride}, n_elems, n_rows, digests);
 }
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
     unsigned blocks = (unsigned)((n_out + 255) / 256);
-    ProfScope ps("k_keccak_compress", st, (double)n_out * (96.0 + 4.0 * n_elems));
+    ProfScope ps("k_keccak_compress", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * node_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
     hipLaunchKernelGGL(k_keccak_compress, dim3(blocks), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
 }
 

@@ -10,11 +10,11 @@
 
 namespace vk {
 
-struct KernelStat { uint64_t launches = 0; double ms = 0; double bytes = 0; };
+struct KernelStat { uint64_t launches = 0; double ms = 0; double bytes = 0; double valu_ops = 0; };
 
 struct Profiler {
     bool enabled = false;
-    struct Rec { const char* name; hipEvent_t start, stop; double bytes; };
+    struct Rec { const char* name; hipEvent_t start, stop; double bytes, valu_ops; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     std::map<std::string, KernelStat> stats;
@@ -30,7 +30,7 @@ struct Profiler {
             float ms = 0;
             if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
                 KernelStat& s = stats[r.name];
-                s.launches++; s.ms += ms; s.bytes += r.bytes;
+                s.launches++; s.ms += ms; s.bytes += r.bytes; s.valu_ops += r.valu_ops;
             }
             pool.push_back(r.start);
             pool.push_back(r.stop);
@@ -47,9 +47,11 @@ struct ProfScope {
     Profiler* p;
     hipStream_t st;
     size_t idx;
-    ProfScope(const char* name, hipStream_t s, double bytes) : p(g_profiler), st(s), idx(0) {
+    // valu_ops: algorithmic wave64 VALU instructions of the launch, for the kernels whose roofline is the integer
+    // issue rate rather than HBM (the Keccak kernels); 0 = not modelled
+    ProfScope(const char* name, hipStream_t s, double bytes, double valu_ops = 0) : p(g_profiler), st(s), idx(0) {
         if (!p || !p->enabled) { p = nullptr; return; }
-        Profiler::Rec r{name, p->get(), p->get(), bytes};
+        Profiler::Rec r{name, p->get(), p->get(), bytes, valu_ops};
         (void)hipEventRecord(r.start, st);
         idx = p->recs.size();
         p->recs.push_back(r);
