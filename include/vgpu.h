@@ -159,6 +159,39 @@ int64_t vgpu_proof_debug_perm_trace(const vgpu_proof_t* pr, uint32_t chip, uint3
 int64_t vgpu_proof_debug_quotient(const vgpu_proof_t* pr, uint32_t chip, uint32_t* out, uint64_t cap_words);
 void vgpu_proof_free(vgpu_proof_t* pr);
 
+/* ---- trace generation on the device: Chip::generate_trace (machine/src/chip.rs:22) of the big
+ * BasicMachine chips as kernels, fed by the VM's operation logs instead of host-built RowMajorMatrix traces.
+ * The logs are what the reference's chips hold after Machine::run: Cpu::operations + pc/fp/instruction per cycle
+ * (cpu/src/lib.rs:56-77), MemoryChip::operations: BTreeMap<clk, Vec<Operation>> flattened in (clk, issue) order
+ * (memory/src/lib.rs:25-60), and each ALU chip's Vec<Operation> (alu_u32/src/add/mod.rs:26-36).  Words cross the
+ * ABI as the u32 value of the big-endian Word (machine/src/core.rs:9). ---- */
+enum { VGPU_CPU_STORE32 = 0, VGPU_CPU_LOAD32, VGPU_CPU_JAL, VGPU_CPU_JALV, VGPU_CPU_BEQ, VGPU_CPU_BNE, VGPU_CPU_IMM32, VGPU_CPU_BUS,
+       VGPU_CPU_BUS_LEFT_IMM, VGPU_CPU_STOP, VGPU_CPU_LOADFP };   /* cpu Operation (cpu/src/lib.rs:40-54) */
+typedef struct vgpu_cpu_op {
+    uint32_t pc, fp, opcode;
+    int32_t operands[5];
+    uint32_t kind;        /* VGPU_CPU_* */
+    uint32_t has_imm;     /* Operation::*(Some(imm)) */
+    uint32_t imm;
+    uint32_t mem_first;   /* index of this cycle's first entry in the memory log */
+} vgpu_cpu_op_t;
+typedef struct vgpu_mem_op { uint32_t clk, addr, value, is_write; } vgpu_mem_op_t;   /* memory Operation::{Read,Write}(addr, value) at clk */
+typedef struct vgpu_alu_op { uint32_t opcode, a, b, c; } vgpu_alu_op_t;              /* e.g. Operation::Add32(a, b, c): a = result */
+typedef struct vgpu_oplog_desc {
+    const vgpu_cpu_op_t* cpu; uint64_t n_cpu;
+    const vgpu_mem_op_t* mem; uint64_t n_mem;
+    const vgpu_alu_op_t* alu[4]; uint64_t n_alu[4];   /* add, sub, lt, bitwise */
+} vgpu_oplog_desc_t;
+typedef struct vgpu_oplog vgpu_oplog_t;
+int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_oplog_t** out);
+void vgpu_oplog_free(vgpu_oplog_t* log);
+/* chip: cpu (0), mem (2), add (3), sub (4), lt (8), bitwise (10); any other chip -> VGPU_ERR_INVALID_ARG (generate it on the
+ * host and vgpu_trace_upload it).  The returned trace is already in the prover's working layout (no ingest pass). */
+int32_t vgpu_generate_trace(vgpu_prover_t* p, const vgpu_oplog_t* log, uint32_t chip, vgpu_trace_t** out);
+void vgpu_trace_shape(const vgpu_trace_t* t, uint64_t* height, uint64_t* width);
+/* canonical row-major copy of a device trace (what the reference's generate_trace would have returned) */
+int32_t vgpu_trace_download(vgpu_prover_t* p, const vgpu_trace_t* t, uint32_t* out, uint64_t cap_words);
+
 /* ---- synthetic workloads (bench inputs; upstream of the hot path) ---- */
 typedef struct vgpu_workload vgpu_workload_t;
 /* fib_program (basic/tests/test_prover.rs:35-188) with loop bound n, fp = 0x1000, run to STOP, traces generated */
@@ -169,6 +202,8 @@ void vgpu_workload_free(vgpu_workload_t* w);
 /* stats: [cycles, cpu ops, memory ops, add ops, result word (u32 at fp+4), program length, padded cpu height] */
 void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]);
 int32_t vgpu_workload_main_trace(const vgpu_workload_t* w, uint32_t chip, const uint32_t** data, uint64_t* height, uint64_t* width);
+/* the VM's operation logs (pointers stay valid until vgpu_workload_free) */
+void vgpu_workload_oplog(const vgpu_workload_t* w, vgpu_oplog_desc_t* out);
 /* k = 0: program ROM (chip 1), k = 1: range table (chip 12) */
 int32_t vgpu_workload_preprocessed(const vgpu_workload_t* w, uint32_t k, uint32_t* chip, const uint32_t** data, uint64_t* height, uint64_t* width);
 

@@ -161,3 +161,19 @@ def test_bench_algorithmic_bytes_matches_survey():
     assert abs(b / 1e9 - 16.84) < 0.02  # C2 = 16.84 GB
     for k, n in bench.FIB_N.items():
         assert (1 << (k - 1)) < 17 + 7 * n <= (1 << k)
+
+
+def test_workload_oplog_shape():
+    # the logs the device trace generators consume: cpu records in clock order, each pointing at its memory operations
+    w = va.Workload.alu(10)
+    d = w.oplog()
+    assert d.n_cpu == w.cycles and d.n_mem == w.mem_ops
+    assert [int(x) for x in d.n_alu] == [30, 10, 10, 30]  # add (3/iter), sub, lt, bitwise (3/iter)
+    cpu = np.ctypeslib.as_array(ctypes.cast(d.cpu, ctypes.POINTER(ctypes.c_uint32)), shape=(int(d.n_cpu), 12))
+    mem = np.ctypeslib.as_array(ctypes.cast(d.mem, ctypes.POINTER(ctypes.c_uint32)), shape=(int(d.n_mem), 4))
+    first = cpu[:, 11]
+    assert first[0] == 0 and np.all(np.diff(first.astype(np.int64)) >= 0) and np.all(np.diff(first.astype(np.int64)) <= 3)
+    assert np.all(np.diff(mem[:, 0].astype(np.int64)) >= 0)  # (clk, issue) order
+    has = np.nonzero(np.diff(np.append(first, d.n_mem).astype(np.int64)) > 0)[0]
+    assert np.all(mem[first[has], 0] == has)  # a record's first memory operation carries its clock
+    assert cpu[-1, 8] == 9  # last record is STOP

@@ -95,6 +95,17 @@ def poseidon_round_constants(seed=0x56414C494441):
     return np.array(out, dtype=np.uint32)
 
 
+class OplogDesc(ctypes.Structure):  # vgpu_oplog_desc_t
+    _fields_ = [
+        ("cpu", ctypes.c_void_p), ("n_cpu", ctypes.c_uint64),
+        ("mem", ctypes.c_void_p), ("n_mem", ctypes.c_uint64),
+        ("alu", ctypes.c_void_p * 4), ("n_alu", ctypes.c_uint64 * 4),
+    ]
+
+
+GENERATED_CHIPS = (0, 2, 3, 4, 8, 10)  # cpu, mem, add, sub, lt, bitwise: chips with a device trace generator
+
+
 class Workload:
     """Synthetic workload: fib_program(n) run on the BasicMachine, all chip traces generated (host)."""
 
@@ -124,6 +135,13 @@ class Workload:
 
     def main_traces(self):
         return [self.main_trace(i) for i in range(NUM_CHIPS)]
+
+    def oplog(self):
+        """The VM's operation logs (vgpu_oplog_desc_t; buffers owned by this workload)."""
+        d = OplogDesc()
+        lib().vgpu_workload_oplog(self._h, ctypes.byref(d))
+        d._owner = self
+        return d
 
     def preprocessed(self):
         """[(chip index, matrix)] in chip order: program ROM, range table."""
@@ -219,9 +237,25 @@ def poseidon16_permute(rc, state):
     return s
 
 
+class DeviceOplog:
+    def __init__(self, prover, handle, nbytes):
+        self._prover, self._h, self.nbytes = prover, handle, nbytes
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vgpu_oplog_free(self._h)
+            self._h = None
+
+
 class DeviceTrace:
     def __init__(self, prover, handle, shape):
         self._prover, self._h, self.shape = prover, handle, shape
+
+    def download(self):
+        """Canonical row-major copy (what the reference's generate_trace would have returned)."""
+        out = np.zeros(self.shape, dtype=np.uint32)
+        _check(lib().vgpu_trace_download(self._prover._h, self._h, out.ctypes.data_as(c_u32p), ctypes.c_uint64(out.size)))
+        return out
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -305,6 +339,22 @@ class Prover:
         h = ctypes.c_void_p()
         _check(lib().vgpu_trace_upload(self._h, m.ctypes.data_as(c_u32p), ctypes.c_uint64(m.shape[0]), ctypes.c_uint64(m.shape[1]), ctypes.byref(h)))
         return DeviceTrace(self, h, m.shape)
+
+    def upload_oplog(self, desc):
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_oplog_upload(self._h, ctypes.byref(desc), ctypes.byref(h)))
+        nbytes = 48 * desc.n_cpu + 16 * desc.n_mem + 16 * sum(desc.n_alu)
+        log = DeviceOplog(self, h, int(nbytes))
+        log._desc = desc
+        return log
+
+    def generate_trace(self, log, chip):
+        """Chip::generate_trace of `chip` on the device, from the uploaded operation logs."""
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_generate_trace(self._h, log._h, ctypes.c_uint32(chip), ctypes.byref(h)))
+        hh, ww = ctypes.c_uint64(), ctypes.c_uint64()
+        lib().vgpu_trace_shape(h, ctypes.byref(hh), ctypes.byref(ww))
+        return DeviceTrace(self, h, (int(hh.value), int(ww.value)))
 
     def commit_batches(self, traces, coset_shifts=None):
         arr = (ctypes.c_void_p * len(traces))(*[t._h for t in traces])

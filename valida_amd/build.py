@@ -20,6 +20,7 @@ SOURCES = [
     "kernels/perm.hip",
     "kernels/quotient.hip",
     "kernels/open.hip",
+    "kernels/tracegen.hip",
     "host/prover.cpp",
     "capi.cpp",
 ]

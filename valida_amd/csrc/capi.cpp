@@ -27,12 +27,21 @@ struct vgpu_prover { std::unique_ptr<Prover> p; };
 struct vgpu_trace { std::unique_ptr<DeviceTrace> t; };
 struct vgpu_pdata { std::unique_ptr<ProverData> pd; };
 struct vgpu_proof { std::vector<uint32_t> words; PhaseTimes tm; ProveDebugOut dbg; };
+struct vgpu_oplog { std::unique_ptr<DeviceOplog> log; };
+static_assert(sizeof(vgpu_cpu_op_t) == sizeof(vk::TgCpuOp) && sizeof(vgpu_mem_op_t) == sizeof(vk::TgMemOp) && sizeof(vgpu_alu_op_t) == sizeof(vk::TgAluOp),
+              "C ABI log records and their device images must match");
+static_assert((int)VGPU_CPU_LOADFP == (int)vk::TG_CPU_LOADFP, "cpu op kinds");
 struct vgpu_workload {
+    std::vector<vgpu_cpu_op_t> log_cpu;
+    std::vector<vgpu_mem_op_t> log_mem;
+    std::vector<vgpu_alu_op_t> log_alu[4];
     std::unique_ptr<vwork::BasicVm> vm;
     std::vector<vwork::RowMajor> main;
     vwork::RowMajor prep_program, prep_range;
     uint64_t result = 0;
 };
+
+static void fill_logs(vgpu_workload& w);
 
 extern "C" {
 
@@ -190,11 +199,47 @@ int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t heigh
     })
 }
 void vgpu_trace_free(vgpu_trace_t* t) { delete t; }
+void vgpu_trace_shape(const vgpu_trace_t* t, uint64_t* height, uint64_t* width) { *height = t->t->height; *width = t->t->width; }
+int32_t vgpu_trace_download(vgpu_prover_t* p, const vgpu_trace_t* t, uint32_t* out, uint64_t cap_words) {
+    VG_TRY({
+        if (!p || !t || !out) throw std::invalid_argument("null argument");
+        if (cap_words < t->t->height * t->t->width) throw std::invalid_argument("output buffer too small");
+        p->p->ctx().activate();
+        p->p->download_trace(*t->t, out);
+    })
+}
+int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_oplog_t** out) {
+    VG_TRY({
+        if (!p || !log || !out) throw std::invalid_argument("null argument");
+        p->p->ctx().activate();
+        HostOplog h;
+        h.cpu = (const vk::TgCpuOp*)log->cpu; h.n_cpu = log->n_cpu;
+        h.mem = (const vk::TgMemOp*)log->mem; h.n_mem = log->n_mem;
+        for (int k = 0; k < 4; k++) { h.alu[k] = (const vk::TgAluOp*)log->alu[k]; h.n_alu[k] = log->n_alu[k]; }
+        for (uint64_t i = 0; i < h.n_cpu; i++)
+            if (log->cpu[i].mem_first > h.n_mem || (i && log->cpu[i].mem_first < log->cpu[i - 1].mem_first) || log->cpu[i].kind > VGPU_CPU_LOADFP)
+                throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + " is malformed");
+        auto* l = new vgpu_oplog();
+        l->log = p->p->upload_oplog(h);
+        *out = l;
+    })
+}
+void vgpu_oplog_free(vgpu_oplog_t* log) { delete log; }
+int32_t vgpu_generate_trace(vgpu_prover_t* p, const vgpu_oplog_t* log, uint32_t chip, vgpu_trace_t** out) {
+    VG_TRY({
+        if (!p || !log || !out) throw std::invalid_argument("null argument");
+        p->p->ctx().activate();
+        auto* t = new vgpu_trace();
+        t->t = p->p->generate_trace(*log->log, (int)chip);
+        *out = t;
+    })
+}
 
 static DMat ingest(DeviceCtx& c, const DeviceTrace& t) {
     if (t.height & (t.height - 1)) throw std::invalid_argument("matrix height must be a power of two");
     DMat m(&c, t.height, t.width);
-    vk::launch_ingest(c.stream, t.raw.data, m.view(), false);
+    if (!t.nat.empty()) VG_HIP_CHECK(hipMemcpyAsync(m.data, t.nat.data, t.height * t.width * 4, hipMemcpyDeviceToDevice, c.stream));
+    else vk::launch_ingest(c.stream, t.raw.data, m.view(), false);
     return m;
 }
 
@@ -331,6 +376,7 @@ int32_t vgpu_workload_fib(uint32_t n, vgpu_workload_t** out) {
         w->prep_range = vwork::BasicVm::range_preprocessed();
         auto it = w->vm->cells.find(0x1000 + 4);
         w->result = it == w->vm->cells.end() ? 0 : it->second;
+        fill_logs(*w);
         *out = w.release();
     })
 }
@@ -345,8 +391,35 @@ int32_t vgpu_workload_alu(uint32_t iters, vgpu_workload_t** out) {
         w->prep_range = vwork::BasicVm::range_preprocessed();
         auto it = w->vm->cells.find(0x1000 - 4);
         w->result = it == w->vm->cells.end() ? 0 : it->second;
+        fill_logs(*w);
         *out = w.release();
     })
+}
+static void fill_logs(vgpu_workload& w) {
+    const vwork::BasicVm& vm = *w.vm;
+    std::vector<uint32_t> first(vm.cpu_ops.size() + 1, 0);
+    for (auto& m : vm.mem_ops) first[m.clk + 1]++;
+    for (size_t i = 0; i < vm.cpu_ops.size(); i++) first[i + 1] += first[i];
+    w.log_cpu.resize(vm.cpu_ops.size());
+    for (size_t i = 0; i < vm.cpu_ops.size(); i++) {
+        const auto& r = vm.cpu_ops[i];
+        vgpu_cpu_op_t& o = w.log_cpu[i];
+        o.pc = r.pc; o.fp = r.fp; o.opcode = r.instr.opcode;
+        for (int k = 0; k < 5; k++) o.operands[k] = r.instr.ops[k];
+        o.kind = (uint32_t)r.op; o.has_imm = r.has_imm ? 1 : 0; o.imm = vwork::u32_of(r.imm); o.mem_first = first[i];
+    }
+    w.log_mem.resize(vm.mem_ops.size());
+    for (size_t i = 0; i < vm.mem_ops.size(); i++) w.log_mem[i] = {vm.mem_ops[i].clk, vm.mem_ops[i].addr, vwork::u32_of(vm.mem_ops[i].value), vm.mem_ops[i].is_write ? 1u : 0u};
+    const std::vector<vwork::AluOp>* src[4] = {&vm.add_ops, &vm.sub_ops, &vm.lt_ops, &vm.bitwise_ops};
+    for (int k = 0; k < 4; k++) {
+        w.log_alu[k].resize(src[k]->size());
+        for (size_t i = 0; i < src[k]->size(); i++) { const auto& a = (*src[k])[i]; w.log_alu[k][i] = {a.opcode, vwork::u32_of(a.a), vwork::u32_of(a.b), vwork::u32_of(a.c)}; }
+    }
+}
+void vgpu_workload_oplog(const vgpu_workload_t* w, vgpu_oplog_desc_t* out) {
+    out->cpu = w->log_cpu.data(); out->n_cpu = w->log_cpu.size();
+    out->mem = w->log_mem.data(); out->n_mem = w->log_mem.size();
+    for (int k = 0; k < 4; k++) { out->alu[k] = w->log_alu[k].data(); out->n_alu[k] = w->log_alu[k].size(); }
 }
 void vgpu_workload_free(vgpu_workload_t* w) { delete w; }
 void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]) {

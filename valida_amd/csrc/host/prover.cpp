@@ -71,6 +71,68 @@ std::unique_ptr<DeviceTrace> Prover::upload_trace(const HostMatrix& m) {
     return t;
 }
 
+static size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+static DBuf upload_bytes(DeviceCtx& c, const void* src, size_t bytes) {
+    DBuf b(&c, (bytes + 3) / 4 + 4);
+    if (bytes) VG_HIP_CHECK(hipMemcpyAsync(b.data, src, bytes, hipMemcpyHostToDevice, c.stream));
+    return b;
+}
+
+std::unique_ptr<DeviceOplog> Prover::upload_oplog(const HostOplog& log) {
+    if (!log.n_cpu || !log.cpu) throw std::invalid_argument("oplog: empty cpu log");
+    DeviceCtx& c = *ctx_;
+    auto d = std::make_unique<DeviceOplog>();
+    d->n_cpu = log.n_cpu; d->n_mem = log.n_mem;
+    d->cpu = upload_bytes(c, log.cpu, log.n_cpu * sizeof(vk::TgCpuOp));
+    d->mem = upload_bytes(c, log.mem, log.n_mem * sizeof(vk::TgMemOp));
+    for (int k = 0; k < 4; k++) { d->n_alu[k] = log.n_alu[k]; d->alu[k] = upload_bytes(c, log.alu[k], log.n_alu[k] * sizeof(vk::TgAluOp)); }
+    c.sync();
+    return d;
+}
+
+bool Prover::can_generate(int chip) {
+    using namespace vchips;
+    return chip == CHIP_CPU || chip == CHIP_MEM || chip == CHIP_ADD || chip == CHIP_SUB || chip == CHIP_LT || chip == CHIP_BITWISE;
+}
+
+std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int chip) {
+    using namespace vchips;
+    if (!can_generate(chip) || (size_t)chip >= machine_.airs.size() || machine_.airs[chip].native_chip != chip)
+        throw std::invalid_argument("generate_trace: no device trace generator for this chip");
+    DeviceCtx& c = *ctx_;
+    auto t = std::make_unique<DeviceTrace>();
+    t->width = machine_.airs[chip].width;
+    if (chip == CHIP_CPU) {
+        t->height = next_pow2(log.n_cpu);
+        t->nat = DMat(&c, t->height, t->width);
+        vk::launch_tracegen_cpu(c.stream, (const vk::TgCpuOp*)log.cpu.data, log.n_cpu, (const vk::TgMemOp*)log.mem.data, log.n_mem, t->nat.view());
+    } else if (chip == CHIP_MEM) {
+        t->height = next_pow2(log.n_mem);  // 0 operations -> one zero row
+        t->nat = DMat(&c, t->height, t->width);
+        const uint64_t n = log.n_mem;
+        const size_t tmp_bytes = vk::tracegen_mem_sort_scratch_bytes(n ? n : 1);
+        DBuf keys(&c, 2 * n + 4), idx(&c, 2 * n + 4), tmp(&c, tmp_bytes / 4 + 4);
+        if (n) VG_HIP_CHECK(vk::launch_tracegen_mem(c.stream, (const vk::TgMemOp*)log.mem.data, n, keys.data, idx.data, tmp.data, tmp_bytes, t->nat.view()));
+        else VG_HIP_CHECK(hipMemsetAsync(t->nat.data, 0, t->height * t->width * 4, c.stream));
+        c.sync();  // scratch buffers go back to the pool
+    } else {
+        const int k = chip == CHIP_ADD ? 0 : chip == CHIP_SUB ? 1 : chip == CHIP_LT ? 2 : 3;
+        t->height = next_pow2(log.n_alu[k]);
+        t->nat = DMat(&c, t->height, t->width);
+        vk::launch_tracegen_alu(c.stream, chip, (const vk::TgAluOp*)log.alu[k].data, log.n_alu[k], t->nat.view());
+    }
+    c.check_launch("generate_trace");
+    return t;
+}
+
+void Prover::download_trace(const DeviceTrace& t, uint32_t* out) {
+    DeviceCtx& c = *ctx_;
+    if (t.nat.empty()) { c.download(out, t.raw.data, t.height * t.width * 4); return; }
+    DBuf tmp(&c, (size_t)(t.height * t.width));
+    vk::launch_export_rows(c.stream, t.nat.view(), 0, t.height, tmp.data);
+    c.download(out, tmp.data, t.height * t.width * 4);
+}
+
 namespace {
 struct PointKey {
     uint32_t w[5];
@@ -110,15 +172,18 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
 
     // ---------------- ingest: row-major canonical -> column-major Montgomery (natural row order)
     std::vector<unsigned> log_deg(NC);
-    std::vector<DMat> main_nat(NC);
+    std::vector<DMat> main_own(NC);
+    std::vector<const DMat*> main_nat(NC);
     Section ingest_section(&c);
     for (size_t i = 0; i < NC; i++) {
         if (main[i]->width != machine_.airs[i].width) throw std::invalid_argument("prove: trace width mismatch for chip " + machine_.airs[i].name);
         uint64_t h = main[i]->height;
         if (h == 0 || (h & (h - 1))) throw std::invalid_argument("prove: trace heights must be powers of two");
         log_deg[i] = vg::log2_strict_u64(h);
-        main_nat[i] = DMat(&c, h, main[i]->width);
-        vk::launch_ingest(c.stream_for(i, h), main[i]->raw.data, main_nat[i].view(), false);
+        if (!main[i]->nat.empty()) { main_nat[i] = &main[i]->nat; continue; }  // generated on the device: already in working layout
+        main_own[i] = DMat(&c, h, main[i]->width);
+        main_nat[i] = &main_own[i];
+        vk::launch_ingest(c.stream_for(i, h), main[i]->raw.data, main_own[i].view(), false);
     }
     std::vector<DMat> prep_nat(preprocessed.size());
     std::vector<int> prep_slot(NC, -1);
@@ -147,7 +212,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     std::unique_ptr<ProverData> main_pd;
     {
         std::vector<CommitInput> in;
-        for (auto& m : main_nat) in.push_back({&m, false, false});
+        for (auto m : main_nat) in.push_back({const_cast<DMat*>(m), false, false});  // consume = false: never modified
         main_pd = commit_batches(&c, in, nullptr, fri_);
     }
     ch.observe_digest(main_pd->tree.root);
@@ -184,12 +249,12 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         Section perm_section(&c);
         for (size_t i = 0; i < NC; i++) {
             uint32_t M = (uint32_t)machine_.airs[i].interactions.size();
-            uint64_t n = main_nat[i].height;
+            uint64_t n = main_nat[i]->height;
             perm_nat[i] = DMat(&c, n, 5 * (M + 1));
             vk::DMatView pv{nullptr, 0, 0, 0};
             if (prep_slot[i] >= 0) pv = prep_nat[prep_slot[i]].view();
             scratch.emplace_back(&c, (size_t)vk::perm_scratch_words(n));
-            vk::launch_perm_trace(c.stream_for(i, n), main_nat[i].view(), pv, iw_dev_[i].data, pool_dev.data + off[i], M, perm_nat[i].view(), scratch.back().data);
+            vk::launch_perm_trace(c.stream_for(i, n), main_nat[i]->view(), pv, iw_dev_[i].data, pool_dev.data + off[i], M, perm_nat[i].view(), scratch.back().data);
             gl.add(perm_nat[i].data + (uint64_t)(5 * M) * n + (n - 1), n, 5, 0);  // cumulative sum = last row, last column (lib.rs:247-250)
         }
         perm_section.join();
@@ -220,7 +285,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     }
     ch.observe_digest(perm_pd->tree.root);
     perm_nat.clear();
-    main_nat.clear();
+    main_own.clear();
     prep_nat.clear();
     tm.commit_perm = ms_since(t0);
 

@@ -17,10 +17,26 @@ struct HostMatrix {  // canonical row-major, host memory (the reference's RowMaj
     uint64_t height, width;
 };
 
-// A trace resident in HBM in the layout the reference hands over (row-major, canonical u32).
+// A trace resident in HBM: either in the layout the reference hands over (`raw`: row-major, canonical u32, from
+// upload_trace) or already in the prover's working layout (`nat`: column-major Montgomery, natural row order, from
+// device trace generation — needs no ingest pass).
 struct DeviceTrace {
     DBuf raw;
+    DMat nat;
     uint64_t height = 0, width = 0;
+};
+
+// The VM's operation logs, as the chips' generate_trace reads them (cpu/src/lib.rs:79-97, memory/src/lib.rs:143-160,
+// alu_u32/src/*/mod.rs), flattened: cpu records in clock order, memory operations in (clk, issue) order with each
+// cpu record pointing at its first one, ALU operations per chip in issue order.
+struct HostOplog {
+    const vk::TgCpuOp* cpu = nullptr; uint64_t n_cpu = 0;
+    const vk::TgMemOp* mem = nullptr; uint64_t n_mem = 0;
+    const vk::TgAluOp* alu[4] = {nullptr, nullptr, nullptr, nullptr}; uint64_t n_alu[4] = {0, 0, 0, 0};  // add, sub, lt, bitwise
+};
+struct DeviceOplog {
+    DBuf cpu, mem, alu[4];
+    uint64_t n_cpu = 0, n_mem = 0, n_alu[4] = {0, 0, 0, 0};
 };
 
 struct PhaseTimes {  // milliseconds, host clock around stream syncs
@@ -46,6 +62,14 @@ class Prover {
 
     // H2D of one host trace (not part of the timed prove()).
     std::unique_ptr<DeviceTrace> upload_trace(const HostMatrix& m);
+
+    // Device trace generation: H2D of the operation logs, then Chip::generate_trace of chip
+    // `chip` (cpu, mem, add, sub, lt, bitwise) as a kernel.  Other chips: host generate_trace + upload_trace.
+    std::unique_ptr<DeviceOplog> upload_oplog(const HostOplog& log);
+    std::unique_ptr<DeviceTrace> generate_trace(const DeviceOplog& log, int chip);
+    static bool can_generate(int chip);
+    // canonical row-major copy of a device trace (tests)
+    void download_trace(const DeviceTrace& t, uint32_t* out);
 
     // main[i]: trace of chip i (chip order).  preprocessed: (chip index, trace) in chip order.
     std::vector<uint32_t> prove(const std::vector<const DeviceTrace*>& main, const std::vector<std::pair<int, const DeviceTrace*>>& preprocessed,

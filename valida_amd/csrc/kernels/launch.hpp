@@ -53,6 +53,16 @@ void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint3
                        uint32_t* scratch);
 // quotient.hip
 void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& tb);
+// tracegen.hip — device images of the VM's operation logs (C ABI twins: vgpu_cpu_op_t, vgpu_mem_op_t, vgpu_alu_op_t)
+struct TgCpuOp { uint32_t pc, fp, opcode; int32_t operands[5]; uint32_t kind, has_imm, imm, mem_first; };
+struct TgMemOp { uint32_t clk, addr, value, is_write; };
+struct TgAluOp { uint32_t opcode, a, b, c; };  // a = result, b / c = inputs, as u32 values of the big-endian Words
+enum { TG_CPU_STORE32 = 0, TG_CPU_LOAD32, TG_CPU_JAL, TG_CPU_JALV, TG_CPU_BEQ, TG_CPU_BNE, TG_CPU_IMM32, TG_CPU_BUS, TG_CPU_BUS_LEFT_IMM, TG_CPU_STOP,
+       TG_CPU_LOADFP };
+void launch_tracegen_cpu(hipStream_t st, const TgCpuOp* ops, uint64_t n, const TgMemOp* mem, uint64_t n_mem, DMatView t);
+size_t tracegen_mem_sort_scratch_bytes(uint64_t n);
+hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, uint32_t* keys2, uint32_t* idx2, void* sort_tmp, size_t sort_tmp_bytes, DMatView t);
+void launch_tracegen_alu(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t);
 // open.hip
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w);
 uint64_t col_dot_slots(uint64_t n);

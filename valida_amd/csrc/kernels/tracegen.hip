@@ -1,0 +1,218 @@
+// Trace generation on the device: `Chip::generate_trace` (machine/src/chip.rs:22) of the big
+// BasicMachine chips, from the VM's operation logs instead of from host-built RowMajorMatrix traces:
+//   cpu      cpu/src/lib.rs:79-97,163-236   op_to_row, set_memory_channel_values :253-296, compute_word_diffs
+//                                            :298-330, pad_to_power_of_two :332-373
+//   mem      memory/src/lib.rs:143-194       sort by (addr, clk), op_to_row, zero padding
+//   add      alu_u32/src/add/mod.rs:38-51,91-121      sub  alu_u32/src/sub/mod.rs:91-121
+//   lt       alu_u32/src/lt/mod.rs:87-166             bitwise  alu_u32/src/bitwise/mod.rs:84-129
+// One thread per trace row; every column is written straight into the column-major Montgomery matrix the
+// commitment phase consumes (natural row order), so neither the 516 MB row-major upload nor k_ingest is needed.
+// The memory chip's (addr, clk) order is a stable LSD radix sort of the clk-ordered log by address (rocPRIM).
+#include <cstring>
+#include "launch.hpp"
+#include "../chips/basic_machine.hpp"
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace vk {
+
+using namespace vchips;
+
+__device__ __forceinline__ void put(DMatView m, int col, uint64_t row, uint32_t canonical) {
+    m.data[(uint64_t)col * m.stride + row] = Fp::from_canonical(canonical).v;
+}
+__device__ __forceinline__ void put_raw(DMatView m, int col, uint64_t row, Fp v) { m.data[(uint64_t)col * m.stride + row] = v.v; }
+__device__ __forceinline__ uint32_t byte_of(uint32_t word, int k) { return (word >> (24 - 8 * k)) & 0xffu; }  // big-endian byte k (machine/src/core.rs:9)
+__device__ __forceinline__ uint32_t from_i32(int32_t x) {  // Val::from_canonical / negative operands as p - |x|
+    uint32_t a = (uint32_t)(x < 0 ? -(int64_t)x : (int64_t)x) % vg::P;
+    return (x < 0 && a) ? vg::P - a : a;
+}
+
+// ---- cpu -----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tracegen_cpu(const TgCpuOp* __restrict__ ops, uint64_t n, const TgMemOp* __restrict__ mem, uint64_t n_mem, DMatView t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.height) return;
+    uint32_t r[cpu::NUM_COLS];
+#pragma unroll
+    for (int c = 0; c < cpu::NUM_COLS; c++) r[c] = 0;
+    r[cpu::ch(0, cpu::CH_IS_READ)] = 1; r[cpu::ch(1, cpu::CH_IS_READ)] = 1;
+    Fp diff = Fp::zero();
+    if (i < n) {
+        const TgCpuOp o = ops[i];
+        r[cpu::PC] = o.pc; r[cpu::FP] = o.fp % vg::P; r[cpu::CLK] = (uint32_t)i; r[cpu::OPCODE] = o.opcode;
+#pragma unroll
+        for (int k = 0; k < 5; k++) r[cpu::OPERAND_A + k] = from_i32(o.operands[k]);
+        const bool left = o.kind == TG_CPU_BUS_LEFT_IMM;
+        // flag column of the op kind (Operation -> is_* flags, cpu/src/lib.rs:163-236)
+        r[cpu::IS_STORE] = o.kind == TG_CPU_STORE32; r[cpu::IS_LOAD] = o.kind == TG_CPU_LOAD32; r[cpu::IS_JAL] = o.kind == TG_CPU_JAL;
+        r[cpu::IS_JALV] = o.kind == TG_CPU_JALV; r[cpu::IS_BEQ] = o.kind == TG_CPU_BEQ; r[cpu::IS_BNE] = o.kind == TG_CPU_BNE;
+        r[cpu::IS_IMM32] = o.kind == TG_CPU_IMM32; r[cpu::IS_BUS_OP] = (o.kind == TG_CPU_BUS || left); r[cpu::IS_STOP] = o.kind == TG_CPU_STOP;
+        r[cpu::IS_LOADFP] = o.kind == TG_CPU_LOADFP;
+        uint32_t val[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, used[3] = {0, 0, 0}, addr[3] = {0, 0, 0};
+        const bool imm_kind = o.kind == TG_CPU_BEQ || o.kind == TG_CPU_BNE || o.kind == TG_CPU_BUS || left;
+        if (o.has_imm && imm_kind) {  // the immediate rides in the read channel it replaces; operand = Word::reduce
+            if (left) { r[cpu::IS_LEFT_IMM_OP] = 1; r[cpu::OPERAND_B] = o.imm % vg::P; }
+            else { r[cpu::IS_IMM_OP] = 1; r[cpu::OPERAND_C] = o.imm % vg::P; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { if (left) val[0][k] = byte_of(o.imm, k); else val[1][k] = byte_of(o.imm, k); }
+        }
+        // set_memory_channel_values: this cycle's memory operations in issue order
+        const uint64_t m0 = o.mem_first, m1 = i + 1 < n ? ops[i + 1].mem_first : n_mem;
+        bool first_read = true;
+        for (uint64_t k = m0; k < m1; k++) {
+            const TgMemOp m = mem[k];
+            const int chn = m.is_write ? 2 : ((first_read && !left) ? 0 : 1);
+            if (!m.is_write && chn == 0) first_read = false;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (c == chn) {
+                    used[c] = 1; addr[c] = m.addr % vg::P;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) val[c][b] = byte_of(m.value, b);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            r[cpu::ch(c, cpu::CH_USED)] = used[c]; r[cpu::ch(c, cpu::CH_ADDR)] = addr[c];
+#pragma unroll
+            for (int b = 0; b < 4; b++) r[cpu::ch(c, cpu::CH_VALUE) + b] = val[c][b];
+        }
+        // compute_word_diffs: sum of squared byte differences of the two read channels, its inverse, the flag
+#pragma unroll
+        for (int b = 0; b < 4; b++) { Fp x = Fp::from_canonical(val[0][b]) - Fp::from_canonical(val[1][b]); diff += x * x; }
+    } else {
+        // pad_to_power_of_two: STOP rows continuing the clock
+        const TgCpuOp o = ops[n - 1];
+        r[cpu::PC] = o.pc; r[cpu::FP] = o.fp % vg::P; r[cpu::CLK] = (uint32_t)(((n - 1) % vg::P + (i - n + 1) % vg::P) % vg::P);
+        r[cpu::IS_STOP] = 1; r[cpu::OPCODE] = OP_STOP;
+    }
+#pragma unroll
+    for (int c = 0; c < cpu::NUM_COLS; c++)
+        if (c != cpu::DIFF && c != cpu::DIFF_INV && c != cpu::NOT_EQUAL) put(t, c, i, r[c]);
+    put_raw(t, cpu::DIFF, i, diff);
+    put_raw(t, cpu::DIFF_INV, i, diff.inv());  // 0 -> 0
+    put(t, cpu::NOT_EQUAL, i, diff.is_zero() ? 0u : 1u);
+}
+
+// ---- memory ----------------------------------------------------------------------------------------------
+__global__ void k_tg_mem_keys(const TgMemOp* __restrict__ mem, uint64_t n, uint32_t* keys, uint32_t* idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = mem[i].addr; idx[i] = (uint32_t)i; }
+}
+__global__ void __launch_bounds__(256) k_tracegen_mem(const TgMemOp* __restrict__ mem, const uint32_t* __restrict__ order, uint64_t n, DMatView t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.height) return;
+    uint32_t r[mem::NUM_COLS];
+#pragma unroll
+    for (int c = 0; c < mem::NUM_COLS; c++) r[c] = 0;
+    if (i < n) {
+        const TgMemOp m = mem[order[i]];
+        r[mem::CLK] = m.clk; r[mem::COUNTER] = (uint32_t)i; r[mem::ADDR] = m.addr % vg::P;
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[mem::VALUE + b] = byte_of(m.value, b);
+        r[mem::IS_WRITE] = m.is_write ? 1 : 0; r[mem::IS_READ] = m.is_write ? 0 : 1;
+    }
+#pragma unroll
+    for (int c = 0; c < mem::NUM_COLS; c++) put(t, c, i, r[c]);
+}
+
+// ---- 32-bit ALU chips -----------------------------------------------------------------------------------
+template <int CHIP> __global__ void __launch_bounds__(256) k_tracegen_alu(const TgAluOp* __restrict__ ops, uint64_t n, DMatView t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.height) return;
+    constexpr int W = CHIP == CHIP_ADD ? (int)add::NUM_COLS : CHIP == CHIP_SUB ? (int)sub::NUM_COLS : CHIP == CHIP_LT ? (int)lt::NUM_COLS : (int)bitwise::NUM_COLS;
+    uint32_t r[W];
+#pragma unroll
+    for (int c = 0; c < W; c++) r[c] = 0;
+    Fp lt_diff_inv = Fp::zero();
+    if (i < n) {
+        const TgAluOp op = ops[i];
+        uint32_t a[4], b[4], c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = byte_of(op.a, k); b[k] = byte_of(op.b, k); c[k] = byte_of(op.c, k); }
+        if (CHIP == CHIP_ADD) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { r[add::INPUT_1 + k] = b[k]; r[add::INPUT_2 + k] = c[k]; r[add::OUTPUT + k] = a[k]; }
+            const uint32_t c1 = b[3] + c[3] > 255 ? 1 : 0, c2 = b[2] + c[2] + c1 > 255 ? 1 : 0, c3 = b[1] + c[1] + c2 > 255 ? 1 : 0;
+            r[add::CARRY] = c1; r[add::CARRY + 1] = c2; r[add::CARRY + 2] = c3;
+            r[add::IS_REAL] = 1;
+        } else if (CHIP == CHIP_SUB) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { r[sub::INPUT_1 + k] = b[k]; r[sub::INPUT_2 + k] = c[k]; r[sub::OUTPUT + k] = a[k]; }
+            r[sub::BORROW] = b[3] < c[3]; r[sub::BORROW + 1] = b[2] < c[2]; r[sub::BORROW + 2] = b[1] < c[1];  // witness as written (sub/mod.rs:104-112)
+            r[sub::IS_REAL] = 1;
+        } else if (CHIP == CHIP_LT) {
+            const bool is_signed = op.opcode == OP_SLT32 || op.opcode == OP_SLE32;
+            r[lt::IS_LT] = op.opcode == OP_LT32; r[lt::IS_LTE] = op.opcode == OP_LTE32; r[lt::IS_SLT] = op.opcode == OP_SLT32; r[lt::IS_SLE] = op.opcode == OP_SLE32;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { r[lt::INPUT_1 + k] = b[k]; r[lt::INPUT_2 + k] = c[k]; }
+            r[lt::OUTPUT] = a[3];
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (!found && b[k] != c[k]) {
+                    found = true;
+                    const uint32_t z = 256u + b[k] - c[k];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) r[lt::BITS + j] = (z >> j) & 1;
+                    r[lt::BYTE_FLAG + k] = 1;
+                    lt_diff_inv = (Fp::from_canonical(b[k]) - Fp::from_canonical(c[k])).inv();
+                }
+#pragma unroll
+            for (int j = 0; j < 8; j++) { r[lt::TOP_BITS_1 + j] = (b[0] >> j) & 1; r[lt::TOP_BITS_2 + j] = (c[0] >> j) & 1; }
+            r[lt::DIFFERENT_SIGNS] = (is_signed && ((b[0] >> 7) != (c[0] >> 7))) ? 1 : 0;
+            r[lt::MULTIPLICITY] = 1;
+        } else {
+            r[bitwise::IS_AND] = op.opcode == OP_AND32; r[bitwise::IS_OR] = op.opcode == OP_OR32; r[bitwise::IS_XOR] = op.opcode == OP_XOR32;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                r[bitwise::INPUT_1 + k] = b[k]; r[bitwise::INPUT_2 + k] = c[k]; r[bitwise::OUTPUT + k] = a[k];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { r[bitwise::BITS_1 + 8 * k + j] = (b[k] >> j) & 1; r[bitwise::BITS_2 + 8 * k + j] = (c[k] >> j) & 1; }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < W; c++)
+        if (!(CHIP == CHIP_LT && c == lt::DIFF_INV)) put(t, c, i, r[c]);
+    if (CHIP == CHIP_LT) put_raw(t, lt::DIFF_INV, i, lt_diff_inv);
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------
+static unsigned blocks_for(uint64_t rows) { return (unsigned)((rows + 255) / 256); }
+
+void launch_tracegen_cpu(hipStream_t st, const TgCpuOp* ops, uint64_t n, const TgMemOp* mem, uint64_t n_mem, DMatView t) {
+    ProfScope ps("k_tracegen_cpu", st, 48.0 * n + 16.0 * n_mem + 4.0 * t.height * t.width);
+    hipLaunchKernelGGL(k_tracegen_cpu, dim3(blocks_for(t.height)), dim3(256), 0, st, ops, n, mem, n_mem, t);
+}
+
+size_t tracegen_mem_sort_scratch_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+// keys/idx: 2 x n words each (in, out); sort_tmp: tracegen_mem_sort_scratch_bytes(n)
+hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, uint32_t* keys2, uint32_t* idx2, void* sort_tmp, size_t sort_tmp_bytes, DMatView t) {
+    {
+        ProfScope ps("k_tracegen_mem_sort", st, 16.0 * n + 4.0 * 8.0 * n);
+        hipLaunchKernelGGL(k_tg_mem_keys, dim3(blocks_for(n)), dim3(256), 0, st, mem, n, keys2, idx2);
+        hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, (const uint32_t*)keys2, keys2 + n, (const uint32_t*)idx2, idx2 + n, (size_t)n, 0, 32, st);
+        if (e != hipSuccess) return e;
+    }
+    ProfScope ps("k_tracegen_mem", st, 20.0 * n + 4.0 * t.height * t.width);
+    hipLaunchKernelGGL(k_tracegen_mem, dim3(blocks_for(t.height)), dim3(256), 0, st, mem, (const uint32_t*)(idx2 + n), n, t);
+    return hipSuccess;
+}
+
+void launch_tracegen_alu(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t) {
+    ProfScope ps("k_tracegen_alu", st, 16.0 * n + 4.0 * t.height * t.width);
+    const dim3 g(blocks_for(t.height)), b(256);
+    switch (chip) {
+        case CHIP_ADD: hipLaunchKernelGGL(k_tracegen_alu<CHIP_ADD>, g, b, 0, st, ops, n, t); break;
+        case CHIP_SUB: hipLaunchKernelGGL(k_tracegen_alu<CHIP_SUB>, g, b, 0, st, ops, n, t); break;
+        case CHIP_LT: hipLaunchKernelGGL(k_tracegen_alu<CHIP_LT>, g, b, 0, st, ops, n, t); break;
+        default: hipLaunchKernelGGL(k_tracegen_alu<CHIP_BITWISE>, g, b, 0, st, ops, n, t); break;
+    }
+}
+
+}  // namespace vk
