@@ -198,6 +198,10 @@ typedef struct vgpu_workload vgpu_workload_t;
 int32_t vgpu_workload_fib(uint32_t n, vgpu_workload_t** out);
 /* ALU-heavy loop (SURVEY.md §8 workload C4): add, sub, xor, and, or, lt, addi, addi, bne per iteration */
 int32_t vgpu_workload_alu(uint32_t iters, vgpu_workload_t** out);
+/* the reference's other pinned prover programs (basic/tests/test_prover.rs:190-402): "left_imm_ops", "signed_inequality", "loadfp" */
+int32_t vgpu_workload_named(const char* name, vgpu_workload_t** out);
+/* final value of the 32-bit memory cell at `addr` (machine.mem().cells, test_prover.rs:483-486,494-640) */
+int32_t vgpu_workload_cell(const vgpu_workload_t* w, uint32_t addr, uint32_t* value);
 void vgpu_workload_free(vgpu_workload_t* w);
 /* stats: [cycles, cpu ops, memory ops, add ops, result word (u32 at fp+4), program length, padded cpu height] */
 void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]);

@@ -18,8 +18,9 @@ from oracle import pyoracle as po  # noqa: E402
 
 
 def make(n, name):
+    """n: Fibonacci loop bound, or the name of one of the reference's other pinned programs / ("alu", iters)."""
     rc = va.poseidon_round_constants()
-    w = va.Workload.fib(n)
+    w = va.Workload.fib(n) if isinstance(n, int) else va.Workload.alu(n[1]) if isinstance(n, tuple) else va.Workload.named(n)
     mt, prep = w.main_traces(), w.preprocessed()
     res = po.prove_basic(mt, prep[0][1], prep[1][1], rc, debug_check=True)
     assert po.verify_basic(prep[0][1], prep[1][1], res.words, rc) is None
@@ -41,3 +42,6 @@ def make(n, name):
 if __name__ == "__main__":
     make(25, "fib25_oracle.json")
     make(582, "fib582_oracle.json")
+    for prog in ("left_imm_ops", "signed_inequality", "loadfp"):  # basic/tests/test_prover.rs:190-402
+        make(prog, prog + "_oracle.json")
+    make(("alu", 100), "alu100_oracle.json")

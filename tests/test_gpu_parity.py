@@ -137,7 +137,8 @@ def test_fib_medium_proof_bytes(prover, rc):
     assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc) is None
 
 
-@pytest.mark.parametrize("name", ["fib25_oracle.json", "fib582_oracle.json"])
+@pytest.mark.parametrize("name", ["fib25_oracle.json", "fib582_oracle.json", "left_imm_ops_oracle.json", "signed_inequality_oracle.json",
+                                  "loadfp_oracle.json", "alu100_oracle.json"])
 def test_gpu_proof_matches_committed_golden_fixture(prover, name):
     import hashlib
     import json
@@ -145,7 +146,8 @@ def test_gpu_proof_matches_committed_golden_fixture(prover, name):
 
     with open(os.path.join(os.path.dirname(__file__), "golden", name)) as f:
         g = json.load(f)
-    w = va.Workload.fib(g["n"])
+    n = g["n"]
+    w = va.Workload.fib(n) if isinstance(n, int) else va.Workload.alu(n[1]) if isinstance(n, list) else va.Workload.named(n)
     mt, prep = w.main_traces(), w.preprocessed()
     assert hashlib.sha256(b"".join(m.tobytes() for m in mt)).hexdigest() == g["traces_sha256"]
     proof = prover.prove([prover.upload(m) for m in mt], [(c, prover.upload(m)) for c, m in prep])
@@ -305,3 +307,20 @@ def test_generated_traces_full_size(prover, rc):
     a = prover.prove([gen[i] if i in gen else prover.upload(mt[i]) for i in range(va.NUM_CHIPS)], dprep)
     b = prover.prove([prover.upload(m) for m in mt], dprep)
     assert a.bytes() == b.bytes()
+
+
+# ---- the reference's other pinned prover programs (basic/tests/test_prover.rs:190-402, asserted :489-640) ---------
+@pytest.mark.parametrize("name", ["left_imm_ops", "signed_inequality", "loadfp"])
+@pytest.mark.parametrize("interpret", [False, True])
+def test_reference_test_programs_proof_bytes(machine, rc, name, interpret):
+    p = va.Prover(machine, rc, interpret_air=interpret)
+    w = va.Workload.named(name)
+    proof, ref, prep = _prove_both(p, w, rc)
+    for chip in range(va.NUM_CHIPS):
+        assert first_mismatch(proof.debug_perm_trace(chip), ref.perm_trace(chip)) is None, "perm trace of chip %d" % chip
+        assert first_mismatch(proof.debug_quotient(chip), ref.quotient(chip)) is None, "quotient chunks of chip %d (%s)" % (chip, va.CHIP_NAMES[chip])
+    assert first_mismatch(proof.words, ref.words) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc) is None
+    log = p.upload_oplog(w.oplog())
+    for chip in va.GENERATED_CHIPS:
+        assert first_mismatch(p.generate_trace(log, chip).download(), w.main_trace(chip)) is None, va.CHIP_NAMES[chip]

@@ -128,6 +128,18 @@ class Workload:
         _check(lib().vgpu_workload_alu(ctypes.c_uint32(iters), ctypes.byref(h)))
         return cls(h)
 
+    @classmethod
+    def named(cls, name):
+        """One of the reference's other pinned prover programs: left_imm_ops, signed_inequality, loadfp."""
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_workload_named(name.encode(), ctypes.byref(h)))
+        return cls(h)
+
+    def cell(self, addr):
+        v = ctypes.c_uint32()
+        _check(lib().vgpu_workload_cell(self._h, ctypes.c_uint32(addr), ctypes.byref(v)))
+        return int(v.value)
+
     def main_trace(self, chip):
         data, h, w = c_u32p(), ctypes.c_uint64(), ctypes.c_uint64()
         _check(lib().vgpu_workload_main_trace(self._h, ctypes.c_uint32(chip), ctypes.byref(data), ctypes.byref(h), ctypes.byref(w)))

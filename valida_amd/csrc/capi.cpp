@@ -416,6 +416,33 @@ static void fill_logs(vgpu_workload& w) {
         for (size_t i = 0; i < src[k]->size(); i++) { const auto& a = (*src[k])[i]; w.log_alu[k][i] = {a.opcode, vwork::u32_of(a.a), vwork::u32_of(a.b), vwork::u32_of(a.c)}; }
     }
 }
+int32_t vgpu_workload_named(const char* name, vgpu_workload_t** out) {
+    VG_TRY({
+        if (!out || !name) throw std::invalid_argument("bad argument");
+        std::string n(name);
+        std::vector<vwork::InstructionWord> prog;
+        if (n == "left_imm_ops") prog = vwork::left_imm_ops_program();
+        else if (n == "signed_inequality") prog = vwork::signed_inequality_program();
+        else if (n == "loadfp") prog = vwork::loadfp_program();
+        else throw std::invalid_argument("unknown program: " + n);
+        auto w = std::make_unique<vgpu_workload>();
+        w->vm.reset(new vwork::BasicVm(prog));
+        w->vm->run();
+        w->main = w->vm->main_traces();
+        w->prep_program = w->vm->program_preprocessed();
+        w->prep_range = vwork::BasicVm::range_preprocessed();
+        fill_logs(*w);
+        *out = w.release();
+    })
+}
+int32_t vgpu_workload_cell(const vgpu_workload_t* w, uint32_t addr, uint32_t* value) {
+    VG_TRY({
+        if (!w || !value) throw std::invalid_argument("bad argument");
+        auto it = w->vm->cells.find(addr);
+        if (it == w->vm->cells.end()) throw std::invalid_argument("memory cell never written");
+        *value = it->second;
+    })
+}
 void vgpu_workload_oplog(const vgpu_workload_t* w, vgpu_oplog_desc_t* out) {
     out->cpu = w->log_cpu.data(); out->n_cpu = w->log_cpu.size();
     out->mem = w->log_mem.data(); out->n_mem = w->log_mem.size();

@@ -460,4 +460,29 @@ inline std::vector<InstructionWord> alu_program(uint32_t iters) {
     };
 }
 
+// The reference's other pinned prover programs (basic/tests/test_prover.rs:190-402): each is proved and verified
+// there, and the listed memory cells are asserted (:489-640).
+inline std::vector<InstructionWord> left_imm_ops_program() {  // test_prover.rs:190-262
+    return {
+        {OP_IMM32, {-4, 0, 0, 0, 3}},    {OP_IMM32, {-8, 0, 0, 1, 0}},
+        {OP_LT32, {4, 3, -4, 1, 0}},     {OP_LTE32, {8, 3, -4, 1, 0}},    {OP_LT32, {12, 4, -4, 1, 0}},  {OP_LTE32, {16, 4, -4, 1, 0}},
+        {OP_LT32, {20, 2, -4, 1, 0}},    {OP_LTE32, {24, 2, -4, 1, 0}},   {OP_LT32, {28, 256, -4, 1, 0}}, {OP_LTE32, {32, 256, -4, 1, 0}},
+        {OP_LT32, {36, 3, -8, 1, 0}},    {OP_LTE32, {40, 3, -8, 1, 0}},   {OP_STOP, {0, 0, 0, 0, 0}},
+    };
+}
+inline std::vector<InstructionWord> signed_inequality_program() {  // test_prover.rs:264-379
+    std::vector<InstructionWord> p = {
+        {OP_IMM32, {-4, 0, 0, 0, 1}}, {OP_IMM32, {-8, 255, 255, 255, 255}}, {OP_IMM32, {-12, 255, 255, 255, 254}},
+    };
+    const int32_t ops[8][5] = {{4, -12, -8, 0, 0}, {8, -12, -4, 0, 0}, {12, -4, -1, 0, 1}, {16, -1, -8, 1, 0},
+                               {20, -1, -8, 1, 0}, {24, -1, -12, 1, 0}, {28, -8, -12, 0, 0}, {32, -8, -4, 0, 0}};
+    for (int i = 0; i < 8; i++) p.push_back({i == 4 ? OP_SLE32 : OP_SLT32, {ops[i][0], ops[i][1], ops[i][2], ops[i][3], ops[i][4]}});
+    for (int i = 0; i < 8; i++) p.push_back({i == 4 ? OP_LTE32 : OP_LT32, {ops[i][0] + 32, ops[i][1], ops[i][2], ops[i][3], ops[i][4]}});
+    p.push_back({OP_STOP, {0, 0, 0, 0, 0}});
+    return p;
+}
+inline std::vector<InstructionWord> loadfp_program() {  // test_prover.rs:381-402
+    return {{OP_LOADFP, {4, 0, 0, 0, 0}}, {OP_LOADFP, {8, 3, 0, 0, 0}}, {OP_STOP, {0, 0, 0, 0, 0}}};
+}
+
 }  // namespace vwork
