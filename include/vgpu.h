@@ -181,6 +181,7 @@ typedef struct vgpu_oplog_desc {
     const vgpu_cpu_op_t* cpu; uint64_t n_cpu;
     const vgpu_mem_op_t* mem; uint64_t n_mem;
     const vgpu_alu_op_t* alu[4]; uint64_t n_alu[4];   /* add, sub, lt, bitwise */
+    const uint32_t* static_cells; uint64_t n_static;  /* MemoryChip::static_data as (addr, value) pairs, ascending address (may be null / 0) */
 } vgpu_oplog_desc_t;
 typedef struct vgpu_oplog vgpu_oplog_t;
 int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_oplog_t** out);
@@ -198,7 +199,8 @@ typedef struct vgpu_workload vgpu_workload_t;
 int32_t vgpu_workload_fib(uint32_t n, vgpu_workload_t** out);
 /* ALU-heavy loop (SURVEY.md §8 workload C4): add, sub, xor, and, or, lt, addi, addi, bne per iteration */
 int32_t vgpu_workload_alu(uint32_t iters, vgpu_workload_t** out);
-/* the reference's other pinned prover programs (basic/tests/test_prover.rs:190-402): "left_imm_ops", "signed_inequality", "loadfp" */
+/* the reference's other pinned prover programs (basic/tests/test_prover.rs:190-402): "left_imm_ops", "signed_inequality", "loadfp",
+ * and "static_data" (basic/tests/test_static_data.rs:31-59, cells 0x10 / 0x14 initialised through the static-data chip) */
 int32_t vgpu_workload_named(const char* name, vgpu_workload_t** out);
 /* final value of the 32-bit memory cell at `addr` (machine.mem().cells, test_prover.rs:483-486,494-640) */
 int32_t vgpu_workload_cell(const vgpu_workload_t* w, uint32_t addr, uint32_t* value);

@@ -42,6 +42,6 @@ def make(n, name):
 if __name__ == "__main__":
     make(25, "fib25_oracle.json")
     make(582, "fib582_oracle.json")
-    for prog in ("left_imm_ops", "signed_inequality", "loadfp"):  # basic/tests/test_prover.rs:190-402
+    for prog in ("left_imm_ops", "signed_inequality", "loadfp", "static_data"):  # basic/tests/test_prover.rs:190-402, test_static_data.rs:31-59
         make(prog, prog + "_oracle.json")
     make(("alu", 100), "alu100_oracle.json")

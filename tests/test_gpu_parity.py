@@ -138,7 +138,7 @@ def test_fib_medium_proof_bytes(prover, rc):
 
 
 @pytest.mark.parametrize("name", ["fib25_oracle.json", "fib582_oracle.json", "left_imm_ops_oracle.json", "signed_inequality_oracle.json",
-                                  "loadfp_oracle.json", "alu100_oracle.json"])
+                                  "loadfp_oracle.json", "static_data_oracle.json", "alu100_oracle.json"])
 def test_gpu_proof_matches_committed_golden_fixture(prover, name):
     import hashlib
     import json
@@ -310,7 +310,7 @@ def test_generated_traces_full_size(prover, rc):
 
 
 # ---- the reference's other pinned prover programs (basic/tests/test_prover.rs:190-402, asserted :489-640) ---------
-@pytest.mark.parametrize("name", ["left_imm_ops", "signed_inequality", "loadfp"])
+@pytest.mark.parametrize("name", ["left_imm_ops", "signed_inequality", "loadfp", "static_data"])
 @pytest.mark.parametrize("interpret", [False, True])
 def test_reference_test_programs_proof_bytes(machine, rc, name, interpret):
     p = va.Prover(machine, rc, interpret_air=interpret)

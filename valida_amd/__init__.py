@@ -100,6 +100,7 @@ class OplogDesc(ctypes.Structure):  # vgpu_oplog_desc_t
         ("cpu", ctypes.c_void_p), ("n_cpu", ctypes.c_uint64),
         ("mem", ctypes.c_void_p), ("n_mem", ctypes.c_uint64),
         ("alu", ctypes.c_void_p * 4), ("n_alu", ctypes.c_uint64 * 4),
+        ("static_cells", ctypes.c_void_p), ("n_static", ctypes.c_uint64),
     ]
 
 
@@ -355,7 +356,7 @@ class Prover:
     def upload_oplog(self, desc):
         h = ctypes.c_void_p()
         _check(lib().vgpu_oplog_upload(self._h, ctypes.byref(desc), ctypes.byref(h)))
-        nbytes = 48 * desc.n_cpu + 16 * desc.n_mem + 16 * sum(desc.n_alu)
+        nbytes = 48 * desc.n_cpu + 16 * desc.n_mem + 16 * sum(desc.n_alu) + 8 * desc.n_static
         log = DeviceOplog(self, h, int(nbytes))
         log._desc = desc
         return log

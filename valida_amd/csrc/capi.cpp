@@ -35,6 +35,7 @@ struct vgpu_workload {
     std::vector<vgpu_cpu_op_t> log_cpu;
     std::vector<vgpu_mem_op_t> log_mem;
     std::vector<vgpu_alu_op_t> log_alu[4];
+    std::vector<uint32_t> log_static;  // (addr, value) pairs, ascending address
     std::unique_ptr<vwork::BasicVm> vm;
     std::vector<vwork::RowMajor> main;
     vwork::RowMajor prep_program, prep_range;
@@ -216,6 +217,9 @@ int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_o
         h.cpu = (const vk::TgCpuOp*)log->cpu; h.n_cpu = log->n_cpu;
         h.mem = (const vk::TgMemOp*)log->mem; h.n_mem = log->n_mem;
         for (int k = 0; k < 4; k++) { h.alu[k] = (const vk::TgAluOp*)log->alu[k]; h.n_alu[k] = log->n_alu[k]; }
+        h.static_cells = log->static_cells; h.n_static = log->n_static;
+        for (uint64_t i = 1; i < h.n_static; i++)
+            if (log->static_cells[2 * i] <= log->static_cells[2 * i - 2]) throw std::invalid_argument("oplog: static cells must be in ascending address order");
         for (uint64_t i = 0; i < h.n_cpu; i++)
             if (log->cpu[i].mem_first > h.n_mem || (i && log->cpu[i].mem_first < log->cpu[i - 1].mem_first) || log->cpu[i].kind > VGPU_CPU_LOADFP)
                 throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + " is malformed");
@@ -410,6 +414,7 @@ static void fill_logs(vgpu_workload& w) {
     }
     w.log_mem.resize(vm.mem_ops.size());
     for (size_t i = 0; i < vm.mem_ops.size(); i++) w.log_mem[i] = {vm.mem_ops[i].clk, vm.mem_ops[i].addr, vwork::u32_of(vm.mem_ops[i].value), vm.mem_ops[i].is_write ? 1u : 0u};
+    for (auto& kv : vm.static_cells) { w.log_static.push_back(kv.first); w.log_static.push_back(vwork::u32_of(kv.second)); }
     const std::vector<vwork::AluOp>* src[4] = {&vm.add_ops, &vm.sub_ops, &vm.lt_ops, &vm.bitwise_ops};
     for (int k = 0; k < 4; k++) {
         w.log_alu[k].resize(src[k]->size());
@@ -424,9 +429,14 @@ int32_t vgpu_workload_named(const char* name, vgpu_workload_t** out) {
         if (n == "left_imm_ops") prog = vwork::left_imm_ops_program();
         else if (n == "signed_inequality") prog = vwork::signed_inequality_program();
         else if (n == "loadfp") prog = vwork::loadfp_program();
+        else if (n == "static_data") prog = vwork::static_data_program();
         else throw std::invalid_argument("unknown program: " + n);
         auto w = std::make_unique<vgpu_workload>();
         w->vm.reset(new vwork::BasicVm(prog));
+        if (n == "static_data") {  // basic/tests/test_static_data.rs:57-58
+            w->vm->write_static(0x10, vwork::Word{{0, 0, 0, 0x25}});
+            w->vm->write_static(0x14, vwork::Word{{0, 0, 0, 0x32}});
+        }
         w->vm->run();
         w->main = w->vm->main_traces();
         w->prep_program = w->vm->program_preprocessed();
@@ -447,6 +457,7 @@ void vgpu_workload_oplog(const vgpu_workload_t* w, vgpu_oplog_desc_t* out) {
     out->cpu = w->log_cpu.data(); out->n_cpu = w->log_cpu.size();
     out->mem = w->log_mem.data(); out->n_mem = w->log_mem.size();
     for (int k = 0; k < 4; k++) { out->alu[k] = w->log_alu[k].data(); out->n_alu[k] = w->log_alu[k].size(); }
+    out->static_cells = w->log_static.data(); out->n_static = w->log_static.size() / 2;
 }
 void vgpu_workload_free(vgpu_workload_t* w) { delete w; }
 void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]) {

@@ -86,6 +86,8 @@ std::unique_ptr<DeviceOplog> Prover::upload_oplog(const HostOplog& log) {
     d->cpu = upload_bytes(c, log.cpu, log.n_cpu * sizeof(vk::TgCpuOp));
     d->mem = upload_bytes(c, log.mem, log.n_mem * sizeof(vk::TgMemOp));
     for (int k = 0; k < 4; k++) { d->n_alu[k] = log.n_alu[k]; d->alu[k] = upload_bytes(c, log.alu[k], log.n_alu[k] * sizeof(vk::TgAluOp)); }
+    d->n_static = log.n_static;
+    d->static_cells = upload_bytes(c, log.static_cells, log.n_static * 8);
     c.sync();
     return d;
 }
@@ -107,13 +109,13 @@ std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int 
         t->nat = DMat(&c, t->height, t->width);
         vk::launch_tracegen_cpu(c.stream, (const vk::TgCpuOp*)log.cpu.data, log.n_cpu, (const vk::TgMemOp*)log.mem.data, log.n_mem, t->nat.view());
     } else if (chip == CHIP_MEM) {
-        t->height = next_pow2(log.n_mem);  // 0 operations -> one zero row
+        t->height = next_pow2(log.n_static + log.n_mem);  // static rows first; 0 rows -> one zero row
         t->nat = DMat(&c, t->height, t->width);
         const uint64_t n = log.n_mem;
         const size_t tmp_bytes = vk::tracegen_mem_sort_scratch_bytes(n ? n : 1);
         DBuf keys(&c, 2 * n + 4), idx(&c, 2 * n + 4), tmp(&c, tmp_bytes / 4 + 4);
-        if (n) VG_HIP_CHECK(vk::launch_tracegen_mem(c.stream, (const vk::TgMemOp*)log.mem.data, n, keys.data, idx.data, tmp.data, tmp_bytes, t->nat.view()));
-        else VG_HIP_CHECK(hipMemsetAsync(t->nat.data, 0, t->height * t->width * 4, c.stream));
+        VG_HIP_CHECK(vk::launch_tracegen_mem(c.stream, (const vk::TgMemOp*)log.mem.data, n, log.static_cells.data, log.n_static, keys.data, idx.data, tmp.data,
+                                             tmp_bytes, t->nat.view()));
         c.sync();  // scratch buffers go back to the pool
     } else {
         const int k = chip == CHIP_ADD ? 0 : chip == CHIP_SUB ? 1 : chip == CHIP_LT ? 2 : 3;

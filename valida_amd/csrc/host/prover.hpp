@@ -33,10 +33,11 @@ struct HostOplog {
     const vk::TgCpuOp* cpu = nullptr; uint64_t n_cpu = 0;
     const vk::TgMemOp* mem = nullptr; uint64_t n_mem = 0;
     const vk::TgAluOp* alu[4] = {nullptr, nullptr, nullptr, nullptr}; uint64_t n_alu[4] = {0, 0, 0, 0};  // add, sub, lt, bitwise
+    const uint32_t* static_cells = nullptr; uint64_t n_static = 0;  // MemoryChip::static_data: (addr, value) pairs, ascending address
 };
 struct DeviceOplog {
-    DBuf cpu, mem, alu[4];
-    uint64_t n_cpu = 0, n_mem = 0, n_alu[4] = {0, 0, 0, 0};
+    DBuf cpu, mem, alu[4], static_cells;
+    uint64_t n_cpu = 0, n_mem = 0, n_alu[4] = {0, 0, 0, 0}, n_static = 0;
 };
 
 struct PhaseTimes {  // milliseconds, host clock around stream syncs

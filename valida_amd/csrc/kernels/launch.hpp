@@ -61,7 +61,8 @@ enum { TG_CPU_STORE32 = 0, TG_CPU_LOAD32, TG_CPU_JAL, TG_CPU_JALV, TG_CPU_BEQ, T
        TG_CPU_LOADFP };
 void launch_tracegen_cpu(hipStream_t st, const TgCpuOp* ops, uint64_t n, const TgMemOp* mem, uint64_t n_mem, DMatView t);
 size_t tracegen_mem_sort_scratch_bytes(uint64_t n);
-hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, uint32_t* keys2, uint32_t* idx2, void* sort_tmp, size_t sort_tmp_bytes, DMatView t);
+hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, const uint32_t* static_cells, uint64_t n_static, uint32_t* keys2, uint32_t* idx2,
+                               void* sort_tmp, size_t sort_tmp_bytes, DMatView t);
 void launch_tracegen_alu(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t);
 // open.hip
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w);

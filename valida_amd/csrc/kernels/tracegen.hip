@@ -98,14 +98,20 @@ __global__ void k_tg_mem_keys(const TgMemOp* __restrict__ mem, uint64_t n, uint3
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { keys[i] = mem[i].addr; idx[i] = (uint32_t)i; }
 }
-__global__ void __launch_bounds__(256) k_tracegen_mem(const TgMemOp* __restrict__ mem, const uint32_t* __restrict__ order, uint64_t n, DMatView t) {
+__global__ void __launch_bounds__(256) k_tracegen_mem(const TgMemOp* __restrict__ mem, const uint32_t* __restrict__ order, uint64_t n,
+                                                      const uint32_t* __restrict__ static_cells, uint64_t n_static, DMatView t) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.height) return;
     uint32_t r[mem::NUM_COLS];
 #pragma unroll
     for (int c = 0; c < mem::NUM_COLS; c++) r[c] = 0;
-    if (i < n) {
-        const TgMemOp m = mem[order[i]];
+    if (i < n_static) {  // static_data_to_row (memory/src/lib.rs:265-284): the statically initialised cells come first
+        const uint32_t addr = static_cells[2 * i], value = static_cells[2 * i + 1];
+        r[mem::IS_STATIC_INITIAL] = 1; r[mem::COUNTER] = (uint32_t)i; r[mem::ADDR] = addr % vg::P; r[mem::IS_WRITE] = 1;
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[mem::VALUE + b] = byte_of(value, b);
+    } else if (i < n_static + n) {
+        const TgMemOp m = mem[order[i - n_static]];
         r[mem::CLK] = m.clk; r[mem::COUNTER] = (uint32_t)i; r[mem::ADDR] = m.addr % vg::P;
 #pragma unroll
         for (int b = 0; b < 4; b++) r[mem::VALUE + b] = byte_of(m.value, b);
@@ -192,15 +198,16 @@ size_t tracegen_mem_sort_scratch_bytes(uint64_t n) {
 }
 
 // keys/idx: 2 x n words each (in, out); sort_tmp: tracegen_mem_sort_scratch_bytes(n)
-hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, uint32_t* keys2, uint32_t* idx2, void* sort_tmp, size_t sort_tmp_bytes, DMatView t) {
-    {
+hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, const uint32_t* static_cells, uint64_t n_static, uint32_t* keys2, uint32_t* idx2,
+                               void* sort_tmp, size_t sort_tmp_bytes, DMatView t) {
+    if (n) {
         ProfScope ps("k_tracegen_mem_sort", st, 16.0 * n + 4.0 * 8.0 * n);
         hipLaunchKernelGGL(k_tg_mem_keys, dim3(blocks_for(n)), dim3(256), 0, st, mem, n, keys2, idx2);
         hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, (const uint32_t*)keys2, keys2 + n, (const uint32_t*)idx2, idx2 + n, (size_t)n, 0, 32, st);
         if (e != hipSuccess) return e;
     }
     ProfScope ps("k_tracegen_mem", st, 20.0 * n + 4.0 * t.height * t.width);
-    hipLaunchKernelGGL(k_tracegen_mem, dim3(blocks_for(t.height)), dim3(256), 0, st, mem, (const uint32_t*)(idx2 + n), n, t);
+    hipLaunchKernelGGL(k_tracegen_mem, dim3(blocks_for(t.height)), dim3(256), 0, st, mem, (const uint32_t*)(idx2 + n), n, static_cells, n_static, t);
     return hipSuccess;
 }
 

@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <map>
 #include <unordered_map>
 #include <vector>
 #include "../chips/basic_machine.hpp"
@@ -70,6 +71,9 @@ struct BasicVm {
     std::vector<AluOp> add_ops, sub_ops, lt_ops, bitwise_ops;
     std::vector<uint32_t> program_counts;
     uint32_t range_counts[256] = {0};
+    std::map<uint32_t, Word> static_cells;  // StaticDataChip::cells, copied into memory by initialize_memory (static_data/src/lib.rs:28-32)
+    // machine.static_data_mut().write(addr, value) before run (basic/tests/test_static_data.rs:57-58)
+    void write_static(uint32_t addr, Word w) { static_cells[addr] = w; cells[addr] = u32_of(w); }
 
     explicit BasicVm(std::vector<InstructionWord> program, uint32_t initial_fp = 0x1000) : rom(std::move(program)), fp(initial_fp) {
         program_counts.assign(rom.size(), 0);
@@ -273,11 +277,18 @@ struct BasicVm {
     RowMajor mem_trace() const {  // memory/src/lib.rs:143-194 (no static data in these workloads)
         std::vector<MemOp> ops = mem_ops;
         std::stable_sort(ops.begin(), ops.end(), [](const MemOp& a, const MemOp& b) { return a.addr != b.addr ? a.addr < b.addr : a.clk < b.clk; });
-        size_t n = ops.size(), N = next_pow2(n);
+        const size_t n0 = static_cells.size(), n = ops.size(), N = next_pow2(n0 + n);
         RowMajor t(N, mem::NUM_COLS);
+        size_t k = 0;
+        for (auto& kv : static_cells) {  // static_data_to_row (memory/src/lib.rs:265-284), ascending address
+            uint32_t* r = t.row(k);
+            r[mem::IS_STATIC_INITIAL] = 1; r[mem::COUNTER] = (uint32_t)k; r[mem::ADDR] = kv.first % P; r[mem::IS_WRITE] = 1;
+            for (int b = 0; b < 4; b++) r[mem::VALUE + b] = kv.second.b[b];
+            k++;
+        }
         for (size_t i = 0; i < n; i++) {
-            uint32_t* r = t.row(i);
-            r[mem::CLK] = ops[i].clk; r[mem::COUNTER] = (uint32_t)i; r[mem::ADDR] = ops[i].addr % P;
+            uint32_t* r = t.row(n0 + i);
+            r[mem::CLK] = ops[i].clk; r[mem::COUNTER] = (uint32_t)(n0 + i); r[mem::ADDR] = ops[i].addr % P;
             for (int b = 0; b < 4; b++) r[mem::VALUE + b] = ops[i].value.b[b];
             r[ops[i].is_write ? mem::IS_WRITE : mem::IS_READ] = 1;
         }
@@ -355,6 +366,16 @@ struct BasicVm {
         for (size_t i = 0; i < 256; i++) { t.row(i)[range::MULT] = range_counts[i] % P; t.row(i)[range::COUNTER] = (uint32_t)i; }
         return t;
     }
+    RowMajor static_data_trace() const {  // static_data/src/lib.rs:60-79
+        RowMajor t(next_pow2(static_cells.size()), static_data::NUM_COLS);
+        size_t k = 0;
+        for (auto& kv : static_cells) {
+            uint32_t* r = t.row(k++);
+            r[static_data::ADDR] = kv.first % P; r[static_data::IS_REAL] = 1;
+            for (int b = 0; b < 4; b++) r[static_data::VALUE + b] = kv.second.b[b];
+        }
+        return t;
+    }
     RowMajor program_trace() const {
         RowMajor t(next_pow2(program_counts.size()), program::NUM_COLS);
         for (size_t i = 0; i < program_counts.size(); i++) t.row(i)[0] = program_counts[i] % P;
@@ -390,7 +411,7 @@ struct BasicVm {
         out[CHIP_BITWISE] = bitwise_trace();
         out[CHIP_OUTPUT] = RowMajor(1, output::NUM_COLS);
         out[CHIP_RANGE] = range_trace();
-        out[CHIP_STATIC_DATA] = RowMajor(1, static_data::NUM_COLS);
+        out[CHIP_STATIC_DATA] = static_data_trace();
         return out;
     }
 };
@@ -480,6 +501,11 @@ inline std::vector<InstructionWord> signed_inequality_program() {  // test_prove
     for (int i = 0; i < 8; i++) p.push_back({i == 4 ? OP_LTE32 : OP_LT32, {ops[i][0] + 32, ops[i][1], ops[i][2], ops[i][3], ops[i][4]}});
     p.push_back({OP_STOP, {0, 0, 0, 0, 0}});
     return p;
+}
+// basic/tests/test_static_data.rs:31-59: loops until the statically initialised cell 0x10 holds 0x25 (cells 0x10 -> 0x25
+// and 0x14 -> 0x32 are written through the static-data chip before the run)
+inline std::vector<InstructionWord> static_data_program() {
+    return {{OP_IMM32, {0, 0, 0, 0, 0x10}}, {OP_LOAD32, {-4, 0, 0, 0, 0}}, {OP_BNE, {0, -4, 0x25, 0, 1}}, {OP_STOP, {0, 0, 0, 0, 0}}};
 }
 inline std::vector<InstructionWord> loadfp_program() {  // test_prover.rs:381-402
     return {{OP_LOADFP, {4, 0, 0, 0, 0}}, {OP_LOADFP, {8, 3, 0, 0, 0}}, {OP_STOP, {0, 0, 0, 0, 0}}};
