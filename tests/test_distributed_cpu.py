@@ -28,6 +28,10 @@ def _worker(rank, world, port, q):
     prep = w.preprocessed()
     res = po.prove_basic(w.main_traces(), prep[0][1], prep[1][1], va.poseidon_round_constants(), num_queries=4)
     roots = bench.exchange_roots(dist, torch, res.words[2:26], torch.device("cpu"))
+    # a batch of K proofs per rank travels in the same single collective (bench.run_steps): 24 words per proof
+    batch = bench.exchange_roots(dist, torch, np.concatenate([res.words[2:26], res.words[2:26][::-1]]), torch.device("cpu"))
+    assert tuple(batch.shape) == (world, 48) and batch[rank, :24].tolist() == [int(x) for x in res.words[2:26]]
+    assert batch[:, 24:].tolist() == [r[::-1] for r in roots.numpy().tolist()]
     q.put((rank, n, [int(x) for x in res.words[2:26]], roots.numpy().tolist()))
     dist.barrier()
     dist.destroy_process_group()

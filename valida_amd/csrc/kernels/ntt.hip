@@ -131,27 +131,56 @@ __device__ __forceinline__ Fp bit_product(const uint32_t* table, int base, uint3
     return r;
 }
 
+// w_{2^m}^x and w_{2^m}^{-x} (x < 2^m) from the universal bit-reversed tables: the product over the set bits i of x of
+// w_{2^(m-i)} is domain_point(bitrev_m(x)) — three table lookups and at most two multiplications instead of a pow.
+__device__ __forceinline__ Fp root_pow(const DeviceTables& tb, int m, uint32_t x) { return domain_point(tb, m ? __brev(x) >> (32 - m) : 0u); }
+__device__ __forceinline__ Fp inv_root_pow(const DeviceTables& tb, int m, uint32_t x) { return inv_domain_point(tb, m ? __brev(x) >> (32 - m) : 0u); }
+
 __host__ __device__ inline int padded_words(int n) { return n + (n >> 4); }
 
 // ---- inverse, contiguous pass: persistent blocks over (N / N_lo) x columns tiles ----------------------
 // In place on `data` (column-major, height N = 2^k).  k_lo = min(k, 12) stages on each contiguous block
 // of N_lo points.  If k_hi > 0 multiplies element r of block h by w_N^{-bitrev(h) * r}; else scales by 1/N.
-// Blocks grid-stride over tiles so the compact twiddle tables are staged into LDS once per block.
+// Blocks grid-stride over tiles; the compact twiddle tables (16 KB, shared by every block) are read through L1/L2, which
+// halves the LDS footprint of a block (6 instead of 4 resident blocks per CU).
+// Software pipeline shared by the two contiguous passes: a block's tiles are independent, so the NEXT tile's global
+// loads are issued (into registers) before the butterfly rounds of the current one and land while it computes —
+// otherwise all co-resident blocks, started together and doing identical phases, stall on HBM in lockstep.
+constexpr int CONTIG_MAX_PER_THREAD = 16;  // n_lo / blockDim.x (launcher: blockDim = max(64, n_lo / 16))
+__device__ __forceinline__ void prefetch_tile(uint32_t (&pre)[CONTIG_MAX_PER_THREAD], const uint32_t* __restrict__ src, int n_lo) {
+#pragma unroll
+    for (int u = 0; u < CONTIG_MAX_PER_THREAD; u++) {
+        const int i = threadIdx.x + u * blockDim.x;
+        if (i < n_lo) pre[u] = src[i];
+    }
+}
+__device__ __forceinline__ void commit_tile(const uint32_t (&pre)[CONTIG_MAX_PER_THREAD], uint32_t* lds, int n_lo) {
+#pragma unroll
+    for (int u = 0; u < CONTIG_MAX_PER_THREAD; u++) {
+        const int i = threadIdx.x + u * blockDim.x;
+        if (i < n_lo) lds[tile_addr<true>(i, 0, 0)] = pre[u];
+    }
+}
+
 __global__ void k_intt_contig(DMatView m, int k, int k_lo, DeviceTables tb, uint32_t n_inv_mont) {
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo, k_hi = k - k_lo;
-    uint32_t* tw = lds + padded_words(n_lo);
-    stage_twiddles(tw, tb.itwc, k_lo);
+    const uint32_t* tw = tb.itwc;  // compact per-stage tables straight from L1/L2: no LDS copy, more blocks per CU
     const uint64_t tiles_per_col = m.height >> k_lo, total = tiles_per_col * m.width;
+    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return m.col(cidx) + (t - cidx * tiles_per_col) * n_lo; };
+    uint32_t pre[CONTIG_MAX_PER_THREAD];
+    if (blockIdx.x < total) prefetch_tile(pre, tile_ptr(blockIdx.x), n_lo);
     for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
-        const uint64_t cidx = t / tiles_per_col, h = t - cidx * tiles_per_col;
-        uint32_t* col = m.col(cidx) + h * n_lo;
-        for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[tile_addr<true>(i, 0, 0)] = col[i];
+        const uint64_t h = t % tiles_per_col;
+        uint32_t* col = tile_ptr(t);
+        commit_tile(pre, lds, n_lo);
         __syncthreads();
+        if (t + gridDim.x < total) prefetch_tile(pre, tile_ptr(t + gridDim.x), n_lo);
         tile_transform<true, true>(lds, tw, k_lo, 0, 0);
         if (k_hi > 0) {
-            Fp base = bit_product(tb.inv_roots, k_lo + 1, (uint32_t)h);  // w_N^{-bitrev_{k_hi}(h)}
-            Fp step = base.pow(blockDim.x), cur = base.pow(threadIdx.x);
+            // element r of block h is multiplied by w_N^{-e r}, e = bitrev_{k_hi}(h); a thread walks r = tid, tid + B, ...
+            const uint32_t e = __brev((uint32_t)h) >> (32 - k_hi), nmask = (1u << k) - 1u;
+            Fp step = inv_root_pow(tb, k, (e * blockDim.x) & nmask), cur = inv_root_pow(tb, k, (e * threadIdx.x) & nmask);
             for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { col[i] = (Fp::raw(lds[tile_addr<true>(i, 0, 0)]) * cur).v; cur *= step; }
         } else {
             Fp ninv = Fp::raw(n_inv_mont);
@@ -181,8 +210,11 @@ __global__ void k_intt_strided(DMatView m, int k, int k_lo, int logT, DeviceTabl
 // ---- forward, strided pass: grid = (N_lo / T, columns) -----------------------------------------------
 // Reads coefficients c_i (natural, column-major `src`), multiplies by shift^i, DIF over h, multiplies the
 // value at (h', r) by w_N^{r * bitrev(h')}, writes to `dst` (one N-row block of the LDE).
-__global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, int logT, DeviceTables tb,
-                              uint32_t shift_mont) {
+// Powers of the coset shift, prepared on the host per launch (kernel arguments, scalar loads):
+//   shift^r = lo[r & 63] * hi[r >> 6] for r < 4096;   hp[i] = shift^(i * N_lo);   step = shift^(hstep * N_lo)
+struct CosetPowers { uint32_t lo[64], hi[64], hp[128], step; };
+
+__global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, int logT, DeviceTables tb, CosetPowers cp) {
     extern __shared__ uint32_t lds[];
     const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
     const uint64_t n_lo = 1ull << k_lo, r0 = (uint64_t)blockIdx.x * T;
@@ -192,9 +224,9 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
     const int total = n_hi << logT;
     {
         // element e = h*T + c has exponent i = h*N_lo + r0 + c; a thread's c is fixed when blockDim % T == 0
-        Fp shift = Fp::raw(shift_mont);
         int c = threadIdx.x & (T - 1), h0 = threadIdx.x >> logT, hstep = blockDim.x >> logT;
-        Fp cur = shift.pow((uint64_t)h0 * n_lo + r0 + c), step = shift.pow((uint64_t)hstep * n_lo);
+        const uint32_t r = (uint32_t)r0 + c;
+        Fp cur = Fp::raw(cp.lo[r & 63]) * Fp::raw(cp.hi[r >> 6]) * Fp::raw(cp.hp[h0]), step = Fp::raw(cp.step);
         for (int h = h0; h < n_hi; h += hstep) { lds[h * LD + c] = (Fp::raw(in[h * n_lo + c]) * cur).v; cur *= step; }
     }
     stage_twiddles(tw, tb.twc, k_hi);
@@ -202,8 +234,9 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
     tile_transform<false, false>(lds, tw, k_hi, logT, LD);
     // twiddle: thread per row h', running product over the T consecutive r
     for (int h = threadIdx.x; h < n_hi; h += blockDim.x) {
-        Fp base = bit_product(tb.roots, k_lo + 1, (uint32_t)h);  // w_N^{bitrev_{k_hi}(h')}
-        Fp cur = base.pow(r0);
+        const uint32_t e = __brev((uint32_t)h) >> (32 - k_hi);  // k_hi >= 1 in this kernel
+        Fp base = root_pow(tb, k, e);                                                   // w_N^{bitrev_{k_hi}(h')}
+        Fp cur = root_pow(tb, k, (uint32_t)(((uint64_t)e * r0) & ((1ull << k) - 1)));  // base^r0
         for (int c = 0; c < T; c++) { lds[h * LD + c] = (Fp::raw(lds[h * LD + c]) * cur).v; cur *= base; }
     }
     __syncthreads();
@@ -217,22 +250,24 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
                              int from_src) {
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo;
-    uint32_t* tw = lds + padded_words(n_lo);
-    stage_twiddles(tw, tb.twc, k_lo);
+    const uint32_t* tw = tb.twc;
     const uint64_t tiles_per_col = src.height >> k_lo, total = tiles_per_col * src.width;
+    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return dst.col(cidx) + dst_row0 + (t - cidx * tiles_per_col) * n_lo; };
     Fp cur0 = Fp::one(), step = Fp::one();
     if (from_src) { Fp shift = Fp::raw(shift_mont); cur0 = shift.pow(threadIdx.x); step = shift.pow(blockDim.x); }
+    uint32_t pre[CONTIG_MAX_PER_THREAD];
+    if (!from_src && blockIdx.x < total) prefetch_tile(pre, tile_ptr(blockIdx.x), n_lo);
     for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
-        const uint64_t cidx = t / tiles_per_col, h = t - cidx * tiles_per_col;
-        uint32_t* out = dst.col(cidx) + dst_row0 + h * n_lo;
-        if (from_src) {  // single-pass transform: tiles_per_col == 1
-            const uint32_t* in = src.col(cidx);
+        uint32_t* out = tile_ptr(t);
+        if (from_src) {  // single-pass transform (n <= 2^12): tiles_per_col == 1, input = coefficients * shift^i
+            const uint32_t* in = src.col(t);
             Fp cur = cur0;
             for (int i = threadIdx.x; i < n_lo; i += blockDim.x) { lds[tile_addr<true>(i, 0, 0)] = (Fp::raw(in[i]) * cur).v; cur *= step; }
         } else {
-            for (int i = threadIdx.x; i < n_lo; i += blockDim.x) lds[tile_addr<true>(i, 0, 0)] = out[i];
+            commit_tile(pre, lds, n_lo);
         }
         __syncthreads();
+        if (!from_src && t + gridDim.x < total) prefetch_tile(pre, tile_ptr(t + gridDim.x), n_lo);
         tile_transform<false, true>(lds, tw, k_lo, 0, 0);
         for (int i = threadIdx.x; i < n_lo; i += blockDim.x) out[i] = lds[tile_addr<true>(i, 0, 0)];
         __syncthreads();
@@ -252,7 +287,7 @@ static NttPlan make_plan(int k) {
     unsigned tile = (1u << p.k_hi) << p.logT;
     p.threads_strided = tile / 32 < 64 ? 64 : (tile / 32 > 1024 ? 1024 : tile / 32);
     if (p.threads_strided < (1u << p.logT)) p.threads_strided = 1u << p.logT;
-    p.lds_contig = (size_t)(padded_words((int)n_lo) + n_lo) * 4;
+    p.lds_contig = (size_t)padded_words((int)n_lo) * 4;
     p.lds_strided = ((size_t)(1u << p.k_hi) * ((1u << p.logT) + 1) + (1u << p.k_hi)) * 4;
     return p;
 }
@@ -300,8 +335,17 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
     if (p.k_hi > 0) {
         dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)coeffs.width);
         {
+            CosetPowers cp;
+            const unsigned hstep = p.threads_strided >> p.logT;  // <= 128: threads <= 1024, T >= 8
+            Fp a = Fp::one(), s64 = shift.pow(64), sn = shift.pow(1ull << p.k_lo);
+            for (int i = 0; i < 64; i++) { cp.lo[i] = a.v; a *= shift; }
+            a = Fp::one();
+            for (int i = 0; i < 64; i++) { cp.hi[i] = a.v; a *= s64; }
+            a = Fp::one();
+            cp.step = 0;
+            for (unsigned i = 0; i < 128; i++) { cp.hp[i] = a.v; a *= sn; if (i + 1 == hstep) cp.step = a.v; }
             ProfScope ps("k_ntt_strided", st, pass_bytes);
-            hipLaunchKernelGGL(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, shift.v);
+            hipLaunchKernelGGL(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, cp);
         }
         ProfScope ps("k_ntt_contig", st, pass_bytes);
         hipLaunchKernelGGL(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0);
