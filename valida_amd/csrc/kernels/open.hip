@@ -29,11 +29,13 @@ __global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t
 
 // ---- column dot products --------------------------------------------------------------------------
 // Y[c][p] = sum_rows M[row][c] * w_p[row]  (base x Ext5): a skinny GEMM (10 x n) * (n x C) over F_p.
-// A block stages a tile of DOT_TR rows of M (all C columns, coalesced 512-byte column segments) and of
-// the weights in LDS; thread (c, pk) then owns ONE output limb and walks the tile rows: every lane of a
-// wave reads a different column (conflict-free, row stride odd) and a broadcast weight, so there is no
-// cross-lane reduction at all.  Blocks grid-stride over row tiles and emit one partial per block.
-constexpr int DOT_THREADS = 256, DOT_TR = 128, DOT_MAX_PASSES = 4, DOT_MAX_BLOCKS = 1024;
+// A block stages a tile of DOT_TR rows of M (all C columns, coalesced column segments) and of the weights in
+// LDS, both ROW-CONTIGUOUS per column; thread (c, pk) owns ONE output limb and walks the tile four rows at a time
+// with one ds_read_b128 per operand (lanes sharing c or pk read the same address: broadcast).  Products are
+// accumulated unreduced: four v_mad_u64_u32 into a 64-bit partial, folded into a 96-bit accumulator with three
+// carry adds — no Montgomery reduction inside the loop, one per thread at the very end.  No cross-lane reduction.
+// Blocks grid-stride over row tiles and emit one partial per block.
+constexpr int DOT_THREADS = 256, DOT_TR = 128, DOT_TRP = DOT_TR + 4, DOT_MAX_PASSES = 4, DOT_MAX_BLOCKS = 1024;
 
 __device__ __forceinline__ Fp wave_sum(Fp v) {
 #pragma unroll
@@ -41,29 +43,47 @@ __device__ __forceinline__ Fp wave_sum(Fp v) {
     return v;
 }
 
+struct Acc96 {
+    uint32_t lo, mid, hi;
+    __device__ __forceinline__ void add(uint64_t t) {
+        const uint64_t s = (uint64_t)lo + (uint32_t)t;
+        lo = (uint32_t)s;
+        const uint64_t m = (uint64_t)mid + (uint32_t)(t >> 32) + (uint32_t)(s >> 32);
+        mid = (uint32_t)m;
+        hi += (uint32_t)(m >> 32);
+    }
+    // (lo + mid 2^32 + hi 2^64) / 2^32 mod p: the Montgomery-form value of the accumulated sum of products
+    __device__ __forceinline__ Fp reduce() const {
+        uint32_t m = mid;
+        if (m >= vg::P) m -= vg::P;
+        if (m >= vg::P) m -= vg::P;
+        return Fp::raw(vg::monty_reduce((uint64_t)lo)) + Fp::raw(m) + Fp::from_canonical(hi);
+    }
+};
+
 template <int NP>
 __global__ void __launch_bounds__(DOT_THREADS) k_col_dot(DMatView m, uint64_t n, const uint32_t* __restrict__ w0, const uint32_t* __restrict__ w1, uint32_t* __restrict__ partial) {
     extern __shared__ uint32_t lds[];
-    constexpr int PK = NP * 5, WLD = PK | 1;
-    const int C = (int)m.width, LD = C | 1, n_out = C * PK;
-    uint32_t* Mt = lds;                // [DOT_TR][LD]
-    uint32_t* Wt = lds + DOT_TR * LD;  // [DOT_TR][WLD]
-    Fp acc[DOT_MAX_PASSES];
+    constexpr int PK = NP * 5;
+    const int C = (int)m.width, n_out = C * PK;
+    uint32_t* Mt = lds;                 // [C][DOT_TRP]
+    uint32_t* Wt = lds + C * DOT_TRP;   // [PK][DOT_TRP]
+    Acc96 acc[DOT_MAX_PASSES];
 #pragma unroll
-    for (int q = 0; q < DOT_MAX_PASSES; q++) acc[q] = Fp::zero();
+    for (int q = 0; q < DOT_MAX_PASSES; q++) acc[q] = Acc96{0, 0, 0};
     const uint64_t n_tiles = (n + DOT_TR - 1) / DOT_TR;
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t row0 = t * DOT_TR;
         const int rows = (int)((n - row0) < (uint64_t)DOT_TR ? (n - row0) : (uint64_t)DOT_TR);
         for (int e = threadIdx.x; e < C * DOT_TR; e += DOT_THREADS) {
             int r = e & (DOT_TR - 1), c = e / DOT_TR;
-            Mt[r * LD + c] = r < rows ? m.data[(uint64_t)c * m.stride + row0 + r] : 0u;
+            Mt[c * DOT_TRP + r] = r < rows ? m.data[(uint64_t)c * m.stride + row0 + r] : 0u;
         }
         for (int e = threadIdx.x; e < PK * DOT_TR; e += DOT_THREADS) {
             int r = e & (DOT_TR - 1), pk = e / DOT_TR;
             const uint32_t* w = pk < 5 ? w0 : w1;
             int k = pk < 5 ? pk : pk - 5;
-            Wt[r * WLD + pk] = r < rows ? w[(uint64_t)k * n + row0 + r] : 0u;
+            Wt[pk * DOT_TRP + r] = r < rows ? w[(uint64_t)k * n + row0 + r] : 0u;
         }
         __syncthreads();
 #pragma unroll
@@ -71,17 +91,17 @@ __global__ void __launch_bounds__(DOT_THREADS) k_col_dot(DMatView m, uint64_t n,
             int idx = q * DOT_THREADS + threadIdx.x;
             if (idx < n_out) {
                 int c = idx / PK, pk = idx - c * PK;
-                const uint32_t* mp = Mt + c;
-                const uint32_t* wp = Wt + pk;
-                Fp a = acc[q];
-                // lazy accumulation: four raw 64-bit products (one v_mad_u64_u32 each) per Montgomery reduction
+                const uint4* mp = reinterpret_cast<const uint4*>(Mt + c * DOT_TRP);
+                const uint4* wp = reinterpret_cast<const uint4*>(Wt + pk * DOT_TRP);
+                Acc96 a = acc[q];
 #pragma unroll 4
-                for (int r = 0; r < DOT_TR; r += 4) {
-                    uint64_t t = (uint64_t)mp[r * LD] * wp[r * WLD];
-                    t += (uint64_t)mp[(r + 1) * LD] * wp[(r + 1) * WLD];
-                    t += (uint64_t)mp[(r + 2) * LD] * wp[(r + 2) * WLD];
-                    t += (uint64_t)mp[(r + 3) * LD] * wp[(r + 3) * WLD];
-                    a += Fp::raw(vg::monty_reduce_wide(t));
+                for (int r = 0; r < DOT_TR / 4; r++) {
+                    const uint4 mv = mp[r], wv = wp[r];
+                    uint64_t t4 = (uint64_t)mv.x * wv.x;  // four products < 4 p^2 < 2^64
+                    t4 += (uint64_t)mv.y * wv.y;
+                    t4 += (uint64_t)mv.z * wv.z;
+                    t4 += (uint64_t)mv.w * wv.w;
+                    a.add(t4);
                 }
                 acc[q] = a;
             }
@@ -91,7 +111,7 @@ __global__ void __launch_bounds__(DOT_THREADS) k_col_dot(DMatView m, uint64_t n,
 #pragma unroll
     for (int q = 0; q < DOT_MAX_PASSES; q++) {
         int idx = q * DOT_THREADS + threadIdx.x;
-        if (idx < n_out) partial[(uint64_t)blockIdx.x * n_out + idx] = acc[q].v;
+        if (idx < n_out) partial[(uint64_t)blockIdx.x * n_out + idx] = acc[q].reduce().v;
     }
 }
 
@@ -282,7 +302,7 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
     if (m.width * np * 5 > (uint64_t)DOT_MAX_PASSES * DOT_THREADS) throw std::runtime_error("col_dot: matrix too wide (width * points * 5 > 1024)");
     unsigned blocks = (unsigned)col_dot_slots(n);
     const int pk = np * 5;
-    size_t lds = (size_t)DOT_TR * ((m.width | 1) + (pk | 1)) * 4;
+    size_t lds = (size_t)DOT_TRP * (m.width + pk) * 4;
     ProfScope ps("k_col_dot", st, 4.0 * n * (m.width + 5.0 * np));
     if (np == 1) hipLaunchKernelGGL(k_col_dot<1>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
     else hipLaunchKernelGGL(k_col_dot<2>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
