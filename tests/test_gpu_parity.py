@@ -324,3 +324,26 @@ def test_reference_test_programs_proof_bytes(machine, rc, name, interpret):
     log = p.upload_oplog(w.oplog())
     for chip in va.GENERATED_CHIPS:
         assert first_mismatch(p.generate_trace(log, chip).download(), w.main_trace(chip)) is None, va.CHIP_NAMES[chip]
+
+
+# ---- error behaviour at the boundary: the reference panics (basic/src/lib.rs:210,624,643-645); the C ABI returns a
+# status and a message instead, never unwinds, and stays usable afterwards --------------------------------------
+def test_bad_inputs_are_rejected_not_crashed(prover, fib25, rc):
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    dmain = [prover.upload(m) for m in mt]
+    dprep = [(c, prover.upload(m)) for c, m in prep]
+    with pytest.raises(va.VgpuError, match="one main trace per chip"):
+        prover.prove(dmain[:-1], dprep)
+    with pytest.raises(va.VgpuError, match="width mismatch"):
+        prover.prove([dmain[1]] + dmain[1:], dprep)
+    with pytest.raises(va.VgpuError, match="powers of two"):
+        prover.prove([prover.upload(mt[0][:192])] + dmain[1:], dprep)
+    with pytest.raises(va.VgpuError, match="shape mismatch"):
+        prover.prove(dmain, [(dprep[0][0], prover.upload(prep[0][1][:16])), dprep[1]])
+    with pytest.raises(va.VgpuError):
+        prover.commit_batches([prover.upload(mt[0][:100])])  # height not a power of two
+    with pytest.raises(va.VgpuError):
+        prover.fri_fold(np.zeros((6, 5), dtype=np.uint32), np.zeros(5, dtype=np.uint32))
+    # the context is still good: the same prover produces the reference proof afterwards
+    ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc)
+    assert first_mismatch(prover.prove(dmain, dprep).words, ref.words) is None
