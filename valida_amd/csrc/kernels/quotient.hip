@@ -16,6 +16,7 @@
 // i = bitrev_k(m) and i + n, i.e. x and -x: exactly the pair decompose() butterflies, so the n x 10
 // quotient-chunk row i is produced in place (written at position m = bit-reversed order, which is what
 // the inverse NTT of the following commit consumes).
+#include <cstdlib>
 #include "launch.hpp"
 #include "interactions.hpp"
 #include "../chips/basic_machine.hpp"
@@ -242,7 +243,11 @@ void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     uint64_t n = 1ull << a.log_n;
-    ProfScope ps("k_quotient", st, 4.0 * n * (2.0 * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 10.0));
+    static const char* names[16] = {"k_quotient.cpu", "k_quotient.program", "k_quotient.mem", "k_quotient.add", "k_quotient.sub", "k_quotient.mul", "k_quotient.div",
+                                    "k_quotient.shift", "k_quotient.lt", "k_quotient.com", "k_quotient.bitwise", "k_quotient.output", "k_quotient.range",
+                                    "k_quotient.static_data", "k_quotient", "k_quotient"};
+    const char* pname = getenv("VGPU_PROF_QUOTIENT_BY_CHIP") && a.native_chip >= 0 && a.native_chip < 14 ? names[a.native_chip] : "k_quotient";
+    ProfScope ps(pname, st, 4.0 * n * (2.0 * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 10.0));
     if (a.native_chip != QuotientArgs::INTERPRET) {
         // the BasicMachine chips: eval compiled ahead of time, one kernel per chip with constraints
         const dim3 grid((unsigned)((n + 255) / 256)), block(256);
