@@ -181,6 +181,12 @@ void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on) {
 // "name launches total_ms total_algorithmic_bytes total_algorithmic_valu_ops\n" per kernel, accumulated since profiling was switched on
 int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap) {
     std::string s;
+    {
+        DeviceCtx& c = p->p->ctx();
+        (void)hipSetDevice(c.device);
+        (void)hipDeviceSynchronize();  // every recorded event has completed: launches made outside prove() are collected too
+        c.profiler.collect();
+    }
     for (auto& kv : p->p->ctx().profiler.stats) {
         char line[256];
         snprintf(line, sizeof line, "%s %llu %.6f %.0f %.0f\n", kv.first.c_str(), (unsigned long long)kv.second.launches, kv.second.ms, kv.second.bytes,
