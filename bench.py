@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="proofs in flight per GPU: M host threads, each with its own prover context and HIP streams, share the K steps "
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the latency / PCIe-inclusive / operation-log legs (profiling runs: the process then consists of the warmup and the timed region only)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="SURVEY.md §8 config: c2 = Fibonacci (headline), c3 = Fibonacci 2^22 rows with 4x blowup, c4 = ALU/range-heavy loop")
     args = ap.parse_args()
@@ -209,7 +211,7 @@ def main():
     run_steps(args.warmup)
     # prover latency with nothing else in flight (the "prover ms" half of the metric)
     single, prof1 = None, None
-    if len(provers) > 1:
+    if len(provers) > 1 and not args.no_extra_legs:
         provers[0].set_profiling(True)
         fence()
         t0 = time.perf_counter()
@@ -219,18 +221,20 @@ def main():
         single = (time.perf_counter() - t0) / 4 * 1e3
         prof1 = provers[0].profile()
         provers[0].set_profiling(False)
-    # PCIe-inclusive rate (never `value`): every step starts from the host-resident main traces
-    fence()
-    t0 = time.perf_counter()
-    run_steps(2 * len(provers), from_host=True)
-    torch.cuda.synchronize()
-    pcie_ms = (time.perf_counter() - t0) / (2 * len(provers)) * 1e3
-    # the same with device trace generation: every step starts from the host-resident operation logs
-    fence()
-    t0 = time.perf_counter()
-    run_steps(2 * len(provers), from_oplog=True)
-    torch.cuda.synchronize()
-    oplog_ms = (time.perf_counter() - t0) / (2 * len(provers)) * 1e3
+    pcie_ms = oplog_ms = None
+    if not args.no_extra_legs:
+        # PCIe-inclusive rate (never `value`): every step starts from the host-resident main traces
+        fence()
+        t0 = time.perf_counter()
+        run_steps(2 * len(provers), from_host=True)
+        torch.cuda.synchronize()
+        pcie_ms = (time.perf_counter() - t0) / (2 * len(provers)) * 1e3
+        # the same with device trace generation: every step starts from the host-resident operation logs
+        fence()
+        t0 = time.perf_counter()
+        run_steps(2 * len(provers), from_oplog=True)
+        torch.cuda.synchronize()
+        oplog_ms = (time.perf_counter() - t0) / (2 * len(provers)) * 1e3
     for p_ in provers:
         p_.set_profiling(True)
     fence()
@@ -307,9 +311,10 @@ def main():
             "kernel_GBs": {k: (v[2] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in prof.items()},
             "kernel_ms_total_per_step": kernel_ms_total,
             "outside_timed_region": {"tracegen_s": t_tracegen, "h2d_upload_s": t_upload, "h2d_bytes": upload_bytes},
-            "pcie_inclusive": {"ms_per_step": pcie_ms, "value": world * 1e3 / pcie_ms, "unit": "proofs/s", "h2d_bytes_per_step": upload_bytes,
-                               "note": "main traces uploaded from pageable host memory inside every step; not the headline value"},
-            "from_operation_logs": {"ms_per_step": oplog_ms, "value": world * 1e3 / oplog_ms, "unit": "proofs/s",
+            "pcie_inclusive": None if pcie_ms is None else {
+                "ms_per_step": pcie_ms, "value": world * 1e3 / pcie_ms, "unit": "proofs/s", "h2d_bytes_per_step": upload_bytes,
+                "note": "main traces uploaded from pageable host memory inside every step; not the headline value"},
+            "from_operation_logs": None if oplog_ms is None else {"ms_per_step": oplog_ms, "value": world * 1e3 / oplog_ms, "unit": "proofs/s",
                                     "h2d_bytes_per_step": int(48 * oplog.n_cpu + 16 * oplog.n_mem + 16 * sum(oplog.n_alu) + sum(mt[c].nbytes for c in small)),
                                     "note": "operation logs uploaded and cpu/mem/add/sub/lt/bitwise traces generated on the device inside every step "
                                             "(replaces host generate_trace, reported as tracegen_s, and the row-major upload)"},

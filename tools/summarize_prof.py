@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 (rocpd SQLite) outputs of tools/profile_round.sh into the small tracked summaries under
-profiles/:   python tools/summarize_prof.py r01
+profiles/:   python tools/summarize_prof.py r01 [outdir]
   profiles/<tag>_kernel_stats_inflight{1,2}.csv   per-kernel calls / total / average duration (us)
   profiles/<tag>_pmc.json                          per-kernel counters per launch: VALU instructions, issue
                                                    utilisation, HBM bytes (FETCH_SIZE / WRITE_SIZE, corrected as
@@ -55,13 +55,16 @@ def counters(db_path):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-    dst = os.path.join(ROOT, "profiles")
+    # default: straight into profiles/ (tracked); on the GPU box pass an output directory under gpurun_out/ — the rocpd
+    # databases themselves are too big to travel back, the summaries are not
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for leg, cmd in (("stats1", "python bench.py --no-cpu-baseline --inflight 1 --steps 5 --warmup 2"), ("stats2", "python bench.py --no-cpu-baseline")):
+    for leg, cmd in (("stats1", "python bench.py --no-cpu-baseline --no-extra-legs --inflight 1 --steps 10 --warmup 1"),
+                     ("stats2", "python bench.py --no-cpu-baseline --no-extra-legs --steps 20 --warmup 2")):
         p = db_of(os.path.join(src, leg))
         if p:
             kernel_stats(p, os.path.join(dst, "%s_kernel_stats_inflight%s.csv" % (tag, leg[-1])), "rocprofv3 --kernel-trace --stats -- " + cmd + "   (MI355X)")
-    for f in ("bench_default.json", "bench_inflight1.json", "stats1.json", "stats2.json"):
+    for f in ("bench_default.json", "bench_inflight1.json", "bench_full.json", "bench_c3.json", "bench_c4.json", "stats1.json", "stats2.json"):
         p = os.path.join(src, f)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, f)))
