@@ -326,11 +326,11 @@ int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uin
         c.activate();
         uint64_t half = n / 2, q = half / 2;
         std::vector<uint32_t> in(5 * n);
-        vk::Ext5Arg bw;
+        std::vector<uint32_t> bw(5);
         for (uint64_t i = 0; i < n; i++) for (int k = 0; k < 5; k++) in[((i & 1) * 5 + k) * half + (i >> 1)] = Fp::from_canonical(f[5 * i + k]).v;
-        for (int k = 0; k < 5; k++) bw.w[k] = Fp::from_canonical(beta[k]).v;
-        DBuf din(&c, in), dout(&c, (size_t)(5 * half));
-        vk::launch_fri_fold(c.stream, din.data, n, bw, nullptr, c.tables, dout.data);
+        for (int k = 0; k < 5; k++) bw[k] = Fp::from_canonical(beta[k]).v;
+        DBuf din(&c, in), dbeta(&c, bw), dout(&c, (size_t)(5 * half));
+        vk::launch_fri_fold(c.stream, din.data, n, dbeta.data, nullptr, c.tables, dout.data);
         c.check_launch("fri fold");
         std::vector<uint32_t> o(5 * half);
         c.download(o.data(), dout.data, o.size() * 4);

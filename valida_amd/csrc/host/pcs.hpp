@@ -27,7 +27,8 @@ struct DeviceTree {
     uint32_t root[8] = {0};            // canonical
 
     // mats: views in commit order.  Enqueues all kernels; root is read back (sync) at the end.
-    void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats) {
+    // fetch_root = false leaves the root on the device only (layers.back()): the FRI commit phase consumes it there.
+    void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats, bool fetch_root = true) {
         ctx = c;
         std::vector<size_t> order(mats.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = i;
@@ -84,7 +85,8 @@ struct DeviceTree {
         if (top.levels) vk::launch_keccak_top(c->stream, top);
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
         c->check_launch("mmcs build");
-        c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished
+        if (fetch_root) c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished
+        else if (!single) throw std::logic_error("mmcs: a deferred root needs a single-matrix tree (no pointer table to keep alive)");
     }
 };
 

@@ -529,27 +529,46 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     {
         DBuf cur = std::move(ro[log_max]);
         ro.erase(log_max);
-        for (unsigned lf = log_max; lf-- > lb;) {
+        // The transcript moves to the device for the commit phase: per layer k_fri_challenge observes the root where
+        // the tree left it and samples beta, the fold reads beta from device memory — no host round trip inside the
+        // chain of dependent layers.  Roots, the final values and the sponge state come back in one sync below.
+        const unsigned n_layers = log_max - lb;
+        std::vector<uint32_t> chw(vk::DEV_CHALLENGER_WORDS, 0);
+        for (int i = 0; i < 16; i++) chw[i] = ch.state[i].v;
+        for (size_t i = 0; i < ch.in.size(); i++) chw[16 + i] = ch.in[i].v;
+        chw[32] = (uint32_t)ch.in.size();
+        for (size_t i = 0; i < ch.out.size(); i++) chw[33 + i] = ch.out[i].v;
+        chw[49] = (uint32_t)ch.out.size();
+        DBuf ch_dev(&c, chw), betas_dev(&c, (size_t)(5 * n_layers + 8)), commits_dev(&c, (size_t)(8 * n_layers + 8));
+        unsigned li = 0;
+        for (unsigned lf = log_max; lf-- > lb; li++) {
             uint64_t L = 2ull << lf, half = L >> 1;  // current length 2^(lf+1)
             layer_trees.emplace_back();
-            layer_trees.back().build(&c, {vk::DMatView{cur.data, half, 10, half}});
-            std::array<uint32_t, 8> root;
-            memcpy(root.data(), layer_trees.back().root, 32);
-            commit_phase_commits.push_back(root);
-            ch.observe_digest(root.data());
-            Ext5 beta = ch.sample_ext();
-            vk::Ext5Arg bw;
-            for (int k = 0; k < 5; k++) bw.w[k] = beta.c[k].v;
+            layer_trees.back().build(&c, {vk::DMatView{cur.data, half, 10, half}}, false);
+            vk::launch_fri_challenge(c.stream, pow_pos_.data, ch_dev.data, layer_trees.back().layers.back().data, betas_dev.data + 5 * li, commits_dev.data + 8 * li);
             DBuf next(&c, (size_t)(5 * half));
             auto it = ro.find(lf);
-            vk::launch_fri_fold(c.stream, cur.data, L, bw, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);
+            vk::launch_fri_fold(c.stream, cur.data, L, betas_dev.data + 5 * li, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);
             layer_bufs.push_back(std::move(cur));
             cur = std::move(next);
         }
         c.check_launch("fri fold");
         // `cur` now holds 2^lb values that must all be equal (a constant polynomial)
-        std::vector<uint32_t> fin(5ull << lb);
-        c.download(fin.data(), cur.data, fin.size() * 4);
+        std::vector<uint32_t> fin(5ull << lb), commits(8 * n_layers);
+        VG_HIP_CHECK(hipMemcpyAsync(chw.data(), ch_dev.data, chw.size() * 4, hipMemcpyDeviceToHost, c.stream));
+        if (n_layers) VG_HIP_CHECK(hipMemcpyAsync(commits.data(), commits_dev.data, commits.size() * 4, hipMemcpyDeviceToHost, c.stream));
+        c.download(fin.data(), cur.data, fin.size() * 4);  // synchronises the stream: all three copies have landed
+        for (int i = 0; i < 16; i++) ch.state[i] = Fp::raw(chw[i]);
+        ch.in.clear();
+        for (uint32_t i = 0; i < chw[32]; i++) ch.in.push_back(Fp::raw(chw[16 + i]));
+        ch.out.clear();
+        for (uint32_t i = 0; i < chw[49]; i++) ch.out.push_back(Fp::raw(chw[33 + i]));
+        for (unsigned i = 0; i < n_layers; i++) {
+            std::array<uint32_t, 8> root;
+            memcpy(root.data(), commits.data() + 8 * i, 32);
+            memcpy(layer_trees[i].root, root.data(), 32);
+            commit_phase_commits.push_back(root);
+        }
         // pair layout of a length-2^lb vector: (2^lb / 2) rows x 10 columns
         uint64_t rows = (1ull << lb) >> 1;
         auto elem = [&](uint64_t idx) { Ext5 e; for (int k = 0; k < 5; k++) e.c[k] = Fp::raw(fin[((idx & 1) * 5 + k) * rows + (idx >> 1)]); return e; };

@@ -70,8 +70,12 @@ uint64_t col_dot_slots(uint64_t n);
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
                     const uint32_t* scale5_dev, uint32_t* out_dev);
 void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width);
-struct Ext5Arg { uint32_t w[5]; };  // an extension element passed by value as a kernel argument (Montgomery words)
-void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, Ext5Arg beta, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
+// beta5_dev: the folding challenge as 5 Montgomery words in device memory (written by k_fri_challenge)
+void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
+// One DuplexChallenger step on the device: observe the 8-word root at digest8_dev, sample beta into beta5_dev; the root is
+// also copied to commit8_dev.  pos_dev: [480 Poseidon round constants][16 circulant MDS coefficients]; ch_dev: 50-word state.
+constexpr int DEV_CHALLENGER_WORDS = 50;
+void launch_fri_challenge(hipStream_t st, const uint32_t* pos_dev, uint32_t* ch_dev, const uint32_t* digest8_dev, uint32_t* beta5_dev, uint32_t* commit8_dev);
 void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev);
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst);
 

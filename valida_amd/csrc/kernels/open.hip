@@ -199,13 +199,13 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
 // ---- FRI fold ---------------------------------------------------------------------------------------
 // in: (L/2) x 10 pair layout (stride L/2).  out[i] = (f0 + f1)/2 + (beta/2) x_i^{-1} (f0 - f1) [+ add[i]],
 // x_i^{-1} = w_L^{-bitrev(i)} (no coset shift inside FRI), written in pair layout of length L/2.
-__global__ void __launch_bounds__(256) k_fri_fold(const uint32_t* __restrict__ in, uint64_t L, Ext5Arg beta_arg, const uint32_t* __restrict__ add,
-                           DeviceTables tb, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_fri_fold(const uint32_t* __restrict__ in, uint64_t L, const uint32_t* __restrict__ beta5 /* device, Montgomery */,
+                           const uint32_t* __restrict__ add, DeviceTables tb, uint32_t* __restrict__ out) {
     const uint64_t half = L >> 1;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     Ext5 f0 = load_ext(in, half, i), f1 = load_ext(in + 5 * half, half, i);
-    Ext5 beta = ext_from_words(beta_arg.w);
+    Ext5 beta = ext_from_words(beta5);
     Fp xinv = inv_domain_point(tb, (uint32_t)(2 * i));  // f[2i], f[2i+1] sit at +-x, x = w_L^{bitrev_L(2i)}
     Ext5 r = (f0 + f1) + beta * ((f0 - f1) * xinv);
 #pragma unroll
@@ -237,6 +237,79 @@ __global__ void k_gather(const uint32_t* __restrict__ desc, uint64_t n_desc, uin
         uint32_t v = src[(uint64_t)k * stride];
         o[k] = kind == 0 ? Fp::raw(v).canonical() : v;
     }
+}
+
+// ---- Fiat-Shamir on the device for the FRI commit phase -----------------------------------------------------------
+// One DuplexChallenger step per FRI layer (basic/src/lib.rs:611-619 -> TwoAdicFriPcs commit phase, App. B8/B10):
+// observe the layer's 8-word root, sample beta.  Keeping this on the device removes the per-layer D2H + host round
+// trip from a chain of 21 dependent layers: the whole commit phase is enqueued without a single synchronisation.
+// One wave; lane i < 16 owns state[i], input[i] and output[i] of the sponge; the Poseidon-16 MDS layer (circulant,
+// coefficients m[(j - i) & 15]) broadcasts the state with v_readlane and accumulates lazily (4 products per
+// Montgomery reduction).  State block `ch` (u32 words): [0,16) state  [16,32) input  [32] n_in  [33,49) output  [49] n_out.
+__device__ __forceinline__ Fp poseidon16_lanes(Fp st, const uint32_t* __restrict__ rc, const uint32_t (&m)[16], int lane) {
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        st += Fp::raw(rc[r * 16 + (lane & 15)]);
+        const Fp x2 = st * st, x5 = x2 * x2 * st;
+        if (r < 4 || r >= 26 || lane == 0) st = x5;
+        Fp acc = Fp::zero();
+#pragma unroll
+        for (int i0 = 0; i0 < 16; i0 += 4) {
+            uint64_t t = 0;
+#pragma unroll
+            for (int i = i0; i < i0 + 4; i++) t += (uint64_t)m[i] * (uint32_t)__builtin_amdgcn_readlane((int)st.v, i);
+            acc += Fp::raw(vg::monty_reduce_wide(t));
+        }
+        st = acc;
+    }
+    return st;
+}
+
+__global__ void __launch_bounds__(64) k_fri_challenge(const uint32_t* __restrict__ pos, uint32_t* __restrict__ ch, const uint32_t* __restrict__ digest8,
+                                                      uint32_t* __restrict__ beta5, uint32_t* __restrict__ commit8) {
+    const int lane = threadIdx.x, l16 = lane & 15;
+    const uint32_t* rc = pos;
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = pos[480 + ((l16 - i) & 15)];
+    Fp state = Fp::raw(ch[l16]), in = Fp::raw(ch[16 + l16]), out = Fp::raw(ch[33 + l16]);
+    uint32_t n_in = ch[32], n_out = ch[49];  // wave-uniform
+    auto duplexing = [&]() {
+        if ((uint32_t)lane < n_in) state = in;
+        n_in = 0;
+        state = poseidon16_lanes(state, rc, m, lane);
+        out = state;
+        n_out = 16;
+    };
+    // observe the commitment: 8 canonical words -> field elements (from_wrapped values are already < p)
+    const uint32_t dword = digest8[lane & 7];
+    const Fp dval = Fp::from_canonical(dword);
+    for (int k = 0; k < 8; k++) {
+        const Fp x = Fp::raw((uint32_t)__builtin_amdgcn_readlane((int)dval.v, k));
+        n_out = 0;
+        if ((uint32_t)lane == n_in) in = x;
+        n_in++;
+        if (n_in == 16) duplexing();
+    }
+    // sample_ext_element: five base samples, popped from the END of the output buffer
+    uint32_t beta[5];
+    for (int k = 0; k < 5; k++) {
+        if (n_in > 0 || n_out == 0) duplexing();
+        uint32_t v = out.v, pick = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) if ((uint32_t)i == n_out - 1) pick = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
+        beta[k] = pick;
+        n_out--;
+    }
+    if (lane < 16) { ch[lane] = state.v; ch[16 + lane] = in.v; ch[33 + lane] = out.v; }
+    if (lane == 0) { ch[32] = n_in; ch[49] = n_out; }
+    if (lane < 5) beta5[lane] = lane == 0 ? beta[0] : lane == 1 ? beta[1] : lane == 2 ? beta[2] : lane == 3 ? beta[3] : beta[4];
+    if (lane < 8) commit8[lane] = dword;
+}
+
+void launch_fri_challenge(hipStream_t st, const uint32_t* pos_dev, uint32_t* ch_dev, const uint32_t* digest8_dev, uint32_t* beta5_dev, uint32_t* commit8_dev) {
+    ProfScope ps("k_fri_challenge", st, 0.0);
+    hipLaunchKernelGGL(k_fri_challenge, dim3(1), dim3(64), 0, st, pos_dev, ch_dev, digest8_dev, beta5_dev, commit8_dev);
 }
 
 // ---- proof-of-work grinding ---------------------------------------------------------
@@ -312,10 +385,10 @@ void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L
     ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + 5.0));
     hipLaunchKernelGGL(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out);
 }
-void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, Ext5Arg beta, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
+void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
     uint64_t half = L >> 1;
     ProfScope ps("k_fri_fold", st, 20.0 * L + 20.0 * half * (add ? 2 : 1));
-    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, L, beta, add, tb, out);
+    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, L, beta5_dev, add, tb, out);
 }
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst) {
     if (!n_desc) return;
