@@ -145,7 +145,8 @@ struct DeviceCtx {
 
   private:
     void init_tables() {
-        std::vector<uint32_t> t(2048 * 6 + 64 + 2 * 4096, 0);
+        constexpr int TWC = 1 << 14;  // compact tables cover stages 1..14 (contiguous NTT tiles of up to 2^14 points)
+        std::vector<uint32_t> t(2048 * 6 + 64 + 2 * TWC, 0);
         Fp roots[28], inv_roots[28];
         for (int i = 0; i <= 27; i++) { roots[i] = vg::two_adic_generator(i); inv_roots[i] = roots[i].inv(); }
         for (int i = 0; i < 28; i++) { tables.roots[i] = roots[i].v; tables.inv_roots[i] = inv_roots[i].v; }
@@ -166,12 +167,12 @@ struct DeviceCtx {
         uint32_t* tw = h + 4096 + 32 + 4096 + 32;
         Fp w = roots[12], wi = inv_roots[12], c = Fp::one(), ci = Fp::one();
         for (int j = 0; j < 2048; j++) { tw[j] = c.v; tw[2048 + j] = ci.v; c *= w; ci *= wi; }
-        // compact per-stage tables: stage s (1..12) at offset 2^(s-1) - 1 holds w_{2^s}^j, j < 2^(s-1)
+        // compact per-stage tables: stage s (1..14) at offset 2^(s-1) - 1 holds w_{2^s}^j, j < 2^(s-1)
         uint32_t* twc = tw + 4096;
-        for (int s = 1; s <= 12; s++) {
+        for (int s = 1; s <= 14; s++) {
             Fp ws = roots[s], wsi = inv_roots[s], a = Fp::one(), b = Fp::one();
             int off = (1 << (s - 1)) - 1;
-            for (int j = 0; j < (1 << (s - 1)); j++) { twc[off + j] = a.v; twc[4096 + off + j] = b.v; a *= ws; b *= wsi; }
+            for (int j = 0; j < (1 << (s - 1)); j++) { twc[off + j] = a.v; twc[TWC + off + j] = b.v; a *= ws; b *= wsi; }
         }
         VG_HIP_CHECK(hipMalloc((void**)&table_mem, t.size() * 4));
         VG_HIP_CHECK(hipMemcpy(table_mem, t.data(), t.size() * 4, hipMemcpyHostToDevice));
@@ -184,7 +185,7 @@ struct DeviceCtx {
         tables.tw12 = table_mem + 4096 + 32 + 4096 + 32;
         tables.itw12 = tables.tw12 + 2048;
         tables.twc = tables.tw12 + 4096;
-        tables.itwc = tables.twc + 4096;
+        tables.itwc = tables.twc + TWC;
     }
 };
 

@@ -109,6 +109,20 @@ __device__ __forceinline__ void tile_transform(uint32_t* buf, const uint32_t* tw
         }
         return;
     }
+    if (PAD && logn == 14) {  // 2^14-point contiguous tiles (heights >= 2^23): three radix-16 rounds and one radix-4
+        if (DIT) {
+            ntt_round<4, true, PAD, 0>(buf, tw, 14, 1, 0, LD);
+            ntt_round<4, true, PAD, 4>(buf, tw, 14, 5, 0, LD);
+            ntt_round<4, true, PAD, 8>(buf, tw, 14, 9, 0, LD);
+            ntt_round<2, true, PAD, 12>(buf, tw, 14, 13, 0, LD);
+        } else {
+            ntt_round<2, false, PAD, 12>(buf, tw, 14, 13, 0, LD);
+            ntt_round<4, false, PAD, 8>(buf, tw, 14, 9, 0, LD);
+            ntt_round<4, false, PAD, 4>(buf, tw, 14, 5, 0, LD);
+            ntt_round<4, false, PAD, 0>(buf, tw, 14, 1, 0, LD);
+        }
+        return;
+    }
     const int rounds = (logn + 3) >> 2, small = logn / rounds, extra = logn - small * rounds;
     if (DIT) {
         int s_lo = 1;
@@ -211,8 +225,8 @@ __global__ void k_intt_strided(DMatView m, int k, int k_lo, int logT, DeviceTabl
 // Reads coefficients c_i (natural, column-major `src`), multiplies by shift^i, DIF over h, multiplies the
 // value at (h', r) by w_N^{r * bitrev(h')}, writes to `dst` (one N-row block of the LDE).
 // Powers of the coset shift, prepared on the host per launch (kernel arguments, scalar loads):
-//   shift^r = lo[r & 63] * hi[r >> 6] for r < 4096;   hp[i] = shift^(i * N_lo);   step = shift^(hstep * N_lo)
-struct CosetPowers { uint32_t lo[64], hi[64], hp[128], step; };
+//   shift^r = lo[r & 63] * hi[r >> 6] for r < N_lo <= 2^14;   hp[i] = shift^(i * N_lo);   step = shift^(hstep * N_lo)
+struct CosetPowers { uint32_t lo[64], hi[256], hp[128], step; };
 
 __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, int logT, DeviceTables tb, CosetPowers cp) {
     extern __shared__ uint32_t lds[];
@@ -278,7 +292,10 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
 struct NttPlan { int k, k_lo, k_hi, logT; unsigned threads_contig, threads_strided; size_t lds_contig, lds_strided; };
 static NttPlan make_plan(int k) {
     NttPlan p;
-    p.k = k; p.k_lo = k < 12 ? k : 12; p.k_hi = k - p.k_lo;
+    // contiguous tile: 2^12 points; 2^14 for the largest heights, where a 2^12 tile would leave the strided pass 2^(k-12)
+    // rows of at most 32 bytes each
+    // (measured: below 2^23 the 2^12 tile with its compile-time-stride rounds is the faster split)
+    p.k = k; p.k_lo = k < 12 ? k : (k >= 23 ? 14 : 12); p.k_hi = k - p.k_lo;
     int t = 16384 >> p.k_hi; if (t > 64) t = 64; if (t < 8) t = 8;
     if ((1 << p.k_lo) < t) t = 1 << p.k_lo;
     p.logT = 0; while ((1 << p.logT) < t) p.logT++;
@@ -340,7 +357,7 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
             Fp a = Fp::one(), s64 = shift.pow(64), sn = shift.pow(1ull << p.k_lo);
             for (int i = 0; i < 64; i++) { cp.lo[i] = a.v; a *= shift; }
             a = Fp::one();
-            for (int i = 0; i < 64; i++) { cp.hi[i] = a.v; a *= s64; }
+            for (int i = 0; i < 256; i++) { cp.hi[i] = a.v; a *= s64; }
             a = Fp::one();
             cp.step = 0;
             for (unsigned i = 0; i < 128; i++) { cp.hp[i] = a.v; a *= sn; if (i + 1 == hstep) cp.step = a.v; }
