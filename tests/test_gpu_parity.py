@@ -347,3 +347,13 @@ def test_bad_inputs_are_rejected_not_crashed(prover, fib25, rc):
     # the context is still good: the same prover produces the reference proof afterwards
     ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc)
     assert first_mismatch(prover.prove(dmain, dprep).words, ref.words) is None
+
+
+# ---- LDE at the large heights: both four-step splits (2^12-point tiles up to 2^22, 2^14-point tiles from 2^23) ------
+@pytest.mark.parametrize("log_h,w,log_blowup", [(18, 3, 1), (20, 2, 1), (22, 1, 1), (23, 1, 1), (24, 1, 1), (22, 1, 2), (23, 2, 2)])
+def test_large_lde_matches_oracle(machine, rc, log_h, w, log_blowup):
+    p = va.Prover(machine, rc, log_blowup=log_blowup)
+    rng = np.random.default_rng(4000 + log_h)
+    m = rand_matrix(rng, 1 << log_h, w)
+    pd = p.commit_batches([p.upload(m)])
+    assert first_mismatch(pd.lde(0), po.committed_lde(m, log_blowup, 31)) is None
