@@ -86,6 +86,9 @@ typedef struct vgpu_machine vgpu_machine_t;
 int32_t vgpu_machine_new(vgpu_machine_t** out);
 int32_t vgpu_machine_push_air(vgpu_machine_t* m, const vgpu_air_t* air);  /* compiles the constraint program */
 int32_t vgpu_machine_basic(vgpu_machine_t** out);                         /* the 14-chip BasicMachine from the in-tree chip definitions */
+/* the same 14 chips, but captured the way a foreign host captures them: each chip's eval runs against a builder that only
+ * calls vgpu_air_* / vgpu_air_add_interaction, then vgpu_machine_push_air (no native kernels: the interpreted path) */
+int32_t vgpu_machine_basic_via_ffi(vgpu_machine_t** out);
 void vgpu_machine_free(vgpu_machine_t* m);
 uint32_t vgpu_machine_num_chips(const vgpu_machine_t* m);
 /* per-chip facts: width, preprocessed width, #interactions, log_quotient_degree (get_log_quotient_degree,

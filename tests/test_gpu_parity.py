@@ -357,3 +357,14 @@ def test_large_lde_matches_oracle(machine, rc, log_h, w, log_blowup):
     m = rand_matrix(rng, 1 << log_h, w)
     pd = p.commit_batches([p.upload(m)])
     assert first_mismatch(pd.lde(0), po.committed_lde(m, log_blowup, 31)) is None
+
+
+# ---- the foreign-host route: chips captured through the vgpu_air_* FFI, proved by the interpreted programs -----------
+@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(100), lambda: va.Workload.named("signed_inequality")])
+def test_ffi_captured_machine_proof_bytes(rc, make):
+    p = va.Prover(va.Machine.basic_via_ffi(), rc)
+    w = make()
+    proof, ref, prep = _prove_both(p, w, rc)
+    assert first_mismatch(proof.words, ref.words) is None
+    with pytest.raises(va.VgpuError):
+        p.generate_trace(p.upload_oplog(w.oplog()), 0)  # device trace generators belong to the in-tree chips

@@ -177,3 +177,19 @@ def test_workload_oplog_shape():
     has = np.nonzero(np.diff(np.append(first, d.n_mem).astype(np.int64)) > 0)[0]
     assert np.all(mem[first[has], 0] == has)  # a record's first memory operation carries its clock
     assert cpu[-1, 8] == 9  # last record is STOP
+
+
+def test_ffi_captured_machine_equals_in_tree_machine():
+    # every chip's eval forwarded call by call through vgpu_air_* compiles to the same program as the in-tree capture,
+    # and evaluates to the same constraint values on random rows
+    a, b = va.Machine.basic(), va.Machine.basic_via_ffi()
+    assert a.num_chips == b.num_chips == va.NUM_CHIPS
+    rng = np.random.default_rng(3)
+    for chip in range(va.NUM_CHIPS):
+        ia, ib = a.chip_info(chip), b.chip_info(chip)
+        assert ia == ib, va.CHIP_NAMES[chip]
+        loc = rng.integers(0, va.P, size=ia["width"], dtype=np.uint32)
+        nxt = rng.integers(0, va.P, size=ia["width"], dtype=np.uint32)
+        ea = a.eval_constraints(chip, loc, nxt, is_first=5, is_last=7, is_transition=11)
+        eb = b.eval_constraints(chip, loc, nxt, is_first=5, is_last=7, is_transition=11)
+        assert list(ea) == list(eb), va.CHIP_NAMES[chip]

@@ -183,6 +183,13 @@ class Machine:
         _check(lib().vgpu_machine_basic(ctypes.byref(h)))
         return cls(h)
 
+    @classmethod
+    def basic_via_ffi(cls):
+        """The same chips captured through the vgpu_air_* FFI (what a foreign host does): interpreted AIR programs."""
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_machine_basic_via_ffi(ctypes.byref(h)))
+        return cls(h)
+
     @property
     def num_chips(self):
         return int(lib().vgpu_machine_num_chips(self._h))

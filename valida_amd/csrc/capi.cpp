@@ -102,6 +102,66 @@ int32_t vgpu_machine_basic(vgpu_machine_t** out) {
     VG_TRY({ if (!out) throw std::invalid_argument("null out"); auto* m = new vgpu_machine(); m->desc = MachineDesc::basic(); *out = m; })
 }
 void vgpu_machine_free(vgpu_machine_t* m) { delete m; }
+
+// The BasicMachine built the way a foreign host builds it: every in-tree chip's `eval` runs against an AirBuilder that
+// only forwards to the public vgpu_air_* entry points (the FFI image of SymbolicAirBuilder), its interactions go
+// through vgpu_air_add_interaction, and the captured AIR is pushed with vgpu_machine_push_air.  The resulting chips
+// carry no native kernel: they prove through the interpreted register program.
+namespace {
+struct FfiExpr {
+    vgpu_air_t* air;
+    uint32_t id;
+    FfiExpr operator+(const FfiExpr& o) const { return {air, vgpu_air_add(air, id, o.id)}; }
+    FfiExpr operator-(const FfiExpr& o) const { return {air, vgpu_air_sub(air, id, o.id)}; }
+    FfiExpr operator*(const FfiExpr& o) const { return {air, vgpu_air_mul(air, id, o.id)}; }
+    FfiExpr operator-() const { return {air, vgpu_air_neg(air, id)}; }
+};
+struct FfiBuilder {
+    using Expr = FfiExpr;
+    vgpu_air_t* air;
+    Expr constant(uint32_t c) { return {air, vgpu_air_constant(air, c)}; }
+    Expr main(int col, bool next) { return {air, vgpu_air_variable(air, 0, (uint32_t)col, next ? 1 : 0)}; }
+    Expr preprocessed(int col, bool next) { return {air, vgpu_air_variable(air, 1, (uint32_t)col, next ? 1 : 0)}; }
+    Expr is_first_row() { return {air, vgpu_air_is_first_row(air)}; }
+    Expr is_last_row() { return {air, vgpu_air_is_last_row(air)}; }
+    Expr is_transition() { return {air, vgpu_air_is_transition(air)}; }
+    void assert_zero(const Expr& e) { vgpu_air_assert_zero(air, e.id); }
+};
+void ffi_vcol(const vair::VirtualCol& v, std::vector<vgpu_vcol_term_t>& store, vgpu_vcol_t& out) {
+    store.clear();
+    for (auto& t : v.terms) store.push_back({t.preprocessed ? 1u : 0u, (uint32_t)t.col, t.weight});
+    out.terms = store.data(); out.n_terms = (uint32_t)store.size(); out.constant = v.constant;
+}
+}  // namespace
+int32_t vgpu_machine_basic_via_ffi(vgpu_machine_t** out) {
+    if (!out) return VGPU_ERR_INVALID_ARG;
+    vgpu_machine_t* m = nullptr;
+    int32_t rc = vgpu_machine_new(&m);
+    for (int chip = 0; rc == 0 && chip < vchips::NUM_CHIPS; chip++) {
+        const auto& info = vchips::chip_info(chip);
+        vgpu_air_t* air = nullptr;
+        rc = vgpu_air_new(info.name, (uint32_t)info.width, (uint32_t)info.preprocessed_width, &air);
+        if (rc) break;
+        FfiBuilder b{air};
+        vchips::eval_chip(chip, b);
+        for (const auto& it : vchips::chip_interactions(chip)) {
+            std::vector<std::vector<vgpu_vcol_term_t>> terms(it.fields.size() + 1);
+            std::vector<vgpu_vcol_t> fields(it.fields.size());
+            for (size_t f = 0; f < it.fields.size(); f++) ffi_vcol(it.fields[f], terms[f], fields[f]);
+            vgpu_interaction_t x{};
+            x.fields = fields.data(); x.n_fields = (uint32_t)fields.size();
+            ffi_vcol(it.count, terms.back(), x.count);
+            x.is_global = it.is_local() ? 0 : 1; x.bus_index = (uint32_t)it.bus_index; x.is_send = it.is_send() ? 1 : 0;
+            rc = vgpu_air_add_interaction(air, &x);
+            if (rc) break;
+        }
+        if (rc == 0) rc = vgpu_machine_push_air(m, air);
+        vgpu_air_free(air);
+    }
+    if (rc) { vgpu_machine_free(m); return rc; }
+    *out = m;
+    return 0;
+}
 uint32_t vgpu_machine_num_chips(const vgpu_machine_t* m) { return (uint32_t)m->desc.airs.size(); }
 int32_t vgpu_machine_chip_info(const vgpu_machine_t* m, uint32_t chip, uint32_t out[8]) {
     VG_TRY({
