@@ -185,11 +185,12 @@ typedef struct vgpu_oplog_desc {
     const vgpu_mem_op_t* mem; uint64_t n_mem;
     const vgpu_alu_op_t* alu[4]; uint64_t n_alu[4];   /* add, sub, lt, bitwise */
     const uint32_t* static_cells; uint64_t n_static;  /* MemoryChip::static_data as (addr, value) pairs, ascending address (may be null / 0) */
+    uint32_t rom_len;                                 /* ProgramROM length (program chip rows before padding) */
 } vgpu_oplog_desc_t;
 typedef struct vgpu_oplog vgpu_oplog_t;
 int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_oplog_t** out);
 void vgpu_oplog_free(vgpu_oplog_t* log);
-/* chip: cpu (0), mem (2), add (3), sub (4), lt (8), bitwise (10); any other chip -> VGPU_ERR_INVALID_ARG (generate it on the
+/* chip: cpu (0), program (1), mem (2), add (3), sub (4), lt (8), bitwise (10), range (12); any other chip -> VGPU_ERR_INVALID_ARG (generate it on the
  * host and vgpu_trace_upload it).  The returned trace is already in the prover's working layout (no ingest pass). */
 int32_t vgpu_generate_trace(vgpu_prover_t* p, const vgpu_oplog_t* log, uint32_t chip, vgpu_trace_t** out);
 void vgpu_trace_shape(const vgpu_trace_t* t, uint64_t* height, uint64_t* width);

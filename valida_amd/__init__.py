@@ -101,10 +101,11 @@ class OplogDesc(ctypes.Structure):  # vgpu_oplog_desc_t
         ("mem", ctypes.c_void_p), ("n_mem", ctypes.c_uint64),
         ("alu", ctypes.c_void_p * 4), ("n_alu", ctypes.c_uint64 * 4),
         ("static_cells", ctypes.c_void_p), ("n_static", ctypes.c_uint64),
+        ("rom_len", ctypes.c_uint32),
     ]
 
 
-GENERATED_CHIPS = (0, 2, 3, 4, 8, 10)  # cpu, mem, add, sub, lt, bitwise: chips with a device trace generator
+GENERATED_CHIPS = (0, 1, 2, 3, 4, 8, 10, 12)  # cpu, program, mem, add, sub, lt, bitwise, range: chips with a device trace generator
 
 
 class Workload:

@@ -284,6 +284,7 @@ int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_o
         h.mem = (const vk::TgMemOp*)log->mem; h.n_mem = log->n_mem;
         for (int k = 0; k < 4; k++) { h.alu[k] = (const vk::TgAluOp*)log->alu[k]; h.n_alu[k] = log->n_alu[k]; }
         h.static_cells = log->static_cells; h.n_static = log->n_static;
+        h.rom_len = log->rom_len;
         for (uint64_t i = 1; i < h.n_static; i++)
             if (log->static_cells[2 * i] <= log->static_cells[2 * i - 2]) throw std::invalid_argument("oplog: static cells must be in ascending address order");
         for (uint64_t i = 0; i < h.n_cpu; i++)
@@ -524,6 +525,7 @@ void vgpu_workload_oplog(const vgpu_workload_t* w, vgpu_oplog_desc_t* out) {
     out->mem = w->log_mem.data(); out->n_mem = w->log_mem.size();
     for (int k = 0; k < 4; k++) { out->alu[k] = w->log_alu[k].data(); out->n_alu[k] = w->log_alu[k].size(); }
     out->static_cells = w->log_static.data(); out->n_static = w->log_static.size() / 2;
+    out->rom_len = (uint32_t)w->vm->rom.size();
 }
 void vgpu_workload_free(vgpu_workload_t* w) { delete w; }
 void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]) {

@@ -86,6 +86,7 @@ std::unique_ptr<DeviceOplog> Prover::upload_oplog(const HostOplog& log) {
     d->cpu = upload_bytes(c, log.cpu, log.n_cpu * sizeof(vk::TgCpuOp));
     d->mem = upload_bytes(c, log.mem, log.n_mem * sizeof(vk::TgMemOp));
     for (int k = 0; k < 4; k++) { d->n_alu[k] = log.n_alu[k]; d->alu[k] = upload_bytes(c, log.alu[k], log.n_alu[k] * sizeof(vk::TgAluOp)); }
+    d->rom_len = log.rom_len;
     d->n_static = log.n_static;
     d->static_cells = upload_bytes(c, log.static_cells, log.n_static * 8);
     c.sync();
@@ -94,7 +95,8 @@ std::unique_ptr<DeviceOplog> Prover::upload_oplog(const HostOplog& log) {
 
 bool Prover::can_generate(int chip) {
     using namespace vchips;
-    return chip == CHIP_CPU || chip == CHIP_MEM || chip == CHIP_ADD || chip == CHIP_SUB || chip == CHIP_LT || chip == CHIP_BITWISE;
+    return chip == CHIP_CPU || chip == CHIP_PROGRAM || chip == CHIP_MEM || chip == CHIP_ADD || chip == CHIP_SUB || chip == CHIP_LT || chip == CHIP_BITWISE ||
+           chip == CHIP_RANGE;
 }
 
 std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int chip) {
@@ -117,6 +119,17 @@ std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int 
         VG_HIP_CHECK(vk::launch_tracegen_mem(c.stream, (const vk::TgMemOp*)log.mem.data, n, log.static_cells.data, log.n_static, keys.data, idx.data, tmp.data,
                                              tmp_bytes, t->nat.view()));
         c.sync();  // scratch buffers go back to the pool
+    } else if (chip == CHIP_RANGE || chip == CHIP_PROGRAM) {
+        if (chip == CHIP_PROGRAM && !log.rom_len) throw std::invalid_argument("generate_trace: the operation log carries no ROM length");
+        t->height = chip == CHIP_RANGE ? 256 : next_pow2(log.rom_len);
+        t->nat = DMat(&c, t->height, t->width);
+        DBuf counts(&c, std::max<size_t>(256, log.rom_len) + 4);
+        if (chip == CHIP_RANGE)
+            VG_HIP_CHECK(vk::launch_tracegen_range(c.stream, (const vk::TgAluOp*)log.alu[0].data, log.n_alu[0], (const vk::TgAluOp*)log.alu[1].data, log.n_alu[1], counts.data,
+                                                   t->nat.view()));
+        else
+            VG_HIP_CHECK(vk::launch_tracegen_program(c.stream, (const vk::TgCpuOp*)log.cpu.data, log.n_cpu, next_pow2(log.n_cpu), log.rom_len, counts.data, t->nat.view()));
+        c.sync();  // the scratch table goes back to the pool
     } else {
         const int k = chip == CHIP_ADD ? 0 : chip == CHIP_SUB ? 1 : chip == CHIP_LT ? 2 : 3;
         t->height = next_pow2(log.n_alu[k]);

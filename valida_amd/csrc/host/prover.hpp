@@ -34,10 +34,12 @@ struct HostOplog {
     const vk::TgMemOp* mem = nullptr; uint64_t n_mem = 0;
     const vk::TgAluOp* alu[4] = {nullptr, nullptr, nullptr, nullptr}; uint64_t n_alu[4] = {0, 0, 0, 0};  // add, sub, lt, bitwise
     const uint32_t* static_cells = nullptr; uint64_t n_static = 0;  // MemoryChip::static_data: (addr, value) pairs, ascending address
+    uint32_t rom_len = 0;                                           // ProgramROM length (height of the program chip's trace before padding)
 };
 struct DeviceOplog {
     DBuf cpu, mem, alu[4], static_cells;
     uint64_t n_cpu = 0, n_mem = 0, n_alu[4] = {0, 0, 0, 0}, n_static = 0;
+    uint32_t rom_len = 0;
 };
 
 struct PhaseTimes {  // milliseconds, host clock around stream syncs
@@ -65,7 +67,7 @@ class Prover {
     std::unique_ptr<DeviceTrace> upload_trace(const HostMatrix& m);
 
     // Device trace generation: H2D of the operation logs, then Chip::generate_trace of chip
-    // `chip` (cpu, mem, add, sub, lt, bitwise) as a kernel.  Other chips: host generate_trace + upload_trace.
+    // `chip` (cpu, program, mem, add, sub, lt, bitwise, range) as a kernel.  Other chips: host generate_trace + upload_trace.
     std::unique_ptr<DeviceOplog> upload_oplog(const HostOplog& log);
     std::unique_ptr<DeviceTrace> generate_trace(const DeviceOplog& log, int chip);
     static bool can_generate(int chip);

@@ -8,6 +8,7 @@
 // One thread per trace row; every column is written straight into the column-major Montgomery matrix the
 // commitment phase consumes (natural row order), so neither the 516 MB row-major upload nor k_ingest is needed.
 // The memory chip's (addr, clk) order is a stable LSD radix sort of the clk-ordered log by address (rocPRIM).
+#include <algorithm>
 #include <cstring>
 #include "launch.hpp"
 #include "../chips/basic_machine.hpp"
@@ -183,6 +184,36 @@ template <int CHIP> __global__ void __launch_bounds__(256) k_tracegen_alu(const 
     if (CHIP == CHIP_LT) put_raw(t, lt::DIFF_INV, i, lt_diff_inv);
 }
 
+// ---- range and program: multiplicity tables ---------------------------------------------------------------------
+// range/src/lib.rs:32-55: row n = (mult = number of range checks of byte n, counter = n).  The checks are those the ALU
+// instructions issue on their result words (alu_u32/src/add/mod.rs, sub/mod.rs: `range_check(a)` on execute), so the
+// table is the byte histogram of the add and sub logs.  program/src/lib.rs:50-68: multiplicity of pc = number of
+// instruction fetches at pc — the histogram of the cpu log's pc column plus the padded STOP rows at the final pc.
+__global__ void __launch_bounds__(256) k_tg_byte_histogram(const TgAluOp* __restrict__ ops, uint64_t n, uint32_t* __restrict__ counts /* 256, zeroed */) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = ops[i].a;
+#pragma unroll
+        for (int k = 0; k < 4; k++) atomicAdd(&h[byte_of(a, k)], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) k_tg_pc_histogram(const TgCpuOp* __restrict__ ops, uint64_t n, uint64_t padded_n, uint32_t rom_len, uint32_t* __restrict__ counts /* zeroed */) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pc = ops[i].pc;
+    if (pc < rom_len) atomicAdd(&counts[pc], i + 1 == n ? (uint32_t)(1 + padded_n - n) : 1u);  // the last instruction (STOP) is re-fetched by every padding row
+}
+__global__ void __launch_bounds__(256) k_tracegen_counts(const uint32_t* __restrict__ counts, uint64_t n_counts, int with_counter, DMatView t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.height) return;
+    put(t, 0, i, i < n_counts ? counts[i] : 0u);
+    if (with_counter) put(t, 1, i, (uint32_t)i);
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------
 static unsigned blocks_for(uint64_t rows) { return (unsigned)((rows + 255) / 256); }
 
@@ -208,6 +239,25 @@ hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, c
     }
     ProfScope ps("k_tracegen_mem", st, 20.0 * n + 4.0 * t.height * t.width);
     hipLaunchKernelGGL(k_tracegen_mem, dim3(blocks_for(t.height)), dim3(256), 0, st, mem, (const uint32_t*)(idx2 + n), n, static_cells, n_static, t);
+    return hipSuccess;
+}
+
+// counts: scratch of max(256, rom_len) words
+hipError_t launch_tracegen_range(hipStream_t st, const TgAluOp* add_ops, uint64_t n_add, const TgAluOp* sub_ops, uint64_t n_sub, uint32_t* counts, DMatView t) {
+    hipError_t e = hipMemsetAsync(counts, 0, 256 * 4, st);
+    if (e != hipSuccess) return e;
+    ProfScope ps("k_tracegen_tables", st, 16.0 * (n_add + n_sub) + 8.0 * t.height);
+    if (n_add) hipLaunchKernelGGL(k_tg_byte_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n_add + 255) / 256)), dim3(256), 0, st, add_ops, n_add, counts);
+    if (n_sub) hipLaunchKernelGGL(k_tg_byte_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n_sub + 255) / 256)), dim3(256), 0, st, sub_ops, n_sub, counts);
+    hipLaunchKernelGGL(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)256, 1, t);
+    return hipSuccess;
+}
+hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t n, uint64_t padded_n, uint32_t rom_len, uint32_t* counts, DMatView t) {
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)rom_len * 4, st);
+    if (e != hipSuccess) return e;
+    ProfScope ps("k_tracegen_tables", st, 48.0 * n + 4.0 * t.height);
+    hipLaunchKernelGGL(k_tg_pc_histogram, dim3(blocks_for(n)), dim3(256), 0, st, ops, n, padded_n, rom_len, counts);
+    hipLaunchKernelGGL(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)rom_len, 0, t);
     return hipSuccess;
 }
 
