@@ -23,8 +23,10 @@ struct ProveResult {
     ProveDebug dbg;
     double seconds = 0;
 };
+bool g_observe_final_poly = false;  // convention switch, set by oracle_set_observe_final_poly
 StarkConfig make_cfg(const uint32_t* rc, uint32_t log_blowup, uint32_t num_queries, uint32_t pow_bits) {
     StarkConfig cfg;
+    cfg.fri.observe_final_poly = g_observe_final_poly;
     cfg.poseidon_constants.assign(rc, rc + 480);
     cfg.fri.log_blowup = log_blowup;
     cfg.fri.num_queries = num_queries;
@@ -34,6 +36,7 @@ StarkConfig make_cfg(const uint32_t* rc, uint32_t log_blowup, uint32_t num_queri
 }  // namespace
 
 extern "C" {
+void oracle_set_observe_final_poly(int on) { g_observe_final_poly = on != 0; }
 
 uint32_t oracle_two_adic_generator(uint32_t bits) { return two_adic_generator(bits).v; }
 uint32_t oracle_fp_mul(uint32_t a, uint32_t b) { return (Fp(a) * Fp(b)).v; }

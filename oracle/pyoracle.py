@@ -206,6 +206,11 @@ class ProveResult:
             self._h = None
 
 
+def set_observe_final_poly(on):
+    """Convention switch of the restatement: absorb final_poly into the transcript before grinding."""
+    lib().oracle_set_observe_final_poly(ctypes.c_int(1 if on else 0))
+
+
 def prove_basic(main_traces, prep_program, prep_range, rc, log_blowup=1, num_queries=40, pow_bits=8, debug_check=False):
     keep = [np.ascontiguousarray(m, dtype=np.uint32) for m in main_traces]
     ptrs = (c_u32p * len(keep))(*[k.ctypes.data_as(c_u32p) for k in keep])

@@ -368,3 +368,18 @@ def test_ffi_captured_machine_proof_bytes(rc, make):
     assert first_mismatch(proof.words, ref.words) is None
     with pytest.raises(va.VgpuError):
         p.generate_trace(p.upload_oplog(w.oplog()), 0)  # device trace generators belong to the in-tree chips
+
+
+# ---- FriConfig variants (basic/tests/test_prover.rs:441-446) and the final-poly convention switch ------------------
+@pytest.mark.parametrize("num_queries,pow_bits,observe", [(1, 0, False), (7, 3, False), (40, 12, False), (40, 8, True), (100, 1, True)])
+def test_fri_config_variants_proof_bytes(machine, rc, fib25, num_queries, pow_bits, observe):
+    p = va.Prover(machine, rc, num_queries=num_queries, pow_bits=pow_bits, observe_final_poly=observe)
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    proof = p.prove([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep])
+    po.set_observe_final_poly(observe)
+    try:
+        ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc, num_queries=num_queries, pow_bits=pow_bits)
+        assert first_mismatch(proof.words, ref.words) is None
+        assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc, num_queries=num_queries, pow_bits=pow_bits) is None
+    finally:
+        po.set_observe_final_poly(False)
