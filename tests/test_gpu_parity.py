@@ -383,3 +383,16 @@ def test_fri_config_variants_proof_bytes(machine, rc, fib25, num_queries, pow_bi
         assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc, num_queries=num_queries, pow_bits=pow_bits) is None
     finally:
         po.set_observe_final_poly(False)
+
+
+def test_other_poseidon_constants(machine, fib25):
+    # the reference draws the 480 round constants from thread_rng (basic/tests/test_prover.rs:418-422): any set must work
+    rng = np.random.default_rng(2024)
+    rc2 = rng.integers(0, P, size=480, dtype=np.uint32)
+    p = va.Prover(machine, rc2)
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    proof = p.prove([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep])
+    ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc2)
+    assert first_mismatch(proof.words, ref.words) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc2) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, va.poseidon_round_constants()) is not None
