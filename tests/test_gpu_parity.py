@@ -396,3 +396,35 @@ def test_other_poseidon_constants(machine, fib25):
     assert first_mismatch(proof.words, ref.words) is None
     assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc2) is None
     assert po.verify_basic(prep[0][1], prep[1][1], proof.words, va.poseidon_round_constants()) is not None
+
+
+def test_two_provers_in_flight_produce_the_reference_proofs(machine, rc):
+    # bench.py keeps two proofs in flight per GPU from two host threads, each with its own prover context: the
+    # contexts must not disturb each other (every proof still the oracle's proof, bit for bit)
+    import threading
+
+    works = [va.Workload.fib(582), va.Workload.alu(300)]
+    refs = []
+    for w in works:
+        prep = w.preprocessed()
+        refs.append(po.prove_basic(w.main_traces(), prep[0][1], prep[1][1], rc).words)
+    provers = [va.Prover(machine, rc) for _ in works]
+    results = [[] for _ in works]
+
+    def worker(i):
+        p, w = provers[i], works[i]
+        mt, prep = w.main_traces(), w.preprocessed()
+        dmain = [p.upload(m) for m in mt]
+        dprep = [(c, p.upload(m)) for c, m in prep]
+        for _ in range(6):
+            results[i].append(p.prove(dmain, dprep).words)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(works))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(len(works)):
+        assert len(results[i]) == 6
+        for got in results[i]:
+            assert first_mismatch(got, refs[i]) is None

@@ -168,7 +168,10 @@ class Workload:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vgpu_workload_free(self._h)
+            try:
+                lib().vgpu_workload_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
 
@@ -218,7 +221,10 @@ class Machine:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vgpu_machine_free(self._h)
+            try:
+                lib().vgpu_machine_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
 
@@ -247,7 +253,10 @@ class Challenger:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vgpu_challenger_free(self._h)
+            try:
+                lib().vgpu_challenger_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
 
@@ -264,7 +273,10 @@ class DeviceOplog:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vgpu_oplog_free(self._h)
+            try:
+                lib().vgpu_oplog_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
 
@@ -280,7 +292,10 @@ class DeviceTrace:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vgpu_trace_free(self._h)
+            try:
+                lib().vgpu_trace_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
 
@@ -300,7 +315,10 @@ class ProverData:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vgpu_pdata_free(self._h)
+            try:
+                lib().vgpu_pdata_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
 
@@ -336,7 +354,10 @@ class Proof:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vgpu_proof_free(self._h)
+            try:
+                lib().vgpu_proof_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
 
@@ -436,5 +457,8 @@ class Prover:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vgpu_prover_destroy(self._h)
+            try:
+                lib().vgpu_prover_destroy(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
