@@ -216,19 +216,21 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
     p1.row = j1; p1.next_row = vg::reverse_bits_len((i1 + 2u) & Qmask, (unsigned)kq);
     p0.is_trans = d01; p0.is_first = Fp::raw(a.zh[par0]) * id00; p0.is_last = Fp::raw(a.zh[par0]) * id01;
     p1.is_trans = d11; p1.is_first = Fp::raw(a.zh[par1]) * id10; p1.is_last = Fp::raw(a.zh[par1]) * id11;
-    Ext5 q0, q1;
-    if (RFKIND == 3) {
-        q0 = run_native<CHIP>(a, p0);
-        q1 = run_native<CHIP>(a, p1);
-    } else if (RFKIND == 0) {
-        q0 = run_program_lds(a, p0, regs);
-        q1 = run_program_lds(a, p1, regs);
-    } else {
-        q0 = run_program_vgpr<RFKIND>(a, p0);
-        q1 = run_program_vgpr<RFKIND>(a, p1);
+    // The two points are evaluated one after the other (not unrolled): interleaving them only doubles the live
+    // registers of the compiled chip code.
+    Ext5 q0 = Ext5::zero(), q1 = Ext5::zero();
+#pragma unroll 1
+    for (int pt = 0; pt < 2; pt++) {
+        PointCtx p;  // field-wise selects (a reference to p0 / p1 would put both in scratch)
+        p.row = pt ? p1.row : p0.row; p.next_row = pt ? p1.next_row : p0.next_row;
+        p.is_first = pt ? p1.is_first : p0.is_first; p.is_last = pt ? p1.is_last : p0.is_last; p.is_trans = pt ? p1.is_trans : p0.is_trans;
+        Ext5 q;
+        if (RFKIND == 3) q = run_native<CHIP>(a, p);
+        else if (RFKIND == 0) q = run_program_lds(a, p, regs);
+        else q = run_program_vgpr<RFKIND>(a, p);
+        q = (q + perm_constraints(a, p)) * Fp::raw(a.zh_inv[pt ? par1 : par0]);
+        if (pt) q1 = q; else q0 = q;
     }
-    q0 = (q0 + perm_constraints(a, p0)) * Fp::raw(a.zh_inv[par0]);
-    q1 = (q1 + perm_constraints(a, p1)) * Fp::raw(a.zh_inv[par1]);
     // decompose (App. B11): even = (a+b)/2, odd = (a-b)/(2 x0)
     Fp x0_inv = Fp::raw(a.coset_shift_inv) * inv_domain_point(tb, j0);
     Ext5 sum = q0 + q1, diff = (q0 - q1) * x0_inv;
