@@ -18,13 +18,38 @@ namespace vk {
 // The first n storage rows of a bit-reversed LDE are the evaluations on s*H_n in bit-reversed order:
 // row j <-> x_j = s * r_j, r_j = w_n^{bitrev(j)}.  p(z) = scale * sum_j y_j * r_j / (z - s r_j) with
 // scale = (z^n - s^n) / (n s^{n-1}) applied on the host.  w: 5 columns of height n (stride n).
+// Four consecutive rows per thread share ONE Ext5 inversion (Montgomery's trick: 9 products + 1 inverse instead of 4 inverses).
+constexpr int BARY_ROWS = 4;
 __global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t* __restrict__ z5, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ w) {
-    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    Fp r = domain_point(tb, (uint32_t)j);
-    Ext5 z = ext_from_words(z5);
-    Ext5 d = z - Fp::raw(shift) * r;
-    store_ext(w, n, j, d.inv() * r);
+    const uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * BARY_ROWS;
+    if (j0 >= n) return;
+    const Ext5 z = ext_from_words(z5);
+    Fp r[BARY_ROWS];
+    Ext5 d[BARY_ROWS], pre[BARY_ROWS];
+    Ext5 run = Ext5::one();
+#pragma unroll
+    for (int q = 0; q < BARY_ROWS; q++) {
+        const bool live = j0 + q < n;
+        r[q] = live ? domain_point(tb, (uint32_t)(j0 + q)) : Fp::one();
+        d[q] = live ? z - Fp::raw(shift) * r[q] : Ext5::one();  // z is out of the domain: never zero
+        pre[q] = run;
+        run = q == 0 ? d[0] : run * d[q];
+    }
+    Ext5 inv = run.inv();
+    Ext5 res[BARY_ROWS];
+#pragma unroll
+    for (int q = BARY_ROWS - 1; q >= 0; q--) {
+        const Ext5 dinv = q == 0 ? inv : inv * pre[q];
+        if (q > 0) inv = inv * d[q];
+        res[q] = dinv * r[q];
+    }
+    if (j0 + BARY_ROWS <= n) {  // n >= 4 is a power of two: the four rows of a limb are one aligned 16-byte store
+#pragma unroll
+        for (int k = 0; k < 5; k++) *reinterpret_cast<uint4*>(w + (uint64_t)k * n + j0) = make_uint4(res[0].c[k].v, res[1].c[k].v, res[2].c[k].v, res[3].c[k].v);
+    } else {
+#pragma unroll
+        for (int q = 0; q < BARY_ROWS; q++) if (j0 + q < n) store_ext(w, n, j0 + q, res[q]);
+    }
 }
 
 // ---- column dot products --------------------------------------------------------------------------
@@ -363,7 +388,8 @@ void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pendin
 // ---- launchers ----------------------------------------------------------------------------------------
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w) {
     ProfScope ps("k_bary_weights", st, 20.0 * n);
-    hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, z5_dev, shift.v, tb, w);
+    const uint64_t threads = (n + BARY_ROWS - 1) / BARY_ROWS;
+    hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n, z5_dev, shift.v, tb, w);
 }
 uint64_t col_dot_slots(uint64_t n) {
     uint64_t tiles = (n + DOT_TR - 1) / DOT_TR;
