@@ -414,6 +414,11 @@ inline bool pcs_verify(const std::vector<VerifyRound>& rounds, const OpenedValue
             idx = pair;
             x = x * x;
         }
+        // Hardening: the prover adds the reduced opening of the SHORTEST LDE height (2^log_blowup:
+        // the height-1 chips) after the last fold; it is identically zero for honest openings (constant columns), so a
+        // verifier that stops at the loop above accepts proofs whose height-1 opened values were altered.  Adding the term
+        // keeps every honest proof valid and binds those values too.
+        if (ro.count(cfg.log_blowup)) folded += ro[cfg.log_blowup];
         if (folded != proof.fri.final_poly) return false;
     }
     return true;
