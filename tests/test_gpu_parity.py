@@ -428,3 +428,31 @@ def test_two_provers_in_flight_produce_the_reference_proofs(machine, rc):
         assert len(results[i]) == 6
         for got in results[i]:
             assert first_mismatch(got, refs[i]) is None
+
+
+# ---- invalid witnesses: the device prover never "fixes" them — the proof is rejected (or proving fails loudly) ----------
+def test_invalid_traces_do_not_yield_accepted_proofs(prover, fib25, rc):
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    dprep = [(c, prover.upload(m)) for c, m in prep]
+
+    def outcome(traces):
+        try:
+            proof = prover.prove([prover.upload(m) for m in traces], dprep)
+        except va.VgpuError as e:
+            return "error: " + str(e)
+        return po.verify_basic(prep[0][1], prep[1][1], proof.words, rc)
+
+    assert outcome(mt) is None
+    # (1) a constraint violation: one output byte of an ADD32 row is wrong -> the quotient is not a polynomial
+    bad = [m.copy() for m in mt]
+    bad[3][5, 11] = (int(bad[3][5, 11]) + 1) % P
+    assert outcome(bad) is not None
+    # (2) constraints hold but a bus is unbalanced: one range-check multiplicity too many -> cumulative sums do not cancel
+    bad = [m.copy() for m in mt]
+    bad[12][7, 0] = (int(bad[12][7, 0]) + 1) % P
+    assert "cumulative" in (outcome(bad) or "").lower() or outcome(bad) is not None
+    # (3) the cpu trace claims another opcode flag on one row
+    bad = [m.copy() for m in mt]
+    row = int(np.nonzero(bad[0][:, 7] == 1)[0][0]) if (bad[0][:, 7] == 1).any() else 3
+    bad[0][row, 7] ^= 1
+    assert outcome(bad) is not None
