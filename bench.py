@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--cpu-log-rows", type=int, default=17, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=2,
-                    help="proofs in flight per GPU: M host threads, each with its own prover context and HIP streams, share the K steps "
+                    help="proofs in flight per GPU: M prover contexts (own HIP streams and pool), one asynchronous proof outstanding on each "
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the latency / PCIe-inclusive / operation-log legs (profiling runs: the process then consists of the warmup and the timed region only)")
@@ -170,34 +170,33 @@ def main():
     small = [i for i in range(va.NUM_CHIPS) if i not in va.GENERATED_CHIPS]
 
     def run_steps(k, from_host=False, from_oplog=False):
-        """k proofs on this GPU, then the path's one collective.  With --inflight M > 1, M host threads (ctypes
-        releases the GIL) take steps i, i + M, ... on their own prover context, so one proof's latency-bound
-        Merkle-top / FRI tail overlaps another's throughput-bound commits."""
+        """k proofs on this GPU, then the path's one collective.  With --inflight M > 1 the steps go round-robin over M
+        prover contexts through the library's asynchronous prove, so one proof's latency-bound Merkle-top / FRI tail
+        overlaps another's throughput-bound commits."""
         done = [None] * k
 
-        def worker(slot):
+        def start(slot):
             pr = provers[slot]
-            for i in range(slot, k, len(provers)):
-                if from_oplog:  # H2D of the VM's operation logs, Chip::generate_trace on the device, small chips uploaded
-                    log = pr.upload_oplog(oplog)
-                    tr = {c: pr.generate_trace(log, c) for c in va.GENERATED_CHIPS}
-                    tr.update({c: pr.upload(mt[c]) for c in small})
-                    done[i] = pr.prove([tr[c] for c in range(va.NUM_CHIPS)], inputs[slot][1])
-                elif from_host:  # the boundary handing over host buffers: H2D of the 14 main traces inside the step
-                    done[i] = pr.prove([pr.upload(m) for m in mt], inputs[slot][1])
-                else:
-                    done[i] = pr.prove(*inputs[slot])
+            if from_oplog:  # H2D of the VM's operation logs, Chip::generate_trace on the device, small chips uploaded
+                log = pr.upload_oplog(oplog)
+                tr = {c: pr.generate_trace(log, c) for c in va.GENERATED_CHIPS}
+                tr.update({c: pr.upload(mt[c]) for c in small})
+                return pr.prove_async([tr[c] for c in range(va.NUM_CHIPS)], inputs[slot][1])
+            if from_host:  # the boundary handing over host buffers: H2D of the 14 main traces inside the step
+                return pr.prove_async([pr.upload(m) for m in mt], inputs[slot][1])
+            return pr.prove_async(*inputs[slot])
 
-        if len(provers) == 1:
-            worker(0)
-        else:
-            import threading
-
-            ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(provers))]
-            for t in ts:
-                t.start()
-            for t in ts:
-                t.join()
+        # one caller thread, one outstanding ticket per prover context (vgpu_prove_async): step i runs on context i % M
+        tickets = [None] * len(provers)
+        for i in range(k):
+            slot = i % len(provers)
+            if tickets[slot] is not None:
+                j, t = tickets[slot]
+                done[j] = t.wait()
+            tickets[slot] = (i, start(slot))
+        for tk in tickets:
+            if tk is not None:
+                done[tk[0]] = tk[1].wait()
         if world > 1 and k:
             all_roots[0] = exchange_roots(dist, torch, np.concatenate([p.words[2:26] for p in done]), torch.device("cuda", local_rank))
         return done

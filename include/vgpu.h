@@ -151,6 +151,13 @@ int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uin
  * with their chip indices in chip order (BasicMachine: program, range). */
 int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
                    const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t debug_flags, vgpu_proof_t** out);
+/* The same, asynchronously: returns at once, a host thread of its own drives this prover's streams.  Two provers on one
+ * GPU, each with one ticket outstanding, keep two proofs in flight from a single caller thread (independent segments:
+ * one proof's latency-bound Merkle-top / FRI chain overlaps the other's commits).  The traces must outlive the wait. */
+typedef struct vgpu_ticket vgpu_ticket_t;
+int32_t vgpu_prove_async(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
+                         const vgpu_trace_t* const* prep, uint32_t n_prep, vgpu_ticket_t** out);
+int32_t vgpu_ticket_wait(vgpu_ticket_t* t, vgpu_proof_t** out);   /* consumes the ticket */
 uint64_t vgpu_proof_len(const vgpu_proof_t* pr);            /* u32 words of the flat "VPF1" encoding */
 const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr);
 /* 11 doubles, ms: ingest, commit_main, perm, commit_perm, quotient, commit_quotient, open_values, open_reduce, fri, queries, total */

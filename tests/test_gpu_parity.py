@@ -456,3 +456,19 @@ def test_invalid_traces_do_not_yield_accepted_proofs(prover, fib25, rc):
     row = int(np.nonzero(bad[0][:, 7] == 1)[0][0]) if (bad[0][:, 7] == 1).any() else 3
     bad[0][row, 7] ^= 1
     assert outcome(bad) is not None
+
+
+def test_async_prove_matches_sync_prove(machine, rc, fib25):
+    # vgpu_prove_async / vgpu_ticket_wait: two contexts, one ticket outstanding on each, single caller thread
+    provers = [va.Prover(machine, rc) for _ in range(2)]
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc).words
+    inputs = [([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep]) for p in provers]
+    tickets = [p.prove_async(*inp) for p, inp in zip(provers, inputs)]
+    for t in tickets:
+        assert first_mismatch(t.wait().words, ref) is None
+    # an error in the worker surfaces at wait() with its message
+    bad = provers[0].prove_async(inputs[0][0][:-1], inputs[0][1])
+    with pytest.raises(va.VgpuError, match="one main trace per chip"):
+        bad.wait()
+    assert first_mismatch(provers[0].prove(*inputs[0]).words, ref) is None

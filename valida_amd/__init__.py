@@ -361,6 +361,27 @@ class Proof:
             self._h = None
 
 
+class Ticket:
+    """An outstanding asynchronous proof (vgpu_prove_async); keeps its inputs alive until waited for."""
+
+    def __init__(self, handle, keep):
+        self._h, self._keep = handle, keep
+
+    def wait(self):
+        h = ctypes.c_void_p()
+        t, self._h = self._h, None
+        _check(lib().vgpu_ticket_wait(t, ctypes.byref(h)))
+        self._keep = None
+        return Proof(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):  # never leave a worker thread using freed traces behind
+            try:
+                self.wait()
+            except Exception:
+                pass
+
+
 class Prover:
     """One MI355X: StarkConfig + Machine -> prove().  Mirrors machine.prove(&config)."""
 
@@ -435,6 +456,15 @@ class Prover:
         _check(lib().vgpu_prove(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)), ctypes.c_uint32(1 if debug else 0),
                                 ctypes.byref(h)))
         return Proof(h)
+
+    def prove_async(self, main, preprocessed):
+        """Start Machine::prove on a host thread of the library; returns a Ticket (wait() -> Proof)."""
+        arr = (ctypes.c_void_p * len(main))(*[t._h for t in main])
+        chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
+        parr = (ctypes.c_void_p * max(1, len(preprocessed)))(*[t._h for _, t in preprocessed])
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_prove_async(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)), ctypes.byref(h)))
+        return Ticket(h, (main, preprocessed, self))
 
     def set_profiling(self, on):
         lib().vgpu_prover_set_profiling(self._h, ctypes.c_uint32(1 if on else 0))

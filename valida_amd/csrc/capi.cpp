@@ -2,6 +2,7 @@
 // entry point replaces.
 #include "../../include/vgpu.h"
 #include <cstring>
+#include <future>
 #include <memory>
 #include <string>
 #include "host/prover.hpp"
@@ -26,6 +27,7 @@ struct vgpu_challenger { std::unique_ptr<Poseidon16> perm; std::unique_ptr<Chall
 struct vgpu_prover { std::unique_ptr<Prover> p; };
 struct vgpu_trace { std::unique_ptr<DeviceTrace> t; };
 struct vgpu_pdata { std::unique_ptr<ProverData> pd; };
+struct vgpu_ticket { std::future<std::pair<vgpu_proof_t*, std::pair<int32_t, std::string>>> result; };
 struct vgpu_proof { std::vector<uint32_t> words; PhaseTimes tm; ProveDebugOut dbg; };
 struct vgpu_oplog { std::unique_ptr<DeviceOplog> log; };
 static_assert(sizeof(vgpu_cpu_op_t) == sizeof(vk::TgCpuOp) && sizeof(vgpu_mem_op_t) == sizeof(vk::TgMemOp) && sizeof(vgpu_alu_op_t) == sizeof(vk::TgAluOp),
@@ -412,6 +414,35 @@ int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n
         proof->words = p->p->prove(m, pr, &proof->tm, &proof->dbg);
         *out = proof.release();
     })
+}
+// Asynchronous prove: the call returns at once; the proof is produced by a host thread of its own driving this prover's
+// streams.  With two provers a single caller thread keeps two proofs in flight on one GPU — one proof's latency-bound
+// Merkle-top / FRI tail overlaps the other's throughput-bound commits (DESIGN.md "Measurement").  One outstanding ticket
+// per prover; the traces must stay alive until vgpu_ticket_wait returns.
+int32_t vgpu_prove_async(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips, const vgpu_trace_t* const* prep,
+                         uint32_t n_prep, vgpu_ticket_t** out) {
+    VG_TRY({
+        if (!p || !main || !out) throw std::invalid_argument("null argument");
+        std::vector<const vgpu_trace_t*> m(main, main + n_main), pr(prep, prep + n_prep);
+        std::vector<uint32_t> chips(prep_chips, prep_chips + n_prep);
+        auto* t = new vgpu_ticket();
+        t->result = std::async(std::launch::async, [p, m, pr, chips]() {
+            std::pair<int32_t, std::string> status{VGPU_OK, ""};
+            vgpu_proof_t* proof = nullptr;
+            int32_t rc = vgpu_prove(p, m.data(), (uint32_t)m.size(), chips.data(), pr.data(), (uint32_t)pr.size(), 0, &proof);
+            if (rc != VGPU_OK) status = {rc, vgpu_last_error()};  // thread-local message of the worker thread
+            return std::make_pair(proof, status);
+        });
+        *out = t;
+    })
+}
+int32_t vgpu_ticket_wait(vgpu_ticket_t* t, vgpu_proof_t** out) {
+    if (!t || !out) return fail(VGPU_ERR_INVALID_ARG, "null argument");
+    auto r = t->result.get();
+    delete t;
+    if (r.second.first != VGPU_OK) return fail(r.second.first, r.second.second);
+    *out = r.first;
+    return VGPU_OK;
 }
 uint64_t vgpu_proof_len(const vgpu_proof_t* pr) { return pr->words.size(); }
 const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr) { return pr->words.data(); }
