@@ -8,14 +8,16 @@
 //       block bitrev_lb(t) of the LDE = DIF-NTT_N( c_i * (s * w_{bN}^t)^i )   (natural in, bit-reversed out)
 // so the committed bit-reversed LDE is produced directly, with no permutation pass.
 //
-// Sizes above 2^12 points use the two-pass ("four-step") split N = N_hi * N_lo, N_lo = 2^12:
+// Sizes above 2^12 points use the two-pass ("four-step") split N = N_hi * N_lo, N_lo = 2^12 (2^14 from N = 2^23):
 //   inverse: [contiguous DIT over N_lo] * w_N^{-bitrev(h) r}  ->  [strided DIT over N_hi] * 1/N
 //   forward: c * shift^i -> [strided DIF over N_hi] * w_N^{r bitrev(h')}  ->  [contiguous DIF over N_lo]
 // Every pass stages its tile in LDS (160 KiB/CU) and reads/writes HBM once.  Inside LDS the radix-2
 // stages are grouped into ROUNDS of up to 4 stages executed in registers (16 points per work item:
 // 32 butterflies between one LDS read and one LDS write, one barrier per round instead of per stage);
-// the twiddles of a round come from per-stage compact tables staged in LDS (broadcast / conflict-free
-// reads).  No MFMA: 31-bit modular butterflies are VALU work; the passes are HBM/VALU balanced.
+// the twiddles of a round come from per-stage compact tables — read through L1/L2 in the contiguous passes
+// (16-64 KB shared by every block), staged in LDS in the strided passes; the coset powers and four-step twiddles
+// come from small host-prepared / universal root tables instead of per-thread exponentiations.
+// No MFMA: 31-bit modular butterflies are VALU work.  Measured balance: DESIGN.md "Where the remaining time is".
 #include "launch.hpp"
 
 namespace vk {
@@ -136,13 +138,6 @@ __device__ __forceinline__ void tile_transform(uint32_t* buf, const uint32_t* tw
 __device__ __forceinline__ void stage_twiddles(uint32_t* dst, const uint32_t* __restrict__ compact, int logn) {
     const int count = (1 << logn) - 1;
     for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = compact[i];
-}
-
-// prod_{bit i of h} table[base + i]
-__device__ __forceinline__ Fp bit_product(const uint32_t* table, int base, uint32_t h) {
-    Fp r = Fp::one();
-    for (int i = 0; h; i++, h >>= 1) if (h & 1) r *= Fp::raw(table[base + i]);
-    return r;
 }
 
 // w_{2^m}^x and w_{2^m}^{-x} (x < 2^m) from the universal bit-reversed tables: the product over the set bits i of x of
