@@ -146,7 +146,7 @@ struct DeviceCtx {
   private:
     void init_tables() {
         constexpr int TWC = 1 << 14;  // compact tables cover stages 1..14 (contiguous NTT tiles of up to 2^14 points)
-        std::vector<uint32_t> t(2048 * 6 + 64 + 2 * TWC, 0);
+        std::vector<uint32_t> t(2048 * 4 + 64 + 2 * TWC, 0);
         Fp roots[28], inv_roots[28];
         for (int i = 0; i <= 27; i++) { roots[i] = vg::two_adic_generator(i); inv_roots[i] = roots[i].inv(); }
         for (int i = 0; i < 28; i++) { tables.roots[i] = roots[i].v; tables.inv_roots[i] = inv_roots[i].v; }
@@ -164,11 +164,8 @@ struct DeviceCtx {
         fill(h + 4096 + 32, 2048, 0, inv_roots);
         fill(h + 4096 + 32 + 2048, 2048, 11, inv_roots);
         fill(h + 4096 + 32 + 4096, 32, 22, inv_roots);
-        uint32_t* tw = h + 4096 + 32 + 4096 + 32;
-        Fp w = roots[12], wi = inv_roots[12], c = Fp::one(), ci = Fp::one();
-        for (int j = 0; j < 2048; j++) { tw[j] = c.v; tw[2048 + j] = ci.v; c *= w; ci *= wi; }
+        uint32_t* twc = h + 4096 + 32 + 4096 + 32;
         // compact per-stage tables: stage s (1..14) at offset 2^(s-1) - 1 holds w_{2^s}^j, j < 2^(s-1)
-        uint32_t* twc = tw + 4096;
         for (int s = 1; s <= 14; s++) {
             Fp ws = roots[s], wsi = inv_roots[s], a = Fp::one(), b = Fp::one();
             int off = (1 << (s - 1)) - 1;
@@ -182,9 +179,7 @@ struct DeviceCtx {
         tables.ibrt_lo = table_mem + 4096 + 32;
         tables.ibrt_hi = table_mem + 4096 + 32 + 2048;
         tables.ibrt_top = table_mem + 4096 + 32 + 4096;
-        tables.tw12 = table_mem + 4096 + 32 + 4096 + 32;
-        tables.itw12 = tables.tw12 + 2048;
-        tables.twc = tables.tw12 + 4096;
+        tables.twc = table_mem + 4096 + 32 + 4096 + 32;
         tables.itwc = tables.twc + TWC;
     }
 };

@@ -39,8 +39,6 @@ struct DeviceTables {
     const uint32_t* ibrt_lo;  // same for inverse roots
     const uint32_t* ibrt_hi;
     const uint32_t* ibrt_top;
-    const uint32_t* tw12;     // [2048] w_{4096}^j   (twiddles for in-LDS stages up to 2^12 points)
-    const uint32_t* itw12;    // [2048] w_{4096}^{-j}
     const uint32_t* twc;      // [16383] compact per-stage tables: twc[2^(s-1) - 1 + j] = w_{2^s}^j, j < 2^(s-1), s = 1..14
     const uint32_t* itwc;     // same with inverse roots
 };

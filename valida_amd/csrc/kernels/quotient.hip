@@ -5,11 +5,13 @@
 //   decompose_and_flatten    machine/src/quotient.rs:63-67 (Plonky3 uni-stark)
 // for log_quotient_degree = 1 (every BasicMachine chip: max constraint degree 3).
 //
-// The chip's `Air::eval` arrives as a linear register program (air/symbolic.hpp) compiled once from
-// the chip's unchanged constraint definitions; every thread interprets it on its row with the
-// register file in LDS (slot-major: reg[slot][thread], bank-conflict free) and program words fetched
-// by scalar loads.  The Horner fold acc = acc*alpha + c is evaluated as sum_k alpha^(K-1-k) c_k with
-// the alpha powers precomputed (same field element, 5 instead of 25 multiplications per constraint).
+// Two realisations of the chip's `Air::eval`, bit-identical in their values:
+//   * the in-tree BasicMachine chips: their unchanged `eval` templates (chips/basic_machine.hpp) are instantiated over a
+//     device-side folder and compiled ahead of time, one kernel per chip (k_quotient<3, CHIP>);
+//   * AIRs captured at run time through the vgpu_air_* FFI: a linear register program (air/symbolic.hpp) interpreted per
+//     row, register file in VGPRs (s_set_gpr_idx, <= 64 registers) or LDS (slot-major), program words by scalar loads.
+// The Horner fold acc = acc*alpha + c is evaluated as sum_k alpha^(K-1-k) c_k with the alpha powers precomputed (same
+// field element, 5 instead of 25 multiplications per constraint), accumulated lazily in the native kernels.
 //
 // Domain bookkeeping: the quotient domain s*H_{2n} is the first 2n storage rows of the bit-reversed
 // LDE; storage row j <-> natural index bitrev(j).  Thread m owns storage rows 2m, 2m+1 = natural
