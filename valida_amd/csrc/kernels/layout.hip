@@ -19,11 +19,24 @@ __global__ void k_ingest(const uint32_t* __restrict__ src, DMatView dst, int log
     const int rows = (int)((dst.height - j0) < 64 ? (dst.height - j0) : 64);
     // each wave reads whole source rows (W contiguous words)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int jr = wave; jr < rows; jr += nwaves) {
-        uint64_t j = j0 + jr;
-        uint64_t r = bitrev ? (uint64_t)vg::reverse_bits_len((uint32_t)j, (unsigned)log_h) : j;
-        const uint32_t* row = src + r * W;
-        for (int c = lane; c < W; c += 64) lds[jr * LD + c] = Fp::from_canonical(row[c]).v;
+    if (!bitrev) {
+        // the 64 source rows are one contiguous run of 64 * W words: flat, fully coalesced reads whatever the width
+        // (a 14-column trace would otherwise keep 14 of 64 lanes busy)
+        const uint32_t* run = src + j0 * W;
+        const int total = rows * W;
+        int jr = (int)threadIdx.x / W, c = (int)threadIdx.x - jr * W;  // one division per thread, then incremental
+        const int dj = (int)blockDim.x / W, dc = (int)blockDim.x - dj * W;
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            lds[jr * LD + c] = Fp::from_canonical(run[e]).v;
+            jr += dj; c += dc;
+            if (c >= W) { c -= W; jr++; }
+        }
+    } else {
+        for (int jr = wave; jr < rows; jr += nwaves) {
+            uint64_t r = (uint64_t)vg::reverse_bits_len((uint32_t)(j0 + jr), (unsigned)log_h);
+            const uint32_t* row = src + r * W;
+            for (int c = lane; c < W; c += 64) lds[jr * LD + c] = Fp::from_canonical(row[c]).v;
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < W * 64; e += blockDim.x) {
