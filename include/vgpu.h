@@ -158,6 +158,12 @@ typedef struct vgpu_ticket vgpu_ticket_t;
 int32_t vgpu_prove_async(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
                          const vgpu_trace_t* const* prep, uint32_t n_prep, vgpu_ticket_t** out);
 int32_t vgpu_ticket_wait(vgpu_ticket_t* t, vgpu_proof_t** out);   /* consumes the ticket */
+/* CBOR image of the proof (ciborium over the serde-derived MachineProof, basic/src/bin/valida.rs:425-427; field names of
+ * machine/src/proof.rs:13-44 and, for the PCS proof, SURVEY.md Appendix B12 — unpinned).  flags: VGPU_CBOR_*.  Returns the
+ * length in bytes (copying when out has room) or a negative status. */
+#define VGPU_CBOR_CANONICAL_FIELDS 1u  /* BabyBear as canonical u32 instead of the derived {"value": <Montgomery word>} */
+#define VGPU_CBOR_PLAIN_DIGESTS 2u     /* commitments as [Val; 8] instead of Hash { value, _marker } */
+int64_t vgpu_proof_cbor(const uint32_t* proof_words, uint64_t n_words, uint32_t flags, uint8_t* out, uint64_t cap_bytes);
 uint64_t vgpu_proof_len(const vgpu_proof_t* pr);            /* u32 words of the flat "VPF1" encoding */
 const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr);
 /* 11 doubles, ms: ingest, commit_main, perm, commit_perm, quotient, commit_quotient, open_values, open_reduce, fri, queries, total */

@@ -193,3 +193,29 @@ def test_ffi_captured_machine_equals_in_tree_machine():
         ea = a.eval_constraints(chip, loc, nxt, is_first=5, is_last=7, is_transition=11)
         eb = b.eval_constraints(chip, loc, nxt, is_first=5, is_last=7, is_transition=11)
         assert list(ea) == list(eb), va.CHIP_NAMES[chip]
+
+
+@pytest.mark.parametrize("flags", [0, va.CBOR_CANONICAL_FIELDS, va.CBOR_PLAIN_DIGESTS, va.CBOR_CANONICAL_FIELDS | va.CBOR_PLAIN_DIGESTS])
+def test_proof_cbor_matches_independent_encoder(flags):
+    # the product's CBOR image of MachineProof vs the test-side serde data model + generic encoder
+    from oracle import cbor_ref
+
+    w = va.Workload.fib(25)
+    prep = w.preprocessed()
+    words = po.prove_basic(w.main_traces(), prep[0][1], prep[1][1], va.poseidon_round_constants(), num_queries=5).words
+    got = va.proof_cbor(words, flags)
+    model = cbor_ref.model(words, bool(flags & va.CBOR_CANONICAL_FIELDS), bool(flags & va.CBOR_PLAIN_DIGESTS))
+    assert got == cbor_ref.encode(model)
+    back = cbor_ref.decode(got)
+    assert back == model and list(back) == ["commitments", "opening_proof", "chip_proofs"]  # machine/src/proof.rs:15-19
+    assert list(back["chip_proofs"][0]["opened_values"]) == ["preprocessed_local", "preprocessed_next", "trace_local", "trace_next", "permutation_local",
+                                                              "permutation_next", "quotient_chunks"]  # :37-44
+    assert back["chip_proofs"][0]["log_degree"] == 8 and len(back["chip_proofs"]) == va.NUM_CHIPS
+    assert len(back["opening_proof"]["fri_proof"]["query_proofs"]) == 5
+    if not flags & va.CBOR_CANONICAL_FIELDS:  # the derive on `struct BabyBear { value: u32 }`: the raw Montgomery word
+        canonical = cbor_ref.model(words, True, True)["opening_proof"]["fri_proof"]["pow_witness"]
+        assert back["opening_proof"]["fri_proof"]["pow_witness"] == {"value": canonical * (1 << 32) % va.P}
+    with pytest.raises(va.VgpuError):
+        va.proof_cbor(words[:-3], flags)  # truncated proof
+    with pytest.raises(va.VgpuError):
+        va.proof_cbor(np.concatenate([words, [0]]).astype(np.uint32), flags)  # trailing word

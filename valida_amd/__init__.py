@@ -338,6 +338,10 @@ class Proof:
     def bytes(self):
         return self.words.tobytes()
 
+    def cbor(self, flags=0):
+        """The proof as the reference writes it to disk: CBOR of the serde-derived MachineProof (see proof_cbor)."""
+        return proof_cbor(self.words, flags)
+
     def _dbg(self, fn, chip):
         n = fn(self._h, ctypes.c_uint32(chip), None, ctypes.c_uint64(0))
         if n < 0:
@@ -359,6 +363,22 @@ class Proof:
             except TypeError:  # interpreter shutdown: module globals already cleared
                 pass
             self._h = None
+
+
+CBOR_CANONICAL_FIELDS, CBOR_PLAIN_DIGESTS = 1, 2
+
+
+def proof_cbor(words, flags=0):
+    """CBOR bytes of a proof given as VPF1 words (ciborium image of MachineProof; host-only, no device needed)."""
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    L = lib()
+    L.vgpu_proof_cbor.restype = ctypes.c_int64
+    n = L.vgpu_proof_cbor(w.ctypes.data_as(c_u32p), ctypes.c_uint64(w.size), ctypes.c_uint32(flags), None, ctypes.c_uint64(0))
+    if n < 0:
+        _check(int(n))
+    buf = (ctypes.c_uint8 * int(n))()
+    L.vgpu_proof_cbor(w.ctypes.data_as(c_u32p), ctypes.c_uint64(w.size), ctypes.c_uint32(flags), buf, ctypes.c_uint64(int(n)))
+    return bytes(buf)
 
 
 class Ticket:

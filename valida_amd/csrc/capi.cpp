@@ -5,6 +5,7 @@
 #include <future>
 #include <memory>
 #include <string>
+#include "host/cbor.hpp"
 #include "host/prover.hpp"
 #include "workload/basic_vm.hpp"
 
@@ -443,6 +444,14 @@ int32_t vgpu_ticket_wait(vgpu_ticket_t* t, vgpu_proof_t** out) {
     if (r.second.first != VGPU_OK) return fail(r.second.first, r.second.second);
     *out = r.first;
     return VGPU_OK;
+}
+int64_t vgpu_proof_cbor(const uint32_t* proof_words, uint64_t n_words, uint32_t flags, uint8_t* out, uint64_t cap_bytes) {
+    try {
+        if (!proof_words) throw std::invalid_argument("null argument");
+        std::vector<uint8_t> b = proof_to_cbor(proof_words, (size_t)n_words, flags);
+        if (out && cap_bytes >= b.size()) memcpy(out, b.data(), b.size());
+        return (int64_t)b.size();
+    } catch (const std::exception& e) { return (int64_t)fail(VGPU_ERR_INVALID_ARG, e.what()); }
 }
 uint64_t vgpu_proof_len(const vgpu_proof_t* pr) { return pr->words.size(); }
 const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr) { return pr->words.data(); }
