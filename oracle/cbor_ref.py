@@ -134,3 +134,56 @@ def decode(b):
     v, i = item(0)
     assert i == len(b), "trailing bytes"
     return v
+
+
+def words_from_model(m):
+    """Inverse of model(): the VPF1 words of a decoded CBOR proof (either variant of the two switches)."""
+    rinv = pow(R, -1, P)
+
+    def val(v):
+        return v["value"] * rinv % P if isinstance(v, dict) else v
+
+    def ext(e):
+        return [val(x) for x in (e["value"] if isinstance(e, dict) else e)]
+
+    def digest(d):
+        return [val(x) for x in (d["value"] if isinstance(d, dict) else d)]
+
+    def path(p):
+        out = [len(p)]
+        for node in p:
+            out += [val(x) for x in node]
+        return out
+
+    w = [0x31465056, len(m["chip_proofs"])]
+    for k in ("main_trace", "perm_trace", "quotient_chunks"):
+        w += digest(m["commitments"][k])
+    for cp in m["chip_proofs"]:
+        ov = cp["opened_values"]
+        assert ov["preprocessed_local"] == [] and ov["preprocessed_next"] == []
+        w.append(cp["log_degree"])
+        for k in ("trace_local", "trace_next", "permutation_local", "permutation_next", "quotient_chunks"):
+            w.append(len(ov[k]))
+            for e in ov[k]:
+                w += ext(e)
+        w += ext(cp["cumulative_sum"])
+    fri = m["opening_proof"]["fri_proof"]
+    w.append(len(fri["commit_phase_commits"]))
+    for c in fri["commit_phase_commits"]:
+        w += digest(c)
+    w.append(len(fri["query_proofs"]))
+    for q in fri["query_proofs"]:
+        w.append(len(q["commit_phase_openings"]))
+        for step in q["commit_phase_openings"]:
+            w += ext(step["sibling_value"]) + path(step["opening_proof"])
+    w += ext(fri["final_poly"]) + [val(fri["pow_witness"])]
+    qo = m["opening_proof"]["query_openings"]
+    w.append(len(qo))
+    for rounds in qo:
+        w.append(len(rounds))
+        for bo in rounds:
+            w.append(len(bo["opened_values"]))
+            for row in bo["opened_values"]:
+                w += [len(row)] + [val(x) for x in row]
+            w += path(bo["opening_proof"])
+    return w
