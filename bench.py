@@ -267,7 +267,9 @@ def main():
         b_alg = algorithmic_bytes_per_proof(shapes, prover.log_blowup)
         kernel_ms_total = sum(v[1] for v in prof.values()) / args.steps
         out = {
-            "metric": "proofs/sec, 2^%d-row %s trace (BabyBear, Keccak-256 MMCS, FRI blowup %d, 40 queries)" % (args.log_rows, "ALU-loop" if args.workload == "c4" else "Fibonacci", 1 << prover.log_blowup),
+            # BASELINE.json: "proofs/sec + prover ms, 2^20-row Fibonacci trace": `value` is the proofs/sec half, the prover ms
+            # half is `prover_ms_single_proof_in_flight`
+            "metric": "proofs/sec, 2^%d-row %s trace" % (args.log_rows, "ALU-loop" if args.workload == "c4" else "Fibonacci"),
             "value": value,
             "unit": "proofs/s",
             "n_gpus": world,
@@ -277,10 +279,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (BabyBear mod p, Montgomery) / u64 (Keccak lanes)",
+            "dtype": "u32",  # BabyBear mod p in Montgomery form; Keccak lanes as pairs of u32
             "data": "synthetic: %s traces generated by the in-tree VM, deterministic; Poseidon constants SplitMix64(0x56414C494441)" % data,
             "config": {
                 "workload": wl_name + ", 14 chips, one proof per GPU",
+                "field": "BabyBear / Ext5", "mmcs": "Keccak-256", "fri_blowup": 1 << prover.log_blowup,
                 "log_blowup": prover.log_blowup, "num_queries": prover.num_queries, "pow_bits": prover.pow_bits,
                 "parallelism": "segments: one independent proof per GPU + all-gather of 3 roots" if world > 1 else "single GPU",
                 "proofs_in_flight_per_gpu": len(provers),
