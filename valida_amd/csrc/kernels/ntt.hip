@@ -208,7 +208,17 @@ __global__ void k_intt_strided(DMatView m, int k, int k_lo, int logT, DeviceTabl
     uint32_t* tw = lds + n_hi * LD;
     uint32_t* col = m.col(blockIdx.y) + (uint64_t)blockIdx.x * T;
     const int total = n_hi << logT;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; lds[h * LD + c] = col[h * n_lo + c]; }
+    {
+        int e = threadIdx.x;
+        for (; e + 7 * (int)blockDim.x < total; e += 8 * blockDim.x) {  // eight independent loads in flight per thread
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int eu = e + u * (int)blockDim.x; v[u] = col[(uint64_t)(eu >> logT) * n_lo + (eu & (T - 1))]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int eu = e + u * (int)blockDim.x; lds[(eu >> logT) * LD + (eu & (T - 1))] = v[u]; }
+        }
+        for (; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; lds[h * LD + c] = col[h * n_lo + c]; }
+    }
     stage_twiddles(tw, tb.itwc, k_hi);
     __syncthreads();
     tile_transform<true, false>(lds, tw, k_hi, logT, LD);
@@ -236,7 +246,16 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
         int c = threadIdx.x & (T - 1), h0 = threadIdx.x >> logT, hstep = blockDim.x >> logT;
         const uint32_t r = (uint32_t)r0 + c;
         Fp cur = Fp::raw(cp.lo[r & 63]) * Fp::raw(cp.hi[r >> 6]) * Fp::raw(cp.hp[h0]), step = Fp::raw(cp.step);
-        for (int h = h0; h < n_hi; h += hstep) { lds[h * LD + c] = (Fp::raw(in[h * n_lo + c]) * cur).v; cur *= step; }
+        // eight independent row loads in flight per thread before the (serial) running product consumes them
+        int h = h0;
+        for (; h + 7 * hstep < n_hi; h += 8 * hstep) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = in[(uint64_t)(h + u * hstep) * n_lo + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { lds[(h + u * hstep) * LD + c] = (Fp::raw(v[u]) * cur).v; cur *= step; }
+        }
+        for (; h < n_hi; h += hstep) { lds[h * LD + c] = (Fp::raw(in[h * n_lo + c]) * cur).v; cur *= step; }
     }
     stage_twiddles(tw, tb.twc, k_hi);
     __syncthreads();
