@@ -26,7 +26,19 @@ __global__ void k_ingest(const uint32_t* __restrict__ src, DMatView dst, int log
         const int total = rows * W;
         int jr = (int)threadIdx.x / W, c = (int)threadIdx.x - jr * W;  // one division per thread, then incremental
         const int dj = (int)blockDim.x / W, dc = (int)blockDim.x - dj * W;
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        int e = threadIdx.x;
+        for (; e + 3 * (int)blockDim.x < total; e += 4 * blockDim.x) {  // four independent loads in flight per thread
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = run[e + u * (int)blockDim.x];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                lds[jr * LD + c] = Fp::from_canonical(v[u]).v;
+                jr += dj; c += dc;
+                if (c >= W) { c -= W; jr++; }
+            }
+        }
+        for (; e < total; e += blockDim.x) {
             lds[jr * LD + c] = Fp::from_canonical(run[e]).v;
             jr += dj; c += dc;
             if (c >= W) { c -= W; jr++; }
