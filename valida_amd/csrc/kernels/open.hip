@@ -100,15 +100,36 @@ __global__ void __launch_bounds__(DOT_THREADS) k_col_dot(DMatView m, uint64_t n,
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t row0 = t * DOT_TR;
         const int rows = (int)((n - row0) < (uint64_t)DOT_TR ? (n - row0) : (uint64_t)DOT_TR);
-        for (int e = threadIdx.x; e < C * DOT_TR; e += DOT_THREADS) {
-            int r = e & (DOT_TR - 1), c = e / DOT_TR;
-            Mt[c * DOT_TRP + r] = r < rows ? m.data[(uint64_t)c * m.stride + row0 + r] : 0u;
+        {   // staging: a thread's row r = tid & 127 is fixed, its columns are c0, c0 + 2, ...: four loads in flight
+            const int r = threadIdx.x & (DOT_TR - 1);
+            const uint32_t* src = m.data + row0 + r;
+            uint32_t* dstp = Mt + r;
+            const bool live = r < rows;
+            int c = threadIdx.x / DOT_TR;  // 0 or 1
+            for (; c + 6 < C; c += 8) {
+                uint32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = live ? src[(uint64_t)(c + 2 * u) * m.stride] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) dstp[(c + 2 * u) * DOT_TRP] = v[u];
+            }
+            for (; c < C; c += 2) dstp[c * DOT_TRP] = live ? src[(uint64_t)c * m.stride] : 0u;
         }
-        for (int e = threadIdx.x; e < PK * DOT_TR; e += DOT_THREADS) {
-            int r = e & (DOT_TR - 1), pk = e / DOT_TR;
-            const uint32_t* w = pk < 5 ? w0 : w1;
-            int k = pk < 5 ? pk : pk - 5;
-            Wt[pk * DOT_TRP + r] = r < rows ? w[(uint64_t)k * n + row0 + r] : 0u;
+        {   // weights: same fixed-row scheme, all of a thread's limb loads issued before the LDS stores
+            const int r = threadIdx.x & (DOT_TR - 1);
+            const bool live = r < rows;
+            uint32_t v[(PK + 1) / 2];
+#pragma unroll
+            for (int u = 0; u < (PK + 1) / 2; u++) {
+                const int pk = (int)(threadIdx.x / DOT_TR) + 2 * u;
+                const uint32_t* w = pk < 5 ? w0 : w1;
+                v[u] = (live && pk < PK) ? w[(uint64_t)(pk < 5 ? pk : pk - 5) * n + row0 + r] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < (PK + 1) / 2; u++) {
+                const int pk = (int)(threadIdx.x / DOT_TR) + 2 * u;
+                if (pk < PK) Wt[pk * DOT_TRP + r] = v[u];
+            }
         }
         __syncthreads();
 #pragma unroll
