@@ -148,7 +148,10 @@ int32_t vgpu_perm_trace(vgpu_prover_t* p, uint32_t chip, const vgpu_trace_t* mai
 int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uint32_t beta[5], uint32_t* out);
 
 /* Machine::prove (basic/src/lib.rs:147-675).  main[i] = trace of chip i; preprocessed traces are given
- * with their chip indices in chip order (BasicMachine: program, range). */
+ * with their chip indices in chip order (BasicMachine: program, range).
+ * debug_flags: 1 = keep the per-chip intermediate matrices (vgpu_proof_debug_*); 2 = run check_constraints and
+ * check_cumulative_sums on the device before committing, as debug builds of the reference do (basic/src/lib.rs:270-375):
+ * a violated constraint fails the call with VGPU_ERR_INVALID_ARG and a message naming chip, constraint and row. */
 int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
                    const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t debug_flags, vgpu_proof_t** out);
 /* The same, asynchronously: returns at once, a host thread of its own drives this prover's streams.  Two provers on one

@@ -472,3 +472,56 @@ def test_async_prove_matches_sync_prove(machine, rc, fib25):
     with pytest.raises(va.VgpuError, match="one main trace per chip"):
         bad.wait()
     assert first_mismatch(provers[0].prove(*inputs[0]).words, ref) is None
+
+
+# ---- check_constraints / check_cumulative_sums on the device (debug builds of the reference, basic/src/lib.rs:270-375) ----
+@pytest.mark.parametrize("interpret", [False, True])
+def test_device_check_constraints(machine, rc, fib25, interpret):
+    p = va.Prover(machine, rc, interpret_air=interpret)
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    dprep = [(c, p.upload(m)) for c, m in prep]
+    ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc).words
+    ok = p.prove([p.upload(m) for m in mt], dprep, check=True)  # a valid witness passes and the proof is unchanged
+    assert first_mismatch(ok.words, ref) is None
+    for w in (va.Workload.alu(50), va.Workload.named("signed_inequality"), va.Workload.named("static_data")):
+        wp = w.preprocessed()
+        p.prove([p.upload(m) for m in w.main_traces()], [(c, p.upload(m)) for c, m in wp], check=True)
+
+    def failure(traces):
+        with pytest.raises(va.VgpuError) as e:
+            p.prove([p.upload(m) for m in traces], dprep, check=True)
+        return str(e.value)
+
+    bad = [m.copy() for m in mt]
+    bad[3][5, 11] = (int(bad[3][5, 11]) + 1) % P  # ADD32 row 5: output byte 0 (column 11) is off by one
+    msg = failure(bad)
+    assert "chip add" in msg.lower() and "row 5" in msg and ("AIR constraint 3" in msg if not interpret else "AIR constraint" in msg)
+    bad = [m.copy() for m in mt]
+    bad[12][7, 0] = (int(bad[12][7, 0]) + 1) % P  # one range multiplicity too many: every chip is fine, the bus is not
+    assert "cumulative sums" in failure(bad)
+    bad = [m.copy() for m in mt]
+    bad[0][100, 1] = (int(bad[0][100, 1]) + 4) % P  # the cpu's frame pointer jumps on row 100
+    msg = failure(bad)
+    assert "chip cpu" in msg.lower() and ("row 99" in msg or "row 100" in msg)
+
+
+def test_handles_may_be_freed_in_any_order(machine, rc, fib25):
+    # a garbage collector frees handles in arbitrary order: device objects keep their prover's context and pool alive
+    import gc
+
+    p = va.Prover(machine, rc)
+    t = p.upload(fib25.main_trace(0))
+    pd = p.commit_batches([t])
+    log = p.upload_oplog(fib25.oplog())
+    g = p.generate_trace(log, 0)
+    # drop the Python-side back references, then free the prover FIRST
+    for obj in (t, pd, log, g):
+        obj._prover = None
+    h = p._h
+    p._h = None
+    va.lib().vgpu_prover_destroy(h)
+    gc.collect()
+    del t, pd, log, g  # the buffers return to a pool that must still exist
+    gc.collect()
+    q = va.Prover(machine, rc)  # and the device is still usable
+    assert q.upload(fib25.main_trace(3)).shape == fib25.main_trace(3).shape

@@ -467,14 +467,15 @@ class Prover:
         _check(lib().vgpu_fri_fold(self._h, f.ctypes.data_as(c_u32p), ctypes.c_uint64(n), bp, out.ctypes.data_as(c_u32p)))
         return out
 
-    def prove(self, main, preprocessed, debug=False):
-        """main: list of DeviceTrace (chip order); preprocessed: list of (chip index, DeviceTrace)."""
+    def prove(self, main, preprocessed, debug=False, check=False):
+        """main: list of DeviceTrace (chip order); preprocessed: list of (chip index, DeviceTrace).
+        check: evaluate every constraint on the traces first (the reference's debug-build check_constraints)."""
         arr = (ctypes.c_void_p * len(main))(*[t._h for t in main])
         chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
         parr = (ctypes.c_void_p * max(1, len(preprocessed)))(*[t._h for _, t in preprocessed])
         h = ctypes.c_void_p()
-        _check(lib().vgpu_prove(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)), ctypes.c_uint32(1 if debug else 0),
-                                ctypes.byref(h)))
+        _check(lib().vgpu_prove(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)),
+                                ctypes.c_uint32((1 if debug else 0) | (2 if check else 0)), ctypes.byref(h)))
         return Proof(h)
 
     def prove_async(self, main, preprocessed):

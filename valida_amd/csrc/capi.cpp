@@ -25,12 +25,14 @@ static int32_t fail(int32_t code, const std::string& msg) { g_err = msg; return 
 struct vgpu_air { std::string name; vair::Dag dag; std::vector<vair::Interaction> interactions; };
 struct vgpu_machine { MachineDesc desc; };
 struct vgpu_challenger { std::unique_ptr<Poseidon16> perm; std::unique_ptr<Challenger> ch; };
-struct vgpu_prover { std::unique_ptr<Prover> p; };
-struct vgpu_trace { std::unique_ptr<DeviceTrace> t; };
-struct vgpu_pdata { std::unique_ptr<ProverData> pd; };
+// Device objects keep their prover (device context, memory pool) alive: a host may free handles in any order — a garbage
+// collector does — and a buffer must never outlive the pool it returns to.  `owner` is declared first, so it is destroyed last.
+struct vgpu_prover { std::shared_ptr<Prover> p; };
+struct vgpu_trace { std::shared_ptr<Prover> owner; std::unique_ptr<DeviceTrace> t; };
+struct vgpu_pdata { std::shared_ptr<Prover> owner; std::unique_ptr<ProverData> pd; };
 struct vgpu_ticket { std::future<std::pair<vgpu_proof_t*, std::pair<int32_t, std::string>>> result; };
 struct vgpu_proof { std::vector<uint32_t> words; PhaseTimes tm; ProveDebugOut dbg; };
-struct vgpu_oplog { std::unique_ptr<DeviceOplog> log; };
+struct vgpu_oplog { std::shared_ptr<Prover> owner; std::unique_ptr<DeviceOplog> log; };
 static_assert(sizeof(vgpu_cpu_op_t) == sizeof(vk::TgCpuOp) && sizeof(vgpu_mem_op_t) == sizeof(vk::TgMemOp) && sizeof(vgpu_alu_op_t) == sizeof(vk::TgAluOp),
               "C ABI log records and their device images must match");
 static_assert((int)VGPU_CPU_LOADFP == (int)vk::TG_CPU_LOADFP, "cpu op kinds");
@@ -262,10 +264,11 @@ int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap) {
 int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t height, uint64_t width, vgpu_trace_t** out) {
     VG_TRY({
         if (!p || !data || !out || !height || !width) throw std::invalid_argument("bad trace");
-        auto* t = new vgpu_trace();
+        std::unique_ptr<vgpu_trace> t(new vgpu_trace());
+        t->owner = p->p;
         p->p->ctx().activate();
         t->t = p->p->upload_trace(HostMatrix{data, height, width});
-        *out = t;
+        *out = t.release();
     })
 }
 void vgpu_trace_free(vgpu_trace_t* t) { delete t; }
@@ -293,9 +296,10 @@ int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_o
         for (uint64_t i = 0; i < h.n_cpu; i++)
             if (log->cpu[i].mem_first > h.n_mem || (i && log->cpu[i].mem_first < log->cpu[i - 1].mem_first) || log->cpu[i].kind > VGPU_CPU_LOADFP)
                 throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + " is malformed");
-        auto* l = new vgpu_oplog();
+        std::unique_ptr<vgpu_oplog> l(new vgpu_oplog());
+        l->owner = p->p;
         l->log = p->p->upload_oplog(h);
-        *out = l;
+        *out = l.release();
     })
 }
 void vgpu_oplog_free(vgpu_oplog_t* log) { delete log; }
@@ -303,9 +307,10 @@ int32_t vgpu_generate_trace(vgpu_prover_t* p, const vgpu_oplog_t* log, uint32_t 
     VG_TRY({
         if (!p || !log || !out) throw std::invalid_argument("null argument");
         p->p->ctx().activate();
-        auto* t = new vgpu_trace();
+        std::unique_ptr<vgpu_trace> t(new vgpu_trace());
+        t->owner = p->p;
         t->t = p->p->generate_trace(*log->log, (int)chip);
-        *out = t;
+        *out = t.release();
     })
 }
 
@@ -329,10 +334,11 @@ int32_t vgpu_commit_batches(vgpu_prover_t* p, const vgpu_trace_t* const* mats, u
         for (auto& m : nat) in.push_back({&m, false, false});
         std::vector<Fp> shifts;
         if (coset_shifts) for (uint32_t i = 0; i < n_mats; i++) shifts.push_back(Fp::from_canonical(coset_shifts[i]));
-        auto* pd = new vgpu_pdata();
+        std::unique_ptr<vgpu_pdata> pd(new vgpu_pdata());
+        pd->owner = p->p;
         pd->pd = commit_batches(&c, in, coset_shifts ? &shifts : nullptr, p->p->fri());
         memcpy(root, pd->pd->tree.root, 32);
-        *out = pd;
+        *out = pd.release();
     })
 }
 int32_t vgpu_pdata_lde(vgpu_prover_t* p, const vgpu_pdata_t* pd, uint32_t idx, uint32_t* out, uint64_t cap_words) {
@@ -412,6 +418,7 @@ int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n
         for (uint32_t i = 0; i < n_prep; i++) pr.push_back({(int)prep_chips[i], prep[i]->t.get()});
         auto proof = std::make_unique<vgpu_proof>();
         proof->dbg.keep_matrices = (debug_flags & 1) != 0;
+        proof->dbg.check_constraints = (debug_flags & 2) != 0;
         proof->words = p->p->prove(m, pr, &proof->tm, &proof->dbg);
         *out = proof.release();
     })

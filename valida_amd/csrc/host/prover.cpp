@@ -291,6 +291,61 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             c.download(dbg->perm_traces[i].data(), tmp.data, dbg->perm_traces[i].size() * 4);
         }
     }
+    if (dbg && dbg->check_constraints) {
+        // check_constraints per chip (basic/src/lib.rs:270-372) and check_cumulative_sums (:373-375), as debug builds of the
+        // reference do before committing: every AIR / permutation constraint on the trace itself.  The fold of the permutation
+        // constraints uses powers of the third permutation challenge (any nonzero element serves a check).
+        std::vector<uint32_t> pool;
+        std::vector<size_t> off(NC);
+        std::vector<uint32_t> Ks(NC);
+        for (size_t i = 0; i < NC; i++) {
+            auto& air = machine_.airs[i];
+            uint32_t M = (uint32_t)air.interactions.size(), K = air.program.num_asserts + M + 3;
+            Ks[i] = K;
+            off[i] = pool.size();
+            Ext5 pw = Ext5::one();
+            std::vector<Ext5> ap(K);
+            for (uint32_t k = 0; k < K; k++) { ap[K - 1 - k] = pw; pw *= rnd[2]; }
+            for (auto& e : ap) put_ext(pool, e);
+            for (auto& e : bus_alphas[i]) put_ext(pool, e);
+            for (auto& e : betas[i]) put_ext(pool, e);
+            put_ext(pool, cumulative_sums[i]);
+        }
+        DBuf pool_dev(&c, pool);
+        std::vector<uint32_t> init(2 * NC, 0xffffffffu);
+        DBuf bad_dev(&c, init);
+        for (size_t i = 0; i < NC; i++) {
+            auto& air = machine_.airs[i];
+            vk::QuotientArgs a{};
+            a.main_lde = main_nat[i]->view();
+            a.perm_lde = perm_nat[i].view();
+            a.prep_lde = prep_slot[i] >= 0 ? prep_nat[prep_slot[i]].view() : vk::DMatView{nullptr, 0, 0, 0};
+            a.log_n = (int)log_deg[i];
+            a.prog = (const vair::Instr*)prog_dev_[i].data;
+            a.n_instrs = (uint32_t)air.program.instrs.size();
+            a.n_regs = air.program.num_regs;
+            a.n_air_asserts = air.program.num_asserts;
+            a.iw = iw_dev_[i].data;
+            a.consts = pool_dev.data + off[i];
+            a.K = Ks[i];
+            a.native_chip = fri_.interpret_air ? vk::QuotientArgs::INTERPRET : air.native_chip;
+            vk::launch_check_constraints(c.stream, a, reinterpret_cast<unsigned long long*>(bad_dev.data) + i);
+        }
+        c.check_launch("check_constraints");
+        std::vector<uint32_t> bad(2 * NC);
+        c.download(bad.data(), bad_dev.data, bad.size() * 4);
+        for (size_t i = 0; i < NC; i++) {
+            const uint64_t v = ((uint64_t)bad[2 * i + 1] << 32) | bad[2 * i];
+            if (v == ~0ull) continue;
+            const uint64_t row = v >> 16;
+            const uint32_t code = (uint32_t)(v & 0xffff);
+            std::string what = code == 0xFFFE ? "a permutation (bus) constraint" : code == 0xFFFD ? "an AIR constraint" : "AIR constraint " + std::to_string(code);
+            throw std::invalid_argument("check_constraints: chip " + machine_.airs[i].name + ": " + what + " is not satisfied on row " + std::to_string(row));
+        }
+        Ext5 total = Ext5::zero();
+        for (auto& s5 : cumulative_sums) total += s5;
+        if (!total.is_zero()) throw std::invalid_argument("check_cumulative_sums: the chips' cumulative sums do not cancel (a bus is unbalanced)");
+    }
     t0 = Clock::now();
     std::unique_ptr<ProverData> perm_pd;
     {

@@ -50,6 +50,7 @@ struct PhaseTimes {  // milliseconds, host clock around stream syncs
 struct ProveDebugOut {  // optional intermediate values for stage-parity tests (canonical words)
     uint32_t prep_root[8];
     uint32_t perm_challenges[15], alpha[5], zeta[5];
+    bool check_constraints = false;                      // check_constraints + check_cumulative_sums before committing (debug builds of the reference)
     bool keep_matrices = false;                          // when set, the vectors below are filled (D2H copies)
     std::vector<std::vector<uint32_t>> perm_traces;      // per chip: n x 5(M+1) row-major, natural order
     std::vector<std::vector<uint32_t>> quotient_chunks;  // per chip: n x 10 row-major, natural order

@@ -53,6 +53,9 @@ void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint3
                        uint32_t* scratch);
 // quotient.hip
 void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& tb);
+// Debug check on the trace domain: `a` carries the NATURAL-order traces in main_lde / perm_lde / prep_lde (log_n = log height);
+// *first_bad_dev (initialised to ~0) receives min over failures of (row << 16 | code), see quotient.hip.
+void launch_check_constraints(hipStream_t st, const QuotientArgs& a, unsigned long long* first_bad_dev);
 // tracegen.hip — device images of the VM's operation logs (C ABI twins: vgpu_cpu_op_t, vgpu_mem_op_t, vgpu_alu_op_t)
 struct TgCpuOp { uint32_t pc, fp, opcode; int32_t operands[5]; uint32_t kind, has_imm, imm, mem_first; };
 struct TgMemOp { uint32_t clk, addr, value, is_write; };

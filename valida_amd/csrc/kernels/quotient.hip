@@ -243,6 +243,77 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
     }
 }
 
+// ---- debug check of the witness (machine/src/check_constraints.rs via basic/src/lib.rs:270-372, debug builds) ---------
+// Every constraint evaluated on the TRACE domain itself: row r, next = r + 1 mod n, is_first / is_last / is_transition as
+// 0/1 selectors (DebugConstraintBuilder, machine/src/debug_builder.rs:7-114).  The first failing (row, constraint) is
+// reported through an atomicMin on (row << 16 | code): code = index of the chip's AIR constraint (native chips),
+// 0xFFFD = some AIR constraint of an interpreted program, 0xFFFE = a permutation / running-sum constraint.
+struct DebugFolder {
+    using Expr = Fp;
+    const uint32_t* __restrict__ main_p;
+    const uint32_t* __restrict__ main_n;
+    uint64_t mstride;
+    const uint32_t* __restrict__ prep_p;
+    const uint32_t* __restrict__ prep_n;
+    uint64_t pstride;
+    Fp first, last, trans;
+    uint32_t k, bad;
+    __device__ __forceinline__ Fp constant(uint32_t c) const { return Fp::from_canonical(c); }
+    __device__ __forceinline__ Fp main(int col, bool next) const { return Fp::raw((next ? main_n : main_p)[(uint64_t)col * mstride]); }
+    __device__ __forceinline__ Fp preprocessed(int col, bool next) const { return Fp::raw((next ? prep_n : prep_p)[(uint64_t)col * pstride]); }
+    __device__ __forceinline__ Fp is_first_row() const { return first; }
+    __device__ __forceinline__ Fp is_last_row() const { return last; }
+    __device__ __forceinline__ Fp is_transition() const { return trans; }
+    __device__ __forceinline__ void assert_zero(const Fp& e) { if (!e.is_zero() && bad == 0xffffffffu) bad = k; k++; }
+};
+
+template <int CHIP>  // vchips::ChipId, -1 = no AIR constraints, QuotientArgs::INTERPRET = interpreted program (LDS register file)
+__global__ void __launch_bounds__(256) k_check_constraints(QuotientArgs a, unsigned long long* __restrict__ first_bad) {
+    extern __shared__ uint32_t regs[];
+    const uint64_t n = 1ull << a.log_n;
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    PointCtx p;
+    p.row = r; p.next_row = (r + 1) & (n - 1);
+    p.is_first = r == 0 ? Fp::one() : Fp::zero();
+    p.is_last = r == n - 1 ? Fp::one() : Fp::zero();
+    p.is_trans = r == n - 1 ? Fp::zero() : Fp::one();
+    uint32_t code = 0xffffffffu;
+    if (CHIP == QuotientArgs::INTERPRET) {
+        if (!run_program_lds(a, p, regs).is_zero()) code = 0xFFFDu;  // random fold of all AIR constraints
+    } else if (CHIP >= 0) {
+        DebugFolder f;
+        f.main_p = a.main_lde.data + p.row; f.main_n = a.main_lde.data + p.next_row; f.mstride = a.main_lde.stride;
+        f.prep_p = a.prep_lde.data + p.row; f.prep_n = a.prep_lde.data + p.next_row; f.pstride = a.prep_lde.stride;
+        f.first = p.is_first; f.last = p.is_last; f.trans = p.is_trans;
+        f.k = 0; f.bad = 0xffffffffu;
+        vchips::eval_chip(CHIP, f);
+        code = f.bad;
+    }
+    if (code == 0xffffffffu && !perm_constraints(a, p).is_zero()) code = 0xFFFEu;
+    if (code != 0xffffffffu) atomicMin(first_bad, (unsigned long long)((r << 16) | code));
+}
+
+void launch_check_constraints(hipStream_t st, const QuotientArgs& a, unsigned long long* first_bad_dev) {
+    const uint64_t n = 1ull << a.log_n;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    ProfScope ps("k_check_constraints", st, 4.0 * n * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width));
+    switch (a.native_chip) {
+#define VG_CHECK(C) case vchips::C: hipLaunchKernelGGL((k_check_constraints<vchips::C>), grid, block, 0, st, a, first_bad_dev); break;
+        VG_CHECK(CHIP_CPU) VG_CHECK(CHIP_ADD) VG_CHECK(CHIP_SUB) VG_CHECK(CHIP_MUL) VG_CHECK(CHIP_SHIFT) VG_CHECK(CHIP_LT)
+        VG_CHECK(CHIP_COM) VG_CHECK(CHIP_BITWISE) VG_CHECK(CHIP_OUTPUT) VG_CHECK(CHIP_STATIC_DATA)
+#undef VG_CHECK
+        case QuotientArgs::INTERPRET: {
+            unsigned threads = 256;
+            while (threads > 64 && (size_t)a.n_regs * threads * 4 > 64 * 1024) threads >>= 1;
+            hipLaunchKernelGGL((k_check_constraints<QuotientArgs::INTERPRET>), dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), (size_t)a.n_regs * threads * 4, st, a,
+                               first_bad_dev);
+            break;
+        }
+        default: hipLaunchKernelGGL((k_check_constraints<-1>), grid, block, 0, st, a, first_bad_dev); break;
+    }
+}
+
 void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& tb) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
