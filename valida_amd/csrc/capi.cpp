@@ -28,7 +28,7 @@ struct vgpu_challenger { std::unique_ptr<Poseidon16> perm; std::unique_ptr<Chall
 // Device objects keep their prover (device context, memory pool) alive: a host may free handles in any order — a garbage
 // collector does — and a buffer must never outlive the pool it returns to.  `owner` is declared first, so it is destroyed last.
 struct vgpu_prover { std::shared_ptr<Prover> p; };
-struct vgpu_trace { std::shared_ptr<Prover> owner; std::unique_ptr<DeviceTrace> t; };
+struct vgpu_trace { std::shared_ptr<Prover> owner; std::shared_ptr<DeviceTrace> t; };  // shared: an asynchronous prove holds its inputs
 struct vgpu_pdata { std::shared_ptr<Prover> owner; std::unique_ptr<ProverData> pd; };
 struct vgpu_ticket { std::future<std::pair<vgpu_proof_t*, std::pair<int32_t, std::string>>> result; };
 struct vgpu_proof { std::vector<uint32_t> words; PhaseTimes tm; ProveDebugOut dbg; };
@@ -431,17 +431,37 @@ int32_t vgpu_prove_async(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint
                          uint32_t n_prep, vgpu_ticket_t** out) {
     VG_TRY({
         if (!p || !main || !out) throw std::invalid_argument("null argument");
-        std::vector<const vgpu_trace_t*> m(main, main + n_main), pr(prep, prep + n_prep);
-        std::vector<uint32_t> chips(prep_chips, prep_chips + n_prep);
-        auto* t = new vgpu_ticket();
-        t->result = std::async(std::launch::async, [p, m, pr, chips]() {
+        // the job owns what it works on (the prover first: destroyed last), so freeing handles meanwhile is harmless
+        struct Job {
+            std::shared_ptr<Prover> prover;
+            std::vector<std::shared_ptr<DeviceTrace>> main, prep;
+            std::vector<int> chips;
+        };
+        auto job = std::make_shared<Job>();
+        job->prover = p->p;
+        for (uint32_t i = 0; i < n_main; i++) { if (!main[i]) throw std::invalid_argument("null trace"); job->main.push_back(main[i]->t); }
+        for (uint32_t i = 0; i < n_prep; i++) { if (!prep[i]) throw std::invalid_argument("null trace"); job->prep.push_back(prep[i]->t); job->chips.push_back((int)prep_chips[i]); }
+        std::unique_ptr<vgpu_ticket> t(new vgpu_ticket());
+        t->result = std::async(std::launch::async, [job]() {
             std::pair<int32_t, std::string> status{VGPU_OK, ""};
             vgpu_proof_t* proof = nullptr;
-            int32_t rc = vgpu_prove(p, m.data(), (uint32_t)m.size(), chips.data(), pr.data(), (uint32_t)pr.size(), 0, &proof);
-            if (rc != VGPU_OK) status = {rc, vgpu_last_error()};  // thread-local message of the worker thread
+            try {
+                std::vector<const DeviceTrace*> m;
+                for (auto& x : job->main) m.push_back(x.get());
+                std::vector<std::pair<int, const DeviceTrace*>> pr;
+                for (size_t i = 0; i < job->prep.size(); i++) pr.push_back({job->chips[i], job->prep[i].get()});
+                auto out = std::make_unique<vgpu_proof>();
+                out->words = job->prover->prove(m, pr, &out->tm, &out->dbg);
+                proof = out.release();
+            } catch (const std::invalid_argument& e) { status = {VGPU_ERR_INVALID_ARG, e.what()};
+            } catch (const std::bad_alloc& e) { status = {VGPU_ERR_OOM, e.what()};
+            } catch (const std::exception& e) {
+                std::string msg = e.what();
+                status = {msg.find("hip") != std::string::npos ? VGPU_ERR_HIP : VGPU_ERR_INTERNAL, msg};
+            }
             return std::make_pair(proof, status);
         });
-        *out = t;
+        *out = t.release();
     })
 }
 int32_t vgpu_ticket_wait(vgpu_ticket_t* t, vgpu_proof_t** out) {
