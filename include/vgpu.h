@@ -120,6 +120,9 @@ int32_t vgpu_prover_create(const vgpu_config_t* cfg, const vgpu_machine_t* machi
 void vgpu_prover_destroy(vgpu_prover_t* p);
 /* bytes currently held / peak in the HBM pool */
 void vgpu_prover_memory(const vgpu_prover_t* p, uint64_t* live_bytes, uint64_t* peak_bytes);
+/* The prover caches device blocks by size and reuses them (no hipMalloc in the steady state).  Returns the cached-but-unused
+ * blocks to the driver (bytes freed); also done automatically, once, when an allocation runs out of memory. */
+uint64_t vgpu_prover_trim(vgpu_prover_t* p);
 
 /* per-kernel HIP-event timing (bench): switch on/off (resets the accumulators); the profile is text,
  * one line per kernel: "name launches total_ms total_algorithmic_bytes".  Returns the size needed. */

@@ -525,3 +525,15 @@ def test_handles_may_be_freed_in_any_order(machine, rc, fib25):
     gc.collect()
     q = va.Prover(machine, rc)  # and the device is still usable
     assert q.upload(fib25.main_trace(3)).shape == fib25.main_trace(3).shape
+
+
+def test_pool_trim_returns_cached_blocks(machine, rc, fib25):
+    p = va.Prover(machine, rc)
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    dmain = [p.upload(m) for m in mt]
+    dprep = [(c, p.upload(m)) for c, m in prep]
+    a = p.prove(dmain, dprep)
+    live_before, _ = p.memory()
+    freed = p.trim()
+    assert freed > 0 and p.memory()[0] == live_before  # live blocks (the uploaded traces) untouched
+    assert p.prove(dmain, dprep).bytes() == a.bytes()     # and the prover simply allocates again

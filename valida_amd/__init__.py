@@ -501,6 +501,11 @@ class Prover:
             out[name] = (int(launches), float(ms), float(nbytes), float(ops))
         return out
 
+    def trim(self):
+        """Give the pool's cached free blocks back to the driver; returns the bytes freed."""
+        lib().vgpu_prover_trim.restype = ctypes.c_uint64
+        return int(lib().vgpu_prover_trim(self._h))
+
     def memory(self):
         live, peak = ctypes.c_uint64(), ctypes.c_uint64()
         lib().vgpu_prover_memory(self._h, ctypes.byref(live), ctypes.byref(peak))

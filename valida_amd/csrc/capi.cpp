@@ -238,6 +238,12 @@ void vgpu_prover_memory(const vgpu_prover_t* p, uint64_t* live, uint64_t* peak) 
     if (live) *live = c.live;
     if (peak) *peak = c.peak_live;
 }
+uint64_t vgpu_prover_trim(vgpu_prover_t* p) {
+    if (!p) return 0;
+    DeviceCtx& c = p->p->ctx();
+    (void)hipSetDevice(c.device);
+    return (uint64_t)c.trim();
+}
 void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on) {
     auto& c = p->p->ctx();
     c.profiler.reset();

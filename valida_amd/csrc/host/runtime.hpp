@@ -2,6 +2,7 @@
 // same few dozen buffers every time — after the first proof nothing in the timed path calls hipMalloc),
 // pinned staging memory, and the column-major device matrix type.
 #pragma once
+#include <new>
 #include <cstdio>
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -70,11 +71,30 @@ struct DeviceCtx {
         auto it = free_blocks.find(bytes);
         void* p;
         if (it != free_blocks.end()) { p = it->second; free_blocks.erase(it); }
-        else { VG_HIP_CHECK(hipMalloc(&p, bytes)); bytes_allocated += bytes; }
+        else {
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e == hipErrorOutOfMemory) {  // cached blocks of other sizes may be holding the memory: give them back, retry once
+                (void)hipGetLastError();
+                trim();
+                e = hipMalloc(&p, bytes);
+            }
+            if (e != hipSuccess) throw std::bad_alloc();
+            bytes_allocated += bytes;
+        }
         live_blocks[p] = bytes;
         live += bytes;
         if (live > peak_live) peak_live = live;
         return p;
+    }
+    // Return every cached (free) block to the driver; live blocks are untouched.  Synchronises the device first: a cached
+    // block may still be read by work in flight.
+    size_t trim() {
+        (void)hipDeviceSynchronize();
+        size_t freed = 0;
+        for (auto& kv : free_blocks) { (void)hipFree(kv.second); freed += kv.first; }
+        free_blocks.clear();
+        bytes_allocated -= freed;
+        return freed;
     }
     // Fork: aux streams wait for everything enqueued so far on the main stream.
     void fork() {
