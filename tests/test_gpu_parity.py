@@ -537,3 +537,13 @@ def test_pool_trim_returns_cached_blocks(machine, rc, fib25):
     freed = p.trim()
     assert freed > 0 and p.memory()[0] == live_before  # live blocks (the uploaded traces) untouched
     assert p.prove(dmain, dprep).bytes() == a.bytes()     # and the prover simply allocates again
+
+
+def test_lde_height_beyond_two_adicity_is_rejected(machine, rc):
+    # BabyBear has no multiplicative subgroup of order 2^28: the reference would panic inside two_adic_generator
+    p = va.Prover(machine, rc, log_blowup=2)
+    t = p.upload(np.zeros((1 << 26, 1), dtype=np.uint32))
+    with pytest.raises(va.VgpuError, match="two-adicity"):
+        p.commit_batches([t])
+    small = np.arange(64, dtype=np.uint32).reshape(16, 4) % P
+    assert first_mismatch(p.commit_batches([p.upload(small)]).root, po.commit_root([small], log_blowup=2)) is None

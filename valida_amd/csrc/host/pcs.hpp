@@ -108,6 +108,9 @@ struct CommitInput {
 // Returns the bit-reversed LDE on lde_shift * H_{n << log_blowup}.
 inline DMat coset_lde(DeviceCtx* c, hipStream_t st, const CommitInput& in, unsigned log_blowup, Fp lde_shift) {
     const uint64_t n = in.mat->height, b = 1ull << log_blowup;
+    if (n == 0 || (n & (n - 1))) throw std::invalid_argument("commit: matrix heights must be powers of two");
+    if (vg::log2_strict_u64(n) + log_blowup > 27)  // BabyBear's two-adicity: no larger multiplicative subgroup exists
+        throw std::invalid_argument("commit: LDE height 2^" + std::to_string(vg::log2_strict_u64(n) + log_blowup) + " exceeds the field's two-adicity (2^27)");
     DMat coeffs;
     if (in.rows_bitrev && in.consume) coeffs = std::move(*in.mat);
     else {
