@@ -7,12 +7,11 @@
 //   lt       alu_u32/src/lt/mod.rs:87-166             bitwise  alu_u32/src/bitwise/mod.rs:84-129
 // One thread per trace row; every column is written straight into the column-major Montgomery matrix the
 // commitment phase consumes (natural row order), so neither the 516 MB row-major upload nor k_ingest is needed.
-// The memory chip's (addr, clk) order is a stable LSD radix sort of the clk-ordered log by address (rocPRIM).
+// The memory chip's (addr, clk) order is a stable LSD radix sort (4 passes of 8 bits) of the clk-ordered log by address.
 #include <algorithm>
 #include <cstring>
 #include "launch.hpp"
 #include "../chips/basic_machine.hpp"
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace vk {
 
@@ -222,23 +221,107 @@ void launch_tracegen_cpu(hipStream_t st, const TgCpuOp* ops, uint64_t n, const T
     hipLaunchKernelGGL(k_tracegen_cpu, dim3(blocks_for(t.height)), dim3(256), 0, st, ops, n, mem, n_mem, t);
 }
 
-size_t tracegen_mem_sort_scratch_bytes(uint64_t n) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
-    return bytes;
+// ---- stable LSD radix sort of (address, index) pairs: 4 passes x 8 bits ----------------------------------------------
+// A block owns RS_ITEMS * 256 consecutive pairs.  Pass = (1) per-block digit histograms (LDS atomics), (2) exclusive scan
+// of the digit-major table counts[digit][block], (3) scatter: the block walks its pairs in order, 256 at a time; a pair's
+// slot is table base + pairs of that digit seen in earlier rounds + earlier waves of the round + lower lanes of its wave
+// (eight ballots isolate the lanes holding the same digit) — which keeps equal keys in input order.
+constexpr int RS_ITEMS = 32, RS_BLOCK = RS_ITEMS * 256;
+
+__global__ void __launch_bounds__(256) k_rs_count(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t* __restrict__ counts, uint32_t n_blocks) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * RS_BLOCK;
+#pragma unroll
+    for (int u = 0; u < RS_ITEMS; u++) {
+        const uint64_t i = base + u * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// In-place exclusive scan of `total` counters by one 1024-thread block (contiguous chunk per thread).
+__global__ void __launch_bounds__(1024) k_rs_scan(uint32_t* __restrict__ counts, uint64_t total) {
+    __shared__ uint32_t sums[1024];
+    const uint64_t chunk = (total + 1023) / 1024, lo = (uint64_t)threadIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
+    uint32_t s = 0;
+    for (uint64_t i = lo; i < hi; i++) s += counts[i];
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t t = sums[threadIdx.x];
+        if ((int)threadIdx.x >= off) t += sums[threadIdx.x - off];
+        __syncthreads();
+        sums[threadIdx.x] = t;
+        __syncthreads();
+    }
+    uint32_t run = sums[threadIdx.x] - s;  // exclusive prefix of this thread's chunk
+    for (uint64_t i = lo; i < hi; i++) { const uint32_t c = counts[i]; counts[i] = run; run += c; }
+}
+
+__global__ void __launch_bounds__(256) k_rs_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n, int shift,
+                                                    const uint32_t* __restrict__ counts, uint32_t n_blocks, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t base[256], wcount[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    base[threadIdx.x] = counts[(uint64_t)threadIdx.x * n_blocks + blockIdx.x];
+    const uint64_t first = (uint64_t)blockIdx.x * RS_BLOCK;
+    for (int u = 0; u < RS_ITEMS; u++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) wcount[w][threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t i = first + u * 256 + threadIdx.x;
+        const bool live = i < n;
+        const uint32_t key = live ? keys[i] : 0u, val = live ? vals[i] : 0u, d = (key >> shift) & 255u;
+        unsigned long long peers = __ballot(live);  // lanes of this wave holding a live pair with the same digit
+#pragma unroll
+        for (int b = 0; b < 8; b++) { const unsigned long long bal = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? bal : ~bal; }
+        const uint32_t rank_in_wave = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (live && rank_in_wave == 0) wcount[wave][d] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (live) {
+            uint32_t before = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) if (w < wave) before += wcount[w][d];
+            const uint32_t pos = base[d] + before + rank_in_wave;
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        base[threadIdx.x] += wcount[0][threadIdx.x] + wcount[1][threadIdx.x] + wcount[2][threadIdx.x] + wcount[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// scratch words for the digit tables of an n-pair sort
+size_t tracegen_mem_sort_scratch_bytes(uint64_t n) { return (size_t)256 * ((n + RS_BLOCK - 1) / RS_BLOCK) * 4; }
+
+// keys2 / vals2: [2n] each (ping-pong halves, input in the first half); after four passes the result is back in the FIRST half.
+static void radix_sort_pairs(hipStream_t st, uint32_t* keys2, uint32_t* vals2, uint64_t n, uint32_t* counts) {
+    const uint32_t n_blocks = (uint32_t)((n + RS_BLOCK - 1) / RS_BLOCK);
+    for (int pass = 0; pass < 4; pass++) {
+        uint32_t* kin = keys2 + (pass & 1) * n;
+        uint32_t* vin = vals2 + (pass & 1) * n;
+        uint32_t* kout = keys2 + ((pass + 1) & 1) * n;
+        uint32_t* vout = vals2 + ((pass + 1) & 1) * n;
+        hipLaunchKernelGGL(k_rs_count, dim3(n_blocks), dim3(256), 0, st, (const uint32_t*)kin, n, 8 * pass, counts, n_blocks);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, counts, (uint64_t)256 * n_blocks);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(n_blocks), dim3(256), 0, st, (const uint32_t*)kin, (const uint32_t*)vin, n, 8 * pass, (const uint32_t*)counts, n_blocks, kout, vout);
+    }
 }
 
 // keys/idx: 2 x n words each (in, out); sort_tmp: tracegen_mem_sort_scratch_bytes(n)
 hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, const uint32_t* static_cells, uint64_t n_static, uint32_t* keys2, uint32_t* idx2,
                                void* sort_tmp, size_t sort_tmp_bytes, DMatView t) {
     if (n) {
-        ProfScope ps("k_tracegen_mem_sort", st, 16.0 * n + 4.0 * 8.0 * n);
+        ProfScope ps("k_tracegen_mem_sort", st, 16.0 * n + 4.0 * 8.0 * 2.0 * n);
+        if (sort_tmp_bytes < tracegen_mem_sort_scratch_bytes(n)) return hipErrorInvalidValue;
         hipLaunchKernelGGL(k_tg_mem_keys, dim3(blocks_for(n)), dim3(256), 0, st, mem, n, keys2, idx2);
-        hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, (const uint32_t*)keys2, keys2 + n, (const uint32_t*)idx2, idx2 + n, (size_t)n, 0, 32, st);
-        if (e != hipSuccess) return e;
+        radix_sort_pairs(st, keys2, idx2, n, (uint32_t*)sort_tmp);
     }
     ProfScope ps("k_tracegen_mem", st, 20.0 * n + 4.0 * t.height * t.width);
-    hipLaunchKernelGGL(k_tracegen_mem, dim3(blocks_for(t.height)), dim3(256), 0, st, mem, (const uint32_t*)(idx2 + n), n, static_cells, n_static, t);
+    hipLaunchKernelGGL(k_tracegen_mem, dim3(blocks_for(t.height)), dim3(256), 0, st, mem, (const uint32_t*)idx2, n, static_cells, n_static, t);
     return hipSuccess;
 }
 
