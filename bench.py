@@ -99,12 +99,12 @@ def cpu_baseline(log_rows, rc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 of the padded CPU-chip height (20 = the headline workload)")
     ap.add_argument("--cpu-log-rows", type=int, default=17, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="proofs in flight per GPU: M prover contexts (own HIP streams and pool), one asynchronous proof outstanding on each "
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
     ap.add_argument("--no-extra-legs", action="store_true",

@@ -29,9 +29,13 @@ struct DeviceCtx {
     vk::Profiler profiler;
     // Auxiliary streams for fork/join sections: independent per-chip pipelines (tiny matrices are
     // latency-bound single-block launches) overlap with the big chips' kernels on the main stream.
-    static constexpr int NUM_AUX = 3;
-    hipStream_t aux[NUM_AUX] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[NUM_AUX] = {nullptr, nullptr, nullptr};
+    // One auxiliary stream.  The device exposes a handful of hardware queues (4 by default) that streams take in creation
+    // order; measured on MI355X with several prover contexts per GPU: 1 aux stream per context beats 0, 2 and 3 (with 3,
+    // the main streams of two contexts land on the same queue and the proofs meant to overlap serialise), and raising
+    // GPU_MAX_HW_QUEUES beyond the number of streams hurts.  DESIGN.md "Measurement".
+    static constexpr int NUM_AUX = 1;
+    hipStream_t aux[NUM_AUX] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[NUM_AUX] = {};
     bool in_section = false;
     std::vector<void*> deferred;  // blocks released inside a section return to the pool at the join
 
