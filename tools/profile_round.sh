@@ -15,7 +15,7 @@ B="python $ROOT/bench.py --no-cpu-baseline"
 $B > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 $B --inflight 1 > "$OUT/bench_inflight1.json" 2> "$OUT/bench_inflight1.err"
 # 1) kernel trace + stats of the default command and of the one-proof-in-flight command
-rocprofv3 --kernel-trace --stats -d "$OUT/stats2" -o run -- $B --no-extra-legs --steps 20 --warmup 2 > "$OUT/stats2.json" 2> "$OUT/stats2.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats2" -o run -- $B --no-extra-legs --steps 24 --warmup 3 > "$OUT/stats2.json" 2> "$OUT/stats2.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats1" -o run -- $B --no-extra-legs --inflight 1 --steps 10 --warmup 1 > "$OUT/stats1.json" 2> "$OUT/stats1.err"
 # 2) counters, separate passes, one proof in flight, few steps
 P="$B --inflight 1 --steps 2 --warmup 1"

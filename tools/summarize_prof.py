@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 (rocpd SQLite) outputs of tools/profile_round.sh into the small tracked summaries under
 profiles/:   python tools/summarize_prof.py r01 [outdir]
-  profiles/<tag>_kernel_stats_inflight{1,2}.csv   per-kernel calls / total / average duration (us)
+  profiles/<tag>_kernel_stats_{inflight1,default}.csv   per-kernel calls / total / average duration (us)
   profiles/<tag>_pmc.json                          per-kernel counters per launch: VALU instructions, issue
                                                    utilisation, HBM bytes (FETCH_SIZE / WRITE_SIZE, corrected as
                                                    /opt/skills/guides/MI355X_MICROARCH.md prescribes)
@@ -60,10 +60,10 @@ def main():
     dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     for leg, cmd in (("stats1", "python bench.py --no-cpu-baseline --no-extra-legs --inflight 1 --steps 10 --warmup 1"),
-                     ("stats2", "python bench.py --no-cpu-baseline --no-extra-legs --steps 20 --warmup 2")):
+                     ("stats2", "python bench.py --no-cpu-baseline --no-extra-legs --steps 24 --warmup 3")):
         p = db_of(os.path.join(src, leg))
         if p:
-            kernel_stats(p, os.path.join(dst, "%s_kernel_stats_inflight%s.csv" % (tag, leg[-1])), "rocprofv3 --kernel-trace --stats -- " + cmd + "   (MI355X)")
+            kernel_stats(p, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, "inflight1" if leg == "stats1" else "default")), "rocprofv3 --kernel-trace --stats -- " + cmd + "   (MI355X)")
     for f in ("bench_default.json", "bench_inflight1.json", "bench_full.json", "bench_c3.json", "bench_c4.json", "stats1.json", "stats2.json"):
         p = os.path.join(src, f)
         if os.path.exists(p) and os.path.getsize(p):
