@@ -547,3 +547,15 @@ def test_lde_height_beyond_two_adicity_is_rejected(machine, rc):
         p.commit_batches([t])
     small = np.arange(64, dtype=np.uint32).reshape(16, 4) % P
     assert first_mismatch(p.commit_batches([p.upload(small)]).root, po.commit_root([small], log_blowup=2)) is None
+
+
+@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(40)])
+def test_blowup8_proof_bytes(machine, rc, make):
+    # FriConfig.log_blowup = 3: the quotient domain is a strided subset of the LDE (machine/src/quotient.rs:41-47)
+    p8 = va.Prover(machine, rc, log_blowup=3)
+    w = make()
+    mt, prep = w.main_traces(), w.preprocessed()
+    proof = p8.prove([p8.upload(m) for m in mt], [(c, p8.upload(m)) for c, m in prep])
+    ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc, log_blowup=3)
+    assert first_mismatch(proof.words, ref.words) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc, log_blowup=3) is None
