@@ -322,7 +322,7 @@ def main():
                 "note": "main traces uploaded from pageable host memory inside every step; not the headline value"},
             "from_operation_logs": None if oplog_ms is None else {"ms_per_step": oplog_ms, "value": world * 1e3 / oplog_ms, "unit": "proofs/s",
                                     "h2d_bytes_per_step": int(48 * oplog.n_cpu + 16 * oplog.n_mem + 16 * sum(oplog.n_alu) + sum(mt[c].nbytes for c in small)),
-                                    "note": "operation logs uploaded and cpu/mem/add/sub/lt/bitwise traces generated on the device inside every step "
+                                    "note": "operation logs uploaded and all 14 chip traces generated on the device inside every step "
                                             "(replaces host generate_trace, reported as tracegen_s, and the row-major upload)"},
             "prover_ms_single_proof_in_flight": single if single is not None else ms_per_step,
             "proof_words": int(p.words.size),

@@ -209,8 +209,10 @@ typedef struct vgpu_oplog_desc {
 typedef struct vgpu_oplog vgpu_oplog_t;
 int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_oplog_t** out);
 void vgpu_oplog_free(vgpu_oplog_t* log);
-/* chip: cpu (0), program (1), mem (2), add (3), sub (4), lt (8), bitwise (10), range (12); any other chip -> VGPU_ERR_INVALID_ARG (generate it on the
- * host and vgpu_trace_upload it).  The returned trace is already in the prover's working layout (no ingest pass). */
+/* Any chip of the BasicMachine: cpu, program, mem, add, sub, lt, bitwise, range from their logs; static_data from the
+ * initialised cells; mul, div, shift, com, output as the padding-only trace of a chip that received no operation (the log
+ * format carries none for them — a program that uses them generates those traces on the host and vgpu_trace_upload's them).
+ * The returned trace is already in the prover's working layout (no ingest pass). */
 int32_t vgpu_generate_trace(vgpu_prover_t* p, const vgpu_oplog_t* log, uint32_t chip, vgpu_trace_t** out);
 void vgpu_trace_shape(const vgpu_trace_t* t, uint64_t* height, uint64_t* width);
 /* canonical row-major copy of a device trace (what the reference's generate_trace would have returned) */

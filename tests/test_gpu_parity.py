@@ -271,7 +271,8 @@ def test_interpreted_air_path_matches_oracle(machine, rc, make):
 
 
 # ---- device trace generation: Chip::generate_trace as kernels, from the VM's operation logs -----
-@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(100), lambda: va.Workload.fib(582), lambda: va.Workload.alu(1)])
+@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(100), lambda: va.Workload.fib(582), lambda: va.Workload.alu(1),
+                                  lambda: va.Workload.named("static_data")])
 def test_generated_traces_match_host_generate_trace(prover, make):
     w = make()
     log = prover.upload_oplog(w.oplog())
@@ -281,7 +282,7 @@ def test_generated_traces_match_host_generate_trace(prover, make):
         assert got.shape == want.shape, va.CHIP_NAMES[chip]
         assert first_mismatch(got.download(), want) is None, va.CHIP_NAMES[chip]
     with pytest.raises(va.VgpuError):
-        prover.generate_trace(log, 5)  # mul: no device generator, host generate_trace + upload
+        prover.generate_trace(log, va.NUM_CHIPS)  # no such chip
 
 
 def test_proof_from_generated_traces_is_the_same_proof(prover, rc):

@@ -105,7 +105,7 @@ class OplogDesc(ctypes.Structure):  # vgpu_oplog_desc_t
     ]
 
 
-GENERATED_CHIPS = (0, 1, 2, 3, 4, 8, 10, 12)  # cpu, program, mem, add, sub, lt, bitwise, range: chips with a device trace generator
+GENERATED_CHIPS = tuple(range(14))  # every BasicMachine chip has a device trace generator (mul, div, shift, com, output: no-operation traces)
 
 
 class Workload:

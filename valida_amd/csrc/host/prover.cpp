@@ -95,8 +95,9 @@ std::unique_ptr<DeviceOplog> Prover::upload_oplog(const HostOplog& log) {
 
 bool Prover::can_generate(int chip) {
     using namespace vchips;
-    return chip == CHIP_CPU || chip == CHIP_PROGRAM || chip == CHIP_MEM || chip == CHIP_ADD || chip == CHIP_SUB || chip == CHIP_LT || chip == CHIP_BITWISE ||
-           chip == CHIP_RANGE;
+    // cpu, program, mem, add, sub, lt, bitwise, range from their logs; mul, div, shift, com, output as the padding-only traces of
+    // chips that received no operation (the log format carries none for them), static_data from the initialised cells
+    return chip >= 0 && chip < NUM_CHIPS;
 }
 
 std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int chip) {
@@ -130,6 +131,10 @@ std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int 
         else
             VG_HIP_CHECK(vk::launch_tracegen_program(c.stream, (const vk::TgCpuOp*)log.cpu.data, log.n_cpu, next_pow2(log.n_cpu), log.rom_len, counts.data, t->nat.view()));
         c.sync();  // the scratch table goes back to the pool
+    } else if (chip == CHIP_MUL || chip == CHIP_DIV || chip == CHIP_SHIFT || chip == CHIP_COM || chip == CHIP_OUTPUT || chip == CHIP_STATIC_DATA) {
+        t->height = chip == CHIP_MUL ? 1024 : chip == CHIP_STATIC_DATA ? next_pow2(log.n_static) : 1;
+        t->nat = DMat(&c, t->height, t->width);
+        vk::launch_tracegen_idle(c.stream, chip == CHIP_MUL ? 1 : chip == CHIP_STATIC_DATA ? 2 : 0, log.static_cells.data, log.n_static, t->nat.view());
     } else {
         const int k = chip == CHIP_ADD ? 0 : chip == CHIP_SUB ? 1 : chip == CHIP_LT ? 2 : 3;
         t->height = next_pow2(log.n_alu[k]);

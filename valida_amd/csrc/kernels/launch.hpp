@@ -67,6 +67,7 @@ size_t tracegen_mem_sort_scratch_bytes(uint64_t n);
 hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, const uint32_t* static_cells, uint64_t n_static, uint32_t* keys2, uint32_t* idx2,
                                void* sort_tmp, size_t sort_tmp_bytes, DMatView t);
 void launch_tracegen_alu(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t);
+void launch_tracegen_idle(hipStream_t st, int mode, const uint32_t* static_cells, uint64_t n_static, DMatView t);  // 0 zeros, 1 mul counter, 2 static data
 hipError_t launch_tracegen_range(hipStream_t st, const TgAluOp* add_ops, uint64_t n_add, const TgAluOp* sub_ops, uint64_t n_sub, uint32_t* counts, DMatView t);
 hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t n, uint64_t padded_n, uint32_t rom_len, uint32_t* counts, DMatView t);
 // open.hip

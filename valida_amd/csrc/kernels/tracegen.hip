@@ -213,6 +213,26 @@ __global__ void __launch_bounds__(256) k_tracegen_counts(const uint32_t* __restr
     if (with_counter) put(t, 1, i, (uint32_t)i);
 }
 
+// ---- chips that received no operations: padding-only traces ------------------------------------------------------------
+// mul (alu_u32/src/mul/mod.rs:38-62): max(1024, ..) rows whose only non-zero column is counter = row + 1; div / shift / com /
+// output (pad_to_power_of_two of an empty table): one zero row; static_data (static_data/src/lib.rs:60-79): one row
+// (addr, value bytes, is_real = 1) per initialised cell.  mode: 0 = zeros, 1 = mul counter, 2 = static-data rows.
+__global__ void __launch_bounds__(256) k_tracegen_idle(int mode, const uint32_t* __restrict__ static_cells, uint64_t n_static, DMatView t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.height) return;
+    for (int c = 0; c < (int)t.width; c++) {
+        uint32_t v = 0;
+        if (mode == 1 && c == mul::COUNTER) v = (uint32_t)(i + 1);
+        if (mode == 2 && i < n_static) {
+            const uint32_t addr = static_cells[2 * i], value = static_cells[2 * i + 1];
+            if (c == static_data::ADDR) v = addr % vg::P;
+            else if (c >= static_data::VALUE && c < static_data::VALUE + 4) v = byte_of(value, c - static_data::VALUE);
+            else if (c == static_data::IS_REAL) v = 1;
+        }
+        put(t, c, i, v);
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------
 static unsigned blocks_for(uint64_t rows) { return (unsigned)((rows + 255) / 256); }
 
@@ -342,6 +362,11 @@ hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t 
     hipLaunchKernelGGL(k_tg_pc_histogram, dim3(blocks_for(n)), dim3(256), 0, st, ops, n, padded_n, rom_len, counts);
     hipLaunchKernelGGL(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)rom_len, 0, t);
     return hipSuccess;
+}
+
+void launch_tracegen_idle(hipStream_t st, int mode, const uint32_t* static_cells, uint64_t n_static, DMatView t) {
+    ProfScope ps("k_tracegen_tables", st, 4.0 * t.height * t.width);
+    hipLaunchKernelGGL(k_tracegen_idle, dim3(blocks_for(t.height)), dim3(256), 0, st, mode, static_cells, n_static, t);
 }
 
 void launch_tracegen_alu(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t) {
