@@ -119,7 +119,8 @@ std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int 
         DBuf keys(&c, 2 * n + 4), idx(&c, 2 * n + 4), tmp(&c, tmp_bytes / 4 + 4);
         VG_HIP_CHECK(vk::launch_tracegen_mem(c.stream, (const vk::TgMemOp*)log.mem.data, n, log.static_cells.data, log.n_static, keys.data, idx.data, tmp.data,
                                              tmp_bytes, t->nat.view()));
-        c.sync();  // scratch buffers go back to the pool
+        // the scratch buffers return to the pool here while the kernels may still be queued: safe, the pool only ever hands a
+        // block to work enqueued LATER on the same stream
     } else if (chip == CHIP_RANGE || chip == CHIP_PROGRAM) {
         if (chip == CHIP_PROGRAM && !log.rom_len) throw std::invalid_argument("generate_trace: the operation log carries no ROM length");
         t->height = chip == CHIP_RANGE ? 256 : next_pow2(log.rom_len);
@@ -130,7 +131,6 @@ std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int 
                                                    t->nat.view()));
         else
             VG_HIP_CHECK(vk::launch_tracegen_program(c.stream, (const vk::TgCpuOp*)log.cpu.data, log.n_cpu, next_pow2(log.n_cpu), log.rom_len, counts.data, t->nat.view()));
-        c.sync();  // the scratch table goes back to the pool
     } else if (chip == CHIP_MUL || chip == CHIP_DIV || chip == CHIP_SHIFT || chip == CHIP_COM || chip == CHIP_OUTPUT || chip == CHIP_STATIC_DATA) {
         t->height = chip == CHIP_MUL ? 1024 : chip == CHIP_STATIC_DATA ? next_pow2(log.n_static) : 1;
         t->nat = DMat(&c, t->height, t->width);

@@ -200,11 +200,26 @@ __global__ void __launch_bounds__(256) k_tg_byte_histogram(const TgAluOp* __rest
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
 }
+// Loops make a few program counters very hot: fetches are first counted in an LDS table per block (pcs below PC_LDS_BINS),
+// and only the non-zero bins reach the global table.
+constexpr int PC_LDS_BINS = 4096, PC_ITEMS = 16;
 __global__ void __launch_bounds__(256) k_tg_pc_histogram(const TgCpuOp* __restrict__ ops, uint64_t n, uint64_t padded_n, uint32_t rom_len, uint32_t* __restrict__ counts /* zeroed */) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t pc = ops[i].pc;
-    if (pc < rom_len) atomicAdd(&counts[pc], i + 1 == n ? (uint32_t)(1 + padded_n - n) : 1u);  // the last instruction (STOP) is re-fetched by every padding row
+    __shared__ uint32_t h[PC_LDS_BINS];
+    for (int b = threadIdx.x; b < PC_LDS_BINS; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    const uint64_t first = (uint64_t)blockIdx.x * (256 * PC_ITEMS);
+#pragma unroll 4
+    for (int u = 0; u < PC_ITEMS; u++) {
+        const uint64_t i = first + u * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const uint32_t pc = ops[i].pc;
+        const uint32_t add = i + 1 == n ? (uint32_t)(1 + padded_n - n) : 1u;  // the last instruction (STOP) is re-fetched by every padding row
+        if (pc < (uint32_t)PC_LDS_BINS) atomicAdd(&h[pc], add);
+        else if (pc < rom_len) atomicAdd(&counts[pc], add);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < PC_LDS_BINS; b += blockDim.x)
+        if (h[b] && (uint32_t)b < rom_len) atomicAdd(&counts[b], h[b]);
 }
 __global__ void __launch_bounds__(256) k_tracegen_counts(const uint32_t* __restrict__ counts, uint64_t n_counts, int with_counter, DMatView t) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,7 +374,7 @@ hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t 
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)rom_len * 4, st);
     if (e != hipSuccess) return e;
     ProfScope ps("k_tracegen_tables", st, 48.0 * n + 4.0 * t.height);
-    hipLaunchKernelGGL(k_tg_pc_histogram, dim3(blocks_for(n)), dim3(256), 0, st, ops, n, padded_n, rom_len, counts);
+    hipLaunchKernelGGL(k_tg_pc_histogram, dim3((unsigned)((n + 256 * PC_ITEMS - 1) / (256 * PC_ITEMS))), dim3(256), 0, st, ops, n, padded_n, rom_len, counts);
     hipLaunchKernelGGL(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)rom_len, 0, t);
     return hipSuccess;
 }
