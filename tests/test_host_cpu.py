@@ -219,3 +219,23 @@ def test_proof_cbor_matches_independent_encoder(flags):
         va.proof_cbor(words[:-3], flags)  # truncated proof
     with pytest.raises(va.VgpuError):
         va.proof_cbor(np.concatenate([words, [0]]).astype(np.uint32), flags)  # trailing word
+
+
+def test_committed_bench_line_follows_the_contract():
+    # profiles/r01_bench_full.json is the line bench.py printed on the MI355X: every field the driver reads is there
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_full.json")) as f:
+        d = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "proofs/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"] and d["dtype"] == "u32" and d["data"].startswith("synthetic")
+    assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
+    assert r["kernel"] == "k_keccak_compress" and d["valu_roofline"]["kernel"] == r["kernel"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "proofs/s" and "sample" in c
+    assert d["value"] / c["value"] > 20  # north star: >= 20x the CPU baseline
