@@ -113,6 +113,9 @@ def main():
                     help="SURVEY.md §8 config: c2 = Fibonacci (headline), c3 = Fibonacci 2^22 rows with 4x blowup, c4 = ALU/range-heavy loop")
     args = ap.parse_args()
 
+    # Pin the measured configuration before the HIP runtime starts: 3 prover contexts x (main + 1 aux stream) over FOUR hardware
+    # queues (the runtime's default; other counts measured worse, DESIGN.md "Measurement").
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
     import torch
     import valida_amd as va
 
