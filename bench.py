@@ -129,12 +129,20 @@ def main():
             sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    # test hooks (a 1-GPU box exercising the N > 1 control flow): every rank on one device, gloo instead of RCCL
+    backend = os.environ.get("VGPU_BENCH_BACKEND", "nccl")
+    if "VGPU_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["VGPU_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=coll_device)
+        else:
+            dist.init_process_group(backend=backend)
 
     rc = va.poseidon_round_constants()
     machine = va.Machine.basic()
@@ -201,7 +209,7 @@ def main():
             if tk is not None:
                 done[tk[0]] = tk[1].wait()
         if world > 1 and k:
-            all_roots[0] = exchange_roots(dist, torch, np.concatenate([p.words[2:26] for p in done]), torch.device("cuda", local_rank))
+            all_roots[0] = exchange_roots(dist, torch, np.concatenate([p.words[2:26] for p in done]), coll_device)
         return done
 
     def fence():
@@ -259,7 +267,7 @@ def main():
         p_.set_profiling(False)
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -560,3 +560,25 @@ def test_blowup8_proof_bytes(machine, rc, make):
     ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc, log_blowup=3)
     assert first_mismatch(proof.words, ref.words) is None
     assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc, log_blowup=3) is None
+
+
+def test_bench_two_rank_control_flow_on_one_gpu():
+    # the N > 1 path of bench.py end to end (prover contexts per rank, barriers, the batched root all-gather, MAX over ranks,
+    # one JSON line from rank 0) with both ranks on this GPU and gloo standing in for RCCL
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VGPU_BENCH_BACKEND="gloo", VGPU_BENCH_DEVICE="0")
+    port = 29600 + os.getpid() % 300
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log-rows", "14", "--no-cpu-baseline", "--no-extra-legs"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
