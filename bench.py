@@ -192,7 +192,7 @@ def main():
                 log = pr.upload_oplog(oplog)
                 tr = {c: pr.generate_trace(log, c) for c in va.GENERATED_CHIPS}
                 tr.update({c: pr.upload(mt[c]) for c in small})
-                return pr.prove_async([tr[c] for c in range(va.NUM_CHIPS)], inputs[slot][1])
+                return pr.prove_async([tr[c] for c in range(va.NUM_CHIPS)], inputs[slot][1], keep=log)
             if from_host:  # the boundary handing over host buffers: H2D of the 14 main traces inside the step
                 return pr.prove_async([pr.upload(m) for m in mt], inputs[slot][1])
             return pr.prove_async(*inputs[slot])

@@ -17,14 +17,15 @@ import valida_amd as va  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 
-def make(n, name):
+def make(n, name, log_blowup=1, out_dir=HERE, debug_check=True):
     """n: Fibonacci loop bound, or the name of one of the reference's other pinned programs / ("alu", iters)."""
     rc = va.poseidon_round_constants()
     w = va.Workload.fib(n) if isinstance(n, int) else va.Workload.alu(n[1]) if isinstance(n, tuple) else va.Workload.named(n)
     mt, prep = w.main_traces(), w.preprocessed()
-    res = po.prove_basic(mt, prep[0][1], prep[1][1], rc, debug_check=True)
-    assert po.verify_basic(prep[0][1], prep[1][1], res.words, rc) is None
+    res = po.prove_basic(mt, prep[0][1], prep[1][1], rc, log_blowup=log_blowup, debug_check=debug_check)
+    assert po.verify_basic(prep[0][1], prep[1][1], res.words, rc, log_blowup=log_blowup) is None
     out = {
+        "log_blowup": log_blowup, "oracle_seconds": round(res.seconds, 2), "host_cores": os.cpu_count(),
         "n": n,
         "poseidon_seed": "0x56414C494441",
         "cycles": w.cycles, "mem_ops": w.mem_ops, "add_ops": w.add_ops, "result": w.result,
@@ -34,12 +35,28 @@ def make(n, name):
         "proof_words": int(res.words.size),
         "proof_sha256": hashlib.sha256(res.bytes()).hexdigest(),
     }
-    with open(os.path.join(HERE, name), "w") as f:
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, name), "w") as f:
         json.dump(out, f, indent=1)
     print(name, out["proof_sha256"])
 
 
+def make_full(out_dir, which):
+    """BASELINE.json's full-size configurations (C2, C4, C3): minutes of oracle time on a many-core host — run once on the
+    GPU box's host through gpurun (`python tests/golden/make_golden.py --full gpurun_out/golden c2 c4 c3`), then commit the
+    files under tests/golden/."""
+    if "c2" in which:
+        make(149794, "full_c2_fib149794.json", 1, out_dir, debug_check=False)
+    if "c4" in which:
+        make(("alu", 116507), "full_c4_alu116507.json", 1, out_dir, debug_check=False)
+    if "c3" in which:
+        make(599183, "full_c3_fib599183_blowup4.json", 2, out_dir, debug_check=False)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--full":
+        make_full(sys.argv[2], sys.argv[3:] or ["c2", "c4", "c3"])
+        sys.exit(0)
     make(25, "fib25_oracle.json")
     make(582, "fib582_oracle.json")
     for prog in ("left_imm_ops", "signed_inequality", "loadfp", "static_data"):  # basic/tests/test_prover.rs:190-402, test_static_data.rs:31-59

@@ -1,53 +1,252 @@
-// Micro-benchmarks of the integer primitives the prover's kernels are built from (gfx950).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I valida_amd/csrc tools/microbench.hip -o build/microbench
+// Issue-rate micro-benchmarks of the integer VALU instructions the prover's kernels are built from (gfx950), with a
+// v_fma_f32 control row, and HBM copy kernels of known byte counts that calibrate FETCH_SIZE / WRITE_SIZE.
+//
+// Every rate loop is written in inline asm so that the instruction stream is exactly what is counted: one loop iteration
+// issues UNROLL instructions of ONE opcode over 8 independent register chains (no dependent-issue stalls at >= 2 waves per
+// SIMD), plus three scalar loop instructions.  tools/microbench.py cross-checks the per-iteration VALU count of every
+// kernel against llvm-objdump's disassembly of the code object and writes profiles/rNN_microbench.txt.
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench.hip -o build/microbench
+// Run:    build/microbench [rates|copies|all]
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
-#include "field.hpp"
-using vg::Fp;
 
-template <int MODE> __global__ void k_chain(uint32_t* out, uint32_t seed, int iters) {
+#define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(_e)); exit(2); } } while (0)
+
+constexpr int UNROLL = 64;  // VALU instructions per loop iteration (8 chains x 8)
+
+// REP8(body): the asm statement for chains 0..7
+#define CHAINS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define REP8(X) CHAINS(X) CHAINS(X) CHAINS(X) CHAINS(X) CHAINS(X) CHAINS(X) CHAINS(X) CHAINS(X)
+
+#define RATE_KERNEL(NAME, ASM_FOR_CHAIN)                                                                    \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t seed, int iters) {                  \
+        uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;                                                 \
+        uint32_t r[8], b = seed | 1u, c = seed * 2654435761u + t;                                           \
+        for (int i = 0; i < 8; i++) r[i] = t * 2654435761u + i * 977u;                                      \
+        for (int it = 0; it < iters; it++) { REP8(ASM_FOR_CHAIN) }                                          \
+        uint32_t x = 0;                                                                                     \
+        for (int i = 0; i < 8; i++) x ^= r[i];                                                              \
+        out[t] = x;                                                                                         \
+    }
+
+#define OP_FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(c));
+#define OP_ADD(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define OP_SUB(i) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define OP_MIN(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define OP_XOR(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define OP_ADD3(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(c));
+#define OP_BITOP3(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[i]) : "v"(b), "v"(c));
+#define OP_ALIGNBIT(i) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(r[i]) : "v"(b));
+#define OP_LSHL(i) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(r[i]));
+#define OP_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(b));
+#define OP_MUL_LO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define OP_MUL_HI(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define OP_MUL_U24(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define OP_MAD_U24(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(c));
+
+RATE_KERNEL(k_v_fma_f32, OP_FMA)
+RATE_KERNEL(k_v_add_u32, OP_ADD)
+RATE_KERNEL(k_v_sub_u32, OP_SUB)
+RATE_KERNEL(k_v_min_u32, OP_MIN)
+RATE_KERNEL(k_v_xor_b32, OP_XOR)
+RATE_KERNEL(k_v_add3_u32, OP_ADD3)
+RATE_KERNEL(k_v_bitop3_b32, OP_BITOP3)
+RATE_KERNEL(k_v_alignbit_b32, OP_ALIGNBIT)
+RATE_KERNEL(k_v_lshlrev_b32, OP_LSHL)
+RATE_KERNEL(k_v_cndmask_b32, OP_CNDMASK)
+RATE_KERNEL(k_v_mul_lo_u32, OP_MUL_LO)
+RATE_KERNEL(k_v_mul_hi_u32, OP_MUL_HI)
+RATE_KERNEL(k_v_mul_u32_u24, OP_MUL_U24)
+RATE_KERNEL(k_v_mad_u32_u24, OP_MAD_U24)
+
+// 64-bit destination: 8 chains of v_mad_u64_u32 acc += x * y (the lazy-accumulation workhorse of quotient / col_dot / reduce)
+__global__ void __launch_bounds__(256) k_v_mad_u64_u32(uint32_t* out, uint32_t seed, int iters) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    Fp a[4], m = Fp::raw(seed | 1);
-    for (int i = 0; i < 4; i++) a[i] = Fp::raw((t * 2654435761u + i * 977u) % vg::P);
+    uint64_t r[8];
+    uint32_t b = seed | 1u, c = seed * 2654435761u + t;
+    for (int i = 0; i < 8; i++) r[i] = t * 2654435761ull + i * 977u;
+#define OP_MAD64(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(b), "v"(c) : "vcc");
+    for (int it = 0; it < iters; it++) { REP8(OP_MAD64) }
+    uint64_t x = 0;
+    for (int i = 0; i < 8; i++) x ^= r[i];
+    out[t] = (uint32_t)x ^ (uint32_t)(x >> 32);
+}
+
+// v_mad_u64_u32 alternating with v_add_u32 (hipcc puts an s_nop between BACK-TO-BACK v_mad_u64_u32; real kernels interleave)
+__global__ void __launch_bounds__(256) k_mix_mad64_add(uint32_t* out, uint32_t seed, int iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t r[8];
+    uint32_t q[8], b = seed | 1u, c = seed * 2654435761u + t;
+    for (int i = 0; i < 8; i++) { r[i] = t * 2654435761ull + i * 977u; q[i] = t + i; }
+#define OP_MIX(i) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_add_u32 %1, %1, %2" : "+v"(r[i]), "+v"(q[i]) : "v"(b), "v"(c) : "vcc");
+    for (int it = 0; it < iters; it++) { CHAINS(OP_MIX) CHAINS(OP_MIX) CHAINS(OP_MIX) CHAINS(OP_MIX) }
+    uint64_t x = 0;
+    for (int i = 0; i < 8; i++) x ^= r[i] ^ q[i];
+    out[t] = (uint32_t)x ^ (uint32_t)(x >> 32);
+}
+
+// Compiled composites (instruction mix counted from the disassembly by tools/microbench.py):
+// a Montgomery product chain (field.hpp's monty_reduce) and one Keccak-style round slice (xor3 / alignbit / chi).
+__device__ __forceinline__ uint32_t monty_mul(uint32_t a, uint32_t b) {
+    const uint32_t P = 0x78000001u;
+    uint64_t t = (uint64_t)a * b;
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo * 0x88000001u;
+    uint32_t u = __umulhi(m, P);
+    uint32_t r = hi - u, r2 = r + P;
+    return r < r2 ? r : r2;
+}
+__global__ void __launch_bounds__(256) k_montgomery_mul(uint32_t* out, uint32_t seed, int iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r[8], b = (seed | 1u) % 0x78000001u;
+    for (int i = 0; i < 8; i++) r[i] = (t * 2654435761u + i * 977u) % 0x78000001u;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (MODE == 0) a[i] = a[i] * m;                       // Montgomery product
-            if (MODE == 1) a[i] = a[i] + m;                       // modular add
-            if (MODE == 2) a[i] = Fp::raw(a[i].v * m.v + 12345u);  // raw v_mul_lo + add
-            if (MODE == 3) a[i] = Fp::raw(__umulhi(a[i].v, m.v) + a[i].v);  // raw v_mul_hi
-            if (MODE == 4) { uint64_t p = (uint64_t)a[i].v * m.v; a[i] = Fp::raw((uint32_t)p ^ (uint32_t)(p >> 32)); }  // v_mad_u64_u32
-            if (MODE == 5) a[i] = Fp::raw(__builtin_amdgcn_alignbit(a[i].v, m.v, 7) ^ a[i].v);  // alignbit + xor
-        }
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) r[i] = monty_mul(r[i], b);
     }
-    out[t] = a[0].v ^ a[1].v ^ a[2].v ^ a[3].v;
+    uint32_t x = 0;
+    for (int i = 0; i < 8; i++) x ^= r[i];
+    out[t] = x;
 }
 
-template <int MODE> double run(const char* name, int ops_per_iter) {
-    const int blocks = 256 * 8, threads = 256, iters = 4096;
-    uint32_t* d;
-    hipMalloc(&d, blocks * threads * 4);
+template <class K> static double time_kernel(K kernel, int blocks, int iters, uint32_t* d) {
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_chain<MODE>, dim3(blocks), dim3(threads), 0, 0, d, 12345u, 16);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(k_chain<MODE>, dim3(blocks), dim3(threads), 0, 0, d, 12345u, iters);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double ops = (double)blocks * threads * iters * 4;
-    printf("%-28s %8.3f ms  %8.2f Gop/s  (%.2f cycles per wave-op per SIMD at 2.1 GHz)\n", name, ms, ops / ms / 1e6,
-           1024.0 * 2.1e9 / (ops / 64 / (ms * 1e-3)));
-    hipFree(d);
-    return ms;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d, 12345u, 8);  // warm the code object / clocks
+    CHECK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d, 12345u, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+    return best;
 }
-int main() {
-    run<0>("montgomery mul", 1);
-    run<1>("modular add", 1);
-    run<2>("v_mul_lo_u32 (+add)", 1);
-    run<3>("v_mul_hi_u32 (+add)", 1);
-    run<4>("v_mad_u64_u32 (+xor)", 1);
-    run<5>("v_alignbit + xor", 1);
+
+// measured shader clock: s_memtime ticks per wall-clock second over a busy kernel
+__global__ void k_clock(uint64_t* out, int iters) {
+    uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    uint32_t x = threadIdx.x;
+    for (int i = 0; i < iters; i++) { asm volatile("v_add_u32 %0, %0, %0" : "+v"(x)); }
+    uint64_t c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = x; }
+}
+
+template <class K> static void rate_row(const char* name, K kernel, int per_iter, int cu, uint32_t* d, double clock_hz) {
+    printf("%-20s", name);
+    const int iters = 4096;
+    double peak = 0;
+    for (int wps : {1, 2, 4, 8}) {  // waves per SIMD = blocks of 256 threads (4 waves) per CU
+        const int blocks = cu * wps;
+        const double ms = time_kernel(kernel, blocks, iters, d);
+        const double wave_instr = (double)blocks * 4 * iters * per_iter;
+        const double rate = wave_instr / (ms * 1e-3);
+        if (rate > peak) peak = rate;
+        printf("  %6.1f", rate / 1e9);
+    }
+    printf("   peak %7.1f G wave-instr/s = %.2f cycles per instr per SIMD at %.2f GHz\n", peak / 1e9, (cu * 4.0) * clock_hz / peak, clock_hz / 1e9);
+}
+
+// ---- HBM copies of known byte counts (FETCH_SIZE / WRITE_SIZE calibration; run under rocprofv3 --pmc) ----
+__global__ void __launch_bounds__(256) k_copy_dword(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_copy_dwordx4(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// the strided NTT passes' pattern: SEG consecutive words per row, rows `pitch` words apart; 16 lanes (SEG=16) or 32 lanes
+// (SEG=32) of a wave share a row segment; all rows x segments are read once and written once
+template <int SEG> __global__ void __launch_bounds__(256) k_copy_segments(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t rows, size_t pitch) {
+    // block (bx, by): column window bx * SEG .. +SEG of rows by * ROWS_PER_BLOCK ..
+    constexpr int ROWS_PER_PASS = 256 / SEG;
+    const int c = threadIdx.x % SEG, r0 = threadIdx.x / SEG;
+    const size_t col0 = (size_t)blockIdx.x * SEG;
+    for (size_t r = (size_t)blockIdx.y * 1024 + r0; r < (size_t)(blockIdx.y + 1) * 1024 && r < rows; r += ROWS_PER_PASS)
+        dst[r * pitch + col0 + c] = src[r * pitch + col0 + c];
+}
+
+static void copy_rows() {
+    const size_t words = (size_t)1 << 28;  // 1 GiB per buffer: far beyond the 256 MiB Infinity Cache
+    uint32_t *a, *b;
+    CHECK(hipMalloc(&a, words * 4)); CHECK(hipMalloc(&b, words * 4));
+    CHECK(hipMemset(a, 1, words * 4)); CHECK(hipMemset(b, 2, words * 4));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    auto report = [&](const char* name, double bytes_each_way, float ms) {
+        printf("%-22s read %.0f B  written %.0f B  %.3f ms  %.2f TB/s (read + write)\n", name, bytes_each_way, bytes_each_way, ms, 2 * bytes_each_way / ms / 1e9);
+    };
+    for (int rep = 0; rep < 2; rep++) {  // second repetition is the measured one; both appear in a PMC trace
+        float ms;
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_copy_dword, dim3(256 * 16), dim3(256), 0, 0, a, b, words);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) report("k_copy_dword", words * 4.0, ms);
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_copy_dwordx4, dim3(256 * 16), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, words / 4);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) report("k_copy_dwordx4", words * 4.0, ms);
+        // 2^16 rows x 4096 words (16 KiB pitch, the 2^12-point contiguous tile): every 64-byte / 128-byte segment once
+        const size_t rows = 1 << 16, pitch = 4096;
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_copy_segments<16>, dim3(pitch / 16, rows / 1024), dim3(256), 0, 0, a, b, rows, pitch);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) report("k_copy_segments<16>", rows * pitch * 4.0, ms);
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_copy_segments<32>, dim3(pitch / 32, rows / 1024), dim3(256), 0, 0, a, b, rows, pitch);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) report("k_copy_segments<32>", rows * pitch * 4.0, ms);
+    }
+    CHECK(hipFree(a)); CHECK(hipFree(b));
+}
+
+int main(int argc, char** argv) {
+    const char* what = argc > 1 ? argv[1] : "all";
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cu = prop.multiProcessorCount;
+    printf("device: %s, %d CUs x 4 SIMDs, clockRate %d kHz\n", prop.gcnArchName, cu, prop.clockRate);
+    if (!strcmp(what, "rates") || !strcmp(what, "all")) {
+        uint64_t* dc;
+        CHECK(hipMalloc(&dc, 64));
+        hipLaunchKernelGGL(k_clock, dim3(cu * 8), dim3(256), 0, 0, dc, 1 << 22);
+        uint64_t hc[3];
+        CHECK(hipMemcpy(hc, dc, 24, hipMemcpyDeviceToHost));
+        const double clock_hz = (double)hc[0] / ((double)hc[1] / 1e8);  // wall_clock64 ticks at 100 MHz
+        printf("measured shader clock under an all-CU VALU load: %.3f GHz (s_memtime ticks / wall_clock64 at 100 MHz)\n", clock_hz / 1e9);
+        uint32_t* d;
+        CHECK(hipMalloc(&d, (size_t)cu * 8 * 256 * 4));
+        printf("G wave64-instr/s over the whole chip at 1 / 2 / 4 / 8 waves per SIMD; %d VALU instructions per loop iteration\n", UNROLL);
+        rate_row("v_fma_f32", k_v_fma_f32, UNROLL, cu, d, clock_hz);
+        rate_row("v_add_u32", k_v_add_u32, UNROLL, cu, d, clock_hz);
+        rate_row("v_sub_u32", k_v_sub_u32, UNROLL, cu, d, clock_hz);
+        rate_row("v_min_u32", k_v_min_u32, UNROLL, cu, d, clock_hz);
+        rate_row("v_xor_b32", k_v_xor_b32, UNROLL, cu, d, clock_hz);
+        rate_row("v_add3_u32", k_v_add3_u32, UNROLL, cu, d, clock_hz);
+        rate_row("v_bitop3_b32", k_v_bitop3_b32, UNROLL, cu, d, clock_hz);
+        rate_row("v_alignbit_b32", k_v_alignbit_b32, UNROLL, cu, d, clock_hz);
+        rate_row("v_lshlrev_b32", k_v_lshlrev_b32, UNROLL, cu, d, clock_hz);
+        rate_row("v_cndmask_b32", k_v_cndmask_b32, UNROLL, cu, d, clock_hz);
+        rate_row("v_mul_u32_u24", k_v_mul_u32_u24, UNROLL, cu, d, clock_hz);
+        rate_row("v_mad_u32_u24", k_v_mad_u32_u24, UNROLL, cu, d, clock_hz);
+        rate_row("v_mul_lo_u32", k_v_mul_lo_u32, UNROLL, cu, d, clock_hz);
+        rate_row("v_mul_hi_u32", k_v_mul_hi_u32, UNROLL, cu, d, clock_hz);
+        rate_row("v_mad_u64_u32", k_v_mad_u64_u32, UNROLL, cu, d, clock_hz);
+        rate_row("mad_u64 + add_u32 mix", k_mix_mad64_add, UNROLL, cu, d, clock_hz);
+        // composite: 64 Montgomery products per iteration; per-product instruction mix from the disassembly (microbench.py)
+        rate_row("montgomery_mul (x1)", k_montgomery_mul, 64, cu, d, clock_hz);
+        CHECK(hipFree(d)); CHECK(hipFree(dc));
+    }
+    if (!strcmp(what, "copies") || !strcmp(what, "all")) copy_rows();
     return 0;
 }

@@ -478,14 +478,15 @@ class Prover:
                                 ctypes.c_uint32((1 if debug else 0) | (2 if check else 0)), ctypes.byref(h)))
         return Proof(h)
 
-    def prove_async(self, main, preprocessed):
-        """Start Machine::prove on a host thread of the library; returns a Ticket (wait() -> Proof)."""
+    def prove_async(self, main, preprocessed, keep=None):
+        """Start Machine::prove on a host thread of the library; returns a Ticket (wait() -> Proof).  `keep`: further objects
+        (e.g. the operation log the traces were generated from) kept alive until the ticket has been waited for."""
         arr = (ctypes.c_void_p * len(main))(*[t._h for t in main])
         chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
         parr = (ctypes.c_void_p * max(1, len(preprocessed)))(*[t._h for _, t in preprocessed])
         h = ctypes.c_void_p()
         _check(lib().vgpu_prove_async(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)), ctypes.byref(h)))
-        return Ticket(h, (main, preprocessed, self))
+        return Ticket(h, (main, preprocessed, self, keep))
 
     def set_profiling(self, on):
         lib().vgpu_prover_set_profiling(self._h, ctypes.c_uint32(1 if on else 0))

@@ -299,9 +299,31 @@ int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_o
         h.rom_len = log->rom_len;
         for (uint64_t i = 1; i < h.n_static; i++)
             if (log->static_cells[2 * i] <= log->static_cells[2 * i - 2]) throw std::invalid_argument("oplog: static cells must be in ascending address order");
-        for (uint64_t i = 0; i < h.n_cpu; i++)
-            if (log->cpu[i].mem_first > h.n_mem || (i && log->cpu[i].mem_first < log->cpu[i - 1].mem_first) || log->cpu[i].kind > VGPU_CPU_LOADFP)
+        if (!h.n_cpu || !log->cpu) throw std::invalid_argument("oplog: empty cpu log");
+        if ((h.n_mem && !log->mem) || (h.n_static && !log->static_cells)) throw std::invalid_argument("oplog: null log with a nonzero length");
+        for (int k = 0; k < 4; k++) if (h.n_alu[k] && !h.alu[k]) throw std::invalid_argument("oplog: null ALU log with a nonzero length");
+        for (uint64_t i = 0; i < h.n_cpu; i++) {
+            const vgpu_cpu_op_t& o = log->cpu[i];
+            if (o.mem_first > h.n_mem || (i && o.mem_first < log->cpu[i - 1].mem_first) || o.kind > VGPU_CPU_LOADFP)
                 throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + " is malformed");
+            // the program chip's multiplicity histogram indexes the ROM by pc
+            if (h.rom_len && o.pc >= h.rom_len) throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + ": pc beyond the ROM length");
+            // Bus operations must target a chip whose device generator is fed by these logs (add, sub, lt, bitwise): the log format
+            // carries no mul / div / shift / com / output operations, and a proof built from their padding-only traces would leave
+            // the general bus unbalanced (an invalid proof with no prover-side error).
+            if (o.kind == VGPU_CPU_BUS || o.kind == VGPU_CPU_BUS_LEFT_IMM) {
+                using namespace vchips;
+                const uint32_t op = o.opcode;
+                const bool fed = op == OP_ADD32 || op == OP_SUB32 || op == OP_LT32 || op == OP_LTE32 || op == OP_SLT32 || op == OP_SLE32 || op == OP_AND32 ||
+                                 op == OP_OR32 || op == OP_XOR32;
+                if (!fed)
+                    throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + ": opcode " + std::to_string(op) +
+                                                " belongs to a chip without a log-driven device trace generator (generate that chip's trace on the host and upload it)");
+            }
+        }
+        // the memory chip's stable by-address radix sort reproduces the reference's (addr, clk) order only for clk-ordered logs
+        for (uint64_t i = 1; i < h.n_mem; i++)
+            if (log->mem[i].clk < log->mem[i - 1].clk) throw std::invalid_argument("oplog: memory log entry " + std::to_string(i) + " is out of clock order");
         std::unique_ptr<vgpu_oplog> l(new vgpu_oplog());
         l->owner = p->p;
         l->log = p->p->upload_oplog(h);
@@ -414,14 +436,20 @@ int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uin
     })
 }
 
+// a trace handle handed to prove must exist and live in THIS prover's context (its stream and pool order the accesses)
+static void check_trace(const vgpu_prover_t* p, const vgpu_trace_t* t) {
+    if (!t || !t->t) throw std::invalid_argument("null trace");
+    if (t->owner != p->p) throw std::invalid_argument("trace belongs to another prover context");
+}
+
 int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips, const vgpu_trace_t* const* prep,
                    uint32_t n_prep, uint32_t debug_flags, vgpu_proof_t** out) {
     VG_TRY({
-        if (!p || !main || !out) throw std::invalid_argument("null argument");
+        if (!p || !main || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
         std::vector<const DeviceTrace*> m;
-        for (uint32_t i = 0; i < n_main; i++) m.push_back(main[i]->t.get());
+        for (uint32_t i = 0; i < n_main; i++) { check_trace(p, main[i]); m.push_back(main[i]->t.get()); }
         std::vector<std::pair<int, const DeviceTrace*>> pr;
-        for (uint32_t i = 0; i < n_prep; i++) pr.push_back({(int)prep_chips[i], prep[i]->t.get()});
+        for (uint32_t i = 0; i < n_prep; i++) { check_trace(p, prep[i]); pr.push_back({(int)prep_chips[i], prep[i]->t.get()}); }
         auto proof = std::make_unique<vgpu_proof>();
         proof->dbg.keep_matrices = (debug_flags & 1) != 0;
         proof->dbg.check_constraints = (debug_flags & 2) != 0;
@@ -445,8 +473,9 @@ int32_t vgpu_prove_async(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint
         };
         auto job = std::make_shared<Job>();
         job->prover = p->p;
-        for (uint32_t i = 0; i < n_main; i++) { if (!main[i]) throw std::invalid_argument("null trace"); job->main.push_back(main[i]->t); }
-        for (uint32_t i = 0; i < n_prep; i++) { if (!prep[i]) throw std::invalid_argument("null trace"); job->prep.push_back(prep[i]->t); job->chips.push_back((int)prep_chips[i]); }
+        if (n_prep && (!prep || !prep_chips)) throw std::invalid_argument("null argument");
+        for (uint32_t i = 0; i < n_main; i++) { check_trace(p, main[i]); job->main.push_back(main[i]->t); }
+        for (uint32_t i = 0; i < n_prep; i++) { check_trace(p, prep[i]); job->prep.push_back(prep[i]->t); job->chips.push_back((int)prep_chips[i]); }
         std::unique_ptr<vgpu_ticket> t(new vgpu_ticket());
         t->result = std::async(std::launch::async, [job]() {
             std::pair<int32_t, std::string> status{VGPU_OK, ""};

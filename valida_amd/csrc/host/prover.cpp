@@ -210,9 +210,13 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     for (size_t k = 0; k < preprocessed.size(); k++) {
         const DeviceTrace* t = preprocessed[k].second;
         int chip = preprocessed[k].first;
+        if (chip < 0 || (size_t)chip >= NC || prep_slot[chip] >= 0) throw std::invalid_argument("prove: bad or repeated preprocessed chip index");
         if (t->width != machine_.airs[chip].prep_width || t->height != main[chip]->height) throw std::invalid_argument("prove: preprocessed trace shape mismatch");
         prep_nat[k] = DMat(&c, t->height, t->width);
-        vk::launch_ingest(c.stream_for(k, t->height), t->raw.data, prep_nat[k].view(), false);
+        if (!t->nat.empty())  // a device-resident working-layout trace handed in as preprocessed: copy, never read the (absent) raw image
+            VG_HIP_CHECK(hipMemcpyAsync(prep_nat[k].data, t->nat.data, t->height * t->width * 4, hipMemcpyDeviceToDevice, c.stream_for(k, t->height)));
+        else
+            vk::launch_ingest(c.stream_for(k, t->height), t->raw.data, prep_nat[k].view(), false);
         prep_slot[chip] = (int)k;
     }
     ingest_section.join();

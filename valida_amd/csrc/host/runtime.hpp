@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -38,6 +39,9 @@ struct DeviceCtx {
     hipEvent_t fork_ev = nullptr, join_ev[NUM_AUX] = {};
     bool in_section = false;
     std::vector<void*> deferred;  // blocks released inside a section return to the pool at the join
+    // The pool is shared by the thread that drives a proof (vgpu_prove_async's worker) and by whichever host thread frees a
+    // handle meanwhile (vgpu_trace_free / vgpu_oplog_free / a garbage collector): every pool operation takes this lock.
+    std::mutex pool_mu;
 
     explicit DeviceCtx(int dev) : device(dev) {
         VG_HIP_CHECK(hipSetDevice(dev));
@@ -70,6 +74,7 @@ struct DeviceCtx {
     DeviceCtx(const DeviceCtx&) = delete;
 
     void* alloc(size_t bytes) {
+        std::lock_guard<std::mutex> lk(pool_mu);
         if (bytes == 0) bytes = 4;
         bytes = (bytes + 255) & ~(size_t)255;
         auto it = free_blocks.find(bytes);
@@ -79,7 +84,7 @@ struct DeviceCtx {
             hipError_t e = hipMalloc(&p, bytes);
             if (e == hipErrorOutOfMemory) {  // cached blocks of other sizes may be holding the memory: give them back, retry once
                 (void)hipGetLastError();
-                trim();
+                trim_locked();
                 e = hipMalloc(&p, bytes);
             }
             if (e != hipSuccess) throw std::bad_alloc();
@@ -93,6 +98,10 @@ struct DeviceCtx {
     // Return every cached (free) block to the driver; live blocks are untouched.  Synchronises the device first: a cached
     // block may still be read by work in flight.
     size_t trim() {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        return trim_locked();
+    }
+    size_t trim_locked() {
         (void)hipDeviceSynchronize();
         size_t freed = 0;
         for (auto& kv : free_blocks) { (void)hipFree(kv.second); freed += kv.first; }
@@ -105,6 +114,7 @@ struct DeviceCtx {
         if (in_section) throw std::runtime_error("nested fork");
         VG_HIP_CHECK(hipEventRecord(fork_ev, stream));
         for (int i = 0; i < NUM_AUX; i++) VG_HIP_CHECK(hipStreamWaitEvent(aux[i], fork_ev, 0));
+        std::lock_guard<std::mutex> lk(pool_mu);
         in_section = true;
     }
     // Join: the main stream waits for all aux work; blocks released meanwhile become reusable.
@@ -113,9 +123,12 @@ struct DeviceCtx {
             VG_HIP_CHECK(hipEventRecord(join_ev[i], aux[i]));
             VG_HIP_CHECK(hipStreamWaitEvent(stream, join_ev[i], 0));
         }
-        in_section = false;
         std::vector<void*> d;
-        d.swap(deferred);
+        {
+            std::lock_guard<std::mutex> lk(pool_mu);
+            in_section = false;
+            d.swap(deferred);
+        }
         for (void* p : d) release(p);
     }
     // Stream for independent work item `i` of estimated size `rows`: big items stay on the main stream.
@@ -125,6 +138,7 @@ struct DeviceCtx {
     }
     void release(void* p) {
         if (!p) return;
+        std::lock_guard<std::mutex> lk(pool_mu);
         if (in_section) { deferred.push_back(p); return; }
         auto it = live_blocks.find(p);
         if (it == live_blocks.end()) {  // called from destructors: never throw (a logic error, reported and survived)
@@ -218,7 +232,7 @@ struct Section {
     bool open;
     explicit Section(DeviceCtx* ctx) : c(ctx), open(true) { c->fork(); }
     void join() { if (open) { open = false; c->join(); } }
-    ~Section() { if (open) { try { c->join(); } catch (...) { c->in_section = false; } } }
+    ~Section() { if (open) { try { c->join(); } catch (...) { std::lock_guard<std::mutex> lk(c->pool_mu); c->in_section = false; } } }
     Section(const Section&) = delete;
     Section& operator=(const Section&) = delete;
 };
