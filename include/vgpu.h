@@ -94,6 +94,10 @@ uint32_t vgpu_machine_num_chips(const vgpu_machine_t* m);
 /* per-chip facts: width, preprocessed width, #interactions, log_quotient_degree (get_log_quotient_degree,
  * symbolic_builder.rs:17-30), #constraints, program length, registers */
 int32_t vgpu_machine_chip_info(const vgpu_machine_t* m, uint32_t chip, uint32_t out[8]);
+/* Neutral word image of chip `chip`'s interactions in Chip::all_interactions order (machine/src/chip.rs:40-63; test hook):
+ *   [n] then per interaction: [is_send] [is_global] [bus_index] [n_fields] count_vcol field_vcols..;
+ *   vcol = [n_terms] [constant] n_terms x ([is_preprocessed] [column] [weight]).  Returns the word count (copies when out has room). */
+int64_t vgpu_machine_interaction_words(const vgpu_machine_t* m, uint32_t chip, uint32_t* out, uint64_t cap);
 /* Host interpretation of chip `chip`'s compiled program on one row pair (test hook; no GPU needed).
  * values out: the asserted constraint values in order; returns their count or a negative status. */
 int32_t vgpu_machine_eval_constraints(const vgpu_machine_t* m, uint32_t chip, const uint32_t* main_local, const uint32_t* main_next,

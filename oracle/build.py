@@ -9,7 +9,6 @@ ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 
 def build_oracle(force=False):
     deps = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".hpp", ".cpp"))]
-    deps += [os.path.join(ROOT, "valida_amd", "csrc", "chips", "basic_machine.hpp"), os.path.join(ROOT, "valida_amd", "csrc", "air", "builder.hpp")]
     if not force and os.path.exists(ORACLE_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(ORACLE_LIB) for d in deps):
         return ORACLE_LIB
     r = subprocess.run(["make", "-C", ORACLE_DIR, "-B"], capture_output=True, text=True)

@@ -115,23 +115,46 @@ void oracle_mmcs_root(uint64_t n_mats, const uint32_t* const* mats, const uint64
 // Returns the number of constraints (out may be null to query it).
 uint32_t oracle_eval_constraints(uint32_t chip, const uint32_t* local, const uint32_t* next, const uint32_t* prep_local, const uint32_t* prep_next,
                                  uint32_t is_first, uint32_t is_last, uint32_t is_transition, uint32_t* out, uint32_t cap) {
+    (void)prep_local; (void)prep_next;  // no BasicMachine chip reads its preprocessed columns in eval
+    const size_t w = chips::chip_shape((int)chip).width;
     struct Rec {
         using Expr = Fp;
-        const uint32_t *l, *n, *pl, *pn;
+        std::vector<Fp> l, n;
         Fp first, last, trans;
         std::vector<Fp> vals;
-        Fp constant(uint32_t k) const { return Fp(k); }
-        Fp main(int c, bool nx) const { return Fp((nx ? n : l)[c]); }
-        Fp preprocessed(int c, bool nx) const { return Fp((nx ? pn : pl)[c]); }
+        Fp from_u32(uint32_t k) const { return Fp(k); }
+        const Fp* main_local() const { return l.data(); }
+        const Fp* main_next() const { return n.data(); }
         Fp is_first_row() const { return first; }
         Fp is_last_row() const { return last; }
         Fp is_transition() const { return trans; }
         void assert_zero(const Fp& x) { vals.push_back(x); }
-    } b{local, next, prep_local, prep_next, Fp(is_first), Fp(is_last), Fp(is_transition), {}};
-    vchips::eval_chip((int)chip, b);
+    } b{std::vector<Fp>(w), std::vector<Fp>(w), Fp(is_first), Fp(is_last), Fp(is_transition), {}};
+    for (size_t c = 0; c < w; c++) { b.l[c] = Fp(local[c]); b.n[c] = Fp(next[c]); }
+    chips::eval((int)chip, b);
     if (out) for (size_t i = 0; i < b.vals.size() && i < cap; i++) out[i] = b.vals[i].v;
     return (uint32_t)b.vals.size();
 }
+// Neutral word image of chip `chip`'s all_interactions (tests compare it with the product's):
+//   [n] then per interaction: [is_send] [is_global] [bus_index] [n_fields] count_vcol field_vcols..;  vcol = [n_terms] [constant] n_terms x ([is_prep] [col] [weight])
+uint32_t oracle_interaction_words(uint32_t chip, uint32_t* out, uint32_t cap) {
+    std::vector<uint32_t> w;
+    auto its = chips::all_interactions((int)chip);
+    auto vcol = [&](const chips::VirtualPairCol& v) {
+        w.push_back((uint32_t)v.terms.size()); w.push_back(v.constant);
+        for (auto& t : v.terms) { w.push_back(t.preprocessed ? 1 : 0); w.push_back((uint32_t)t.col); w.push_back(t.weight); }
+    };
+    w.push_back((uint32_t)its.size());
+    for (auto& it : its) {
+        w.push_back(it.is_send() ? 1 : 0); w.push_back(it.global ? 1 : 0); w.push_back((uint32_t)it.bus_index); w.push_back((uint32_t)it.fields.size());
+        vcol(it.count);
+        for (auto& f : it.fields) vcol(f);
+    }
+    if (out) for (size_t i = 0; i < w.size() && i < cap; i++) out[i] = w[i];
+    return (uint32_t)w.size();
+}
+// [width, preprocessed width] of chip `chip` from the oracle's column structs
+void oracle_chip_shape(uint32_t chip, uint32_t out[2]) { auto s = chips::chip_shape((int)chip); out[0] = (uint32_t)s.width; out[1] = (uint32_t)s.preprocessed_width; }
 uint32_t oracle_log_quotient_degree(uint32_t chip) { return log_quotient_degree(MachineDesc::basic().chips[chip]); }
 uint32_t oracle_num_interactions(uint32_t chip) { return (uint32_t)MachineDesc::basic().chips[chip].interactions.size(); }
 // generate_permutation_trace of BasicMachine chip `chip`; out is height x 5(M+1), row-major (flatten_to_base).
@@ -154,9 +177,9 @@ void* oracle_prove_basic(const uint32_t* const* main, const uint64_t* heights, c
                          uint32_t pow_bits, int debug_check) {
     MachineDesc md = MachineDesc::basic();
     MachineInput in;
-    for (int i = 0; i < vchips::NUM_CHIPS; i++) in.main_traces.push_back(to_matrix(main[i], heights[i], md.chips[i].width));
-    in.preprocessed.push_back({vchips::CHIP_PROGRAM, to_matrix(prep_program, hp, 7)});
-    in.preprocessed.push_back({vchips::CHIP_RANGE, to_matrix(prep_range, 256, 1)});
+    for (int i = 0; i < chips::NUM_CHIPS; i++) in.main_traces.push_back(to_matrix(main[i], heights[i], md.chips[i].width));
+    in.preprocessed.push_back({chips::PROGRAM, to_matrix(prep_program, hp, 7)});
+    in.preprocessed.push_back({chips::RANGE, to_matrix(prep_range, 256, 1)});
     auto* res = new ProveResult();
     auto t0 = std::chrono::steady_clock::now();
     MachineProof p = prove(md, in, make_cfg(rc480, log_blowup, num_queries, pow_bits), &res->dbg, debug_check != 0);
@@ -198,8 +221,8 @@ int oracle_verify_basic(const uint32_t* prep_program, uint64_t hp, const uint32_
     if (!deserialize_proof(proof, n_words, p)) err = "malformed proof";
     if (!err) {
         std::vector<std::pair<int, Matrix>> prep;
-        prep.push_back({vchips::CHIP_PROGRAM, to_matrix(prep_program, hp, 7)});
-        prep.push_back({vchips::CHIP_RANGE, to_matrix(prep_range, 256, 1)});
+        prep.push_back({chips::PROGRAM, to_matrix(prep_program, hp, 7)});
+        prep.push_back({chips::RANGE, to_matrix(prep_range, 256, 1)});
         err = verify(MachineDesc::basic(), prep, p, make_cfg(rc480, log_blowup, num_queries, pow_bits));
     }
     if (err && msg && msg_cap) { strncpy(msg, err, msg_cap - 1); msg[msg_cap - 1] = 0; }

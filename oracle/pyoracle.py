@@ -152,6 +152,22 @@ def eval_constraints(chip, local, nxt, prep_local=None, prep_next=None, is_first
     return out[:n]
 
 
+def interactions(chip):
+    """all_interactions of chip `chip` from the oracle's own transcription, in the neutral word image (see capi.cpp)."""
+    L = lib()
+    L.oracle_interaction_words.restype = ctypes.c_uint32
+    n = int(L.oracle_interaction_words(ctypes.c_uint32(chip), None, ctypes.c_uint32(0)))
+    w = np.zeros(n, dtype=np.uint32)
+    L.oracle_interaction_words(ctypes.c_uint32(chip), w.ctypes.data_as(c_u32p), ctypes.c_uint32(n))
+    return w
+
+
+def chip_shape(chip):
+    out = np.zeros(2, dtype=np.uint32)
+    lib().oracle_chip_shape(ctypes.c_uint32(chip), out.ctypes.data_as(c_u32p))
+    return int(out[0]), int(out[1])
+
+
 def fri_fold(f, beta5):
     a, ap = _u32(f)
     b, bp = _u32(beta5)

@@ -8,17 +8,17 @@
 //   quotient       machine/src/quotient.rs:18-238, folder machine/src/folding_builder.rs:32-125
 //   decompose      p3_uni_stark::decompose_and_flatten (App. B11), zerofier (App. B11)
 //   debug check    machine/src/check_constraints.rs:14-93
-// The chips' AIR definitions and interactions are INPUT to the prover (Chip::eval / all_interactions);
-// they are shared with the product as templates in valida_amd/csrc/chips/basic_machine.hpp.
+// The chips' AIR definitions and interactions are INPUT to the prover (Chip::eval / all_interactions): the oracle has its
+// OWN transcription of them from the Rust sources (chips.hpp) — nothing under valida_amd/ is included here.
 #pragma once
 #include <memory>
 #include <string>
-#include "../valida_amd/csrc/chips/basic_machine.hpp"
+#include "chips.hpp"
 #include "pcs.hpp"
 
 namespace oracle {
-using vair::Interaction;
-using vair::VirtualCol;
+using chips::Interaction;
+using VirtualCol = chips::VirtualPairCol;
 
 // ---------------------------------------------------------------- folders
 inline Ext5 to_ext(const Fp& x) { return Ext5(x); }
@@ -35,9 +35,9 @@ template <class T> struct Folder {
     T first, last, trans;
     Ext5 alpha, acc;
     size_t num_constraints = 0;
-    T constant(uint32_t k) const { return T(Fp(k)); }
-    T main(int c, bool next) const { return next ? main_.next[c] : main_.local[c]; }
-    T preprocessed(int c, bool next) const { return next ? prep_.next[c] : prep_.local[c]; }
+    T from_u32(uint32_t k) const { return T(Fp(k)); }
+    const T* main_local() const { return main_.local; }
+    const T* main_next() const { return main_.next; }
     T is_first_row() const { return first; }
     T is_last_row() const { return last; }
     T is_transition() const { return trans; }
@@ -54,9 +54,9 @@ struct DebugBuilder {
     Fp first, last, trans;
     long failed = -1;
     size_t num_constraints = 0;
-    Fp constant(uint32_t k) const { return Fp(k); }
-    Fp main(int c, bool next) const { return next ? main_.next[c] : main_.local[c]; }
-    Fp preprocessed(int c, bool next) const { return next ? prep_.next[c] : prep_.local[c]; }
+    Fp from_u32(uint32_t k) const { return Fp(k); }
+    const Fp* main_local() const { return main_.local; }
+    const Fp* main_next() const { return main_.next; }
     Fp is_first_row() const { return first; }
     Fp is_last_row() const { return last; }
     Fp is_transition() const { return trans; }
@@ -76,9 +76,10 @@ struct DegreeBuilder {
     };
     int max_degree = 0;
     size_t num_constraints = 0;
-    Expr constant(uint32_t) const { return Expr{0}; }
-    Expr main(int, bool) const { return Expr{1}; }
-    Expr preprocessed(int, bool) const { return Expr{1}; }
+    std::vector<Expr> row = std::vector<Expr>(128, Expr{1});  // every trace variable has degree 1
+    Expr from_u32(uint32_t) const { return Expr{0}; }
+    const Expr* main_local() const { return row.data(); }
+    const Expr* main_next() const { return row.data(); }
     Expr is_first_row() const { return Expr{1}; }
     Expr is_last_row() const { return Expr{1}; }
     Expr is_transition() const { return Expr{0}; }
@@ -87,7 +88,7 @@ struct DegreeBuilder {
 
 // ---------------------------------------------------------------- machine description
 struct ChipDesc {
-    int id;  // vchips::ChipId — selects eval and interactions
+    int id;  // chips::ChipIndex — selects eval and interactions
     std::vector<Interaction> interactions;
     size_t width, prep_width;
 };
@@ -95,12 +96,12 @@ struct MachineDesc {
     std::vector<ChipDesc> chips;
     static MachineDesc basic() {
         MachineDesc m;
-        for (int i = 0; i < vchips::NUM_CHIPS; i++) {
+        for (int i = 0; i < chips::NUM_CHIPS; i++) {
             ChipDesc c;
             c.id = i;
-            c.interactions = vchips::chip_interactions(i);
-            c.width = vchips::chip_info(i).width;
-            c.prep_width = vchips::chip_info(i).preprocessed_width;
+            c.interactions = chips::all_interactions(i);
+            c.width = chips::chip_shape(i).width;
+            c.prep_width = chips::chip_shape(i).preprocessed_width;
             m.chips.push_back(c);
         }
         return m;
@@ -110,7 +111,7 @@ struct MachineDesc {
 // get_log_quotient_degree (machine/src/symbolic/symbolic_builder.rs:17-30)
 inline unsigned log_quotient_degree(const ChipDesc& c) {
     DegreeBuilder db;
-    vchips::eval_chip(c.id, db);
+    chips::eval(c.id, db);
     int deg = std::max(db.max_degree, 3);
     return log2_ceil((size_t)(deg - 1));
 }
@@ -205,9 +206,9 @@ inline std::string check_constraints(const ChipDesc& chip, const Matrix& main, c
         b.first = i == 0 ? Fp::one() : Fp::zero();
         b.last = i == n - 1 ? Fp::one() : Fp::zero();
         b.trans = i == n - 1 ? Fp::zero() : Fp::one();
-        vchips::eval_chip(chip.id, b);
+        chips::eval(chip.id, b);
         eval_permutation_constraints(chip, b, rnd, cumulative_sum);
-        if (b.failed >= 0) err = std::string(vchips::chip_info(chip.id).name) + ": row " + std::to_string(i) + " constraint " + std::to_string(b.failed);
+        if (b.failed >= 0) err = std::string(chips::chip_shape(chip.id).name) + ": row " + std::to_string(i) + " constraint " + std::to_string(b.failed);
     }
     return err;
 }
@@ -249,7 +250,7 @@ inline std::vector<Ext5> quotient_values(const ChipDesc& chip, unsigned log_degr
             f.first = z * (x - Fp::one()).inv();           // lagrange_basis_unnormalized(0)
             f.last = z * (x - subgroup_last).inv();         // lagrange_basis_unnormalized(degree-1)
             f.alpha = alpha;
-            vchips::eval_chip(chip.id, f);
+            chips::eval(chip.id, f);
             eval_permutation_constraints(chip, f, rnd, cumulative_sum);
             out[i] = f.acc * zh_inv[i % next_step];
         }
@@ -446,7 +447,7 @@ inline bool verify_constraints(const ChipDesc& chip, const ChipProof& cp, unsign
     f.perm_ = {pl.data(), pn.data()};
     f.first = is_first; f.last = is_last; f.trans = is_trans;
     f.alpha = alpha;
-    vchips::eval_chip(chip.id, f);
+    chips::eval(chip.id, f);
     eval_permutation_constraints(chip, f, rnd, cp.cumulative_sum);
     reverse_slice_index_bits(parts);
     Ext5 quotient, zp = Ext5::one();

@@ -105,6 +105,31 @@ class OplogDesc(ctypes.Structure):  # vgpu_oplog_desc_t
     ]
 
 
+def decode_interaction_words(w):
+    """Inverse of the neutral interaction word image (vgpu_machine_interaction_words)."""
+    w = [int(x) for x in w]
+    pos = 1
+
+    def vcol():
+        nonlocal pos
+        nt, const = w[pos], w[pos + 1]
+        pos += 2
+        terms = []
+        for _ in range(nt):
+            terms.append((w[pos], w[pos + 1], w[pos + 2]))
+            pos += 3
+        return (const, terms)
+
+    out = []
+    for _ in range(w[0]):
+        send, glob, bus, nf = w[pos:pos + 4]
+        pos += 4
+        count = vcol()
+        out.append({"send": bool(send), "global": bool(glob), "bus": bus, "count": count, "fields": [vcol() for _ in range(nf)]})
+    assert pos == len(w)
+    return out
+
+
 GENERATED_CHIPS = tuple(range(14))  # every BasicMachine chip has a device trace generator (mul, div, shift, com, output: no-operation traces)
 
 
@@ -203,6 +228,18 @@ class Machine:
         _check(lib().vgpu_machine_chip_info(self._h, ctypes.c_uint32(chip), out))
         keys = ["width", "preprocessed_width", "interactions", "log_quotient_degree", "constraints", "instructions", "registers", "max_degree"]
         return dict(zip(keys, [int(v) for v in out]))
+
+    def interactions(self, chip):
+        """Chip::all_interactions of `chip` as a list of dicts (send, global, bus, count, fields); a virtual column is
+        (constant, [(is_preprocessed, column, weight), ...])."""
+        L = lib()
+        L.vgpu_machine_interaction_words.restype = ctypes.c_int64
+        n = L.vgpu_machine_interaction_words(self._h, ctypes.c_uint32(chip), None, ctypes.c_uint64(0))
+        if n < 0:
+            _check(int(n))
+        w = np.zeros(int(n), dtype=np.uint32)
+        L.vgpu_machine_interaction_words(self._h, ctypes.c_uint32(chip), w.ctypes.data_as(c_u32p), ctypes.c_uint64(w.size))
+        return decode_interaction_words(w)
 
     def eval_constraints(self, chip, main_local, main_next, prep_local=None, prep_next=None, is_first=0, is_last=0, is_transition=1):
         info = self.chip_info(chip)

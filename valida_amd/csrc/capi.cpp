@@ -176,6 +176,27 @@ int32_t vgpu_machine_chip_info(const vgpu_machine_t* m, uint32_t chip, uint32_t 
         out[4] = a.program.num_asserts; out[5] = (uint32_t)a.program.instrs.size(); out[6] = a.program.num_regs; out[7] = (uint32_t)a.max_constraint_degree;
     })
 }
+// Neutral word image of chip `chip`'s interactions, in Chip::all_interactions order (test hook: compared with the checker's own
+// transcription and with the shapes extracted from the reference's Rust sources):
+//   [n] then per interaction: [is_send] [is_global] [bus_index] [n_fields] count_vcol field_vcols..
+//   vcol = [n_terms] [constant] n_terms x ([is_preprocessed] [column] [weight]), canonical values
+int64_t vgpu_machine_interaction_words(const vgpu_machine_t* m, uint32_t chip, uint32_t* out, uint64_t cap) {
+    if (!m || chip >= m->desc.airs.size()) return (int64_t)fail(VGPU_ERR_INVALID_ARG, "bad chip index");
+    std::vector<uint32_t> w;
+    auto vcol = [&](const vair::VirtualCol& v) {
+        w.push_back((uint32_t)v.terms.size()); w.push_back(v.constant);
+        for (auto& t : v.terms) { w.push_back(t.preprocessed ? 1u : 0u); w.push_back((uint32_t)t.col); w.push_back(t.weight); }
+    };
+    const auto& its = m->desc.airs[chip].interactions;
+    w.push_back((uint32_t)its.size());
+    for (auto& it : its) {
+        w.push_back(it.is_send() ? 1u : 0u); w.push_back(it.is_local() ? 0u : 1u); w.push_back((uint32_t)it.bus_index); w.push_back((uint32_t)it.fields.size());
+        vcol(it.count);
+        for (auto& f : it.fields) vcol(f);
+    }
+    if (out && cap >= w.size()) memcpy(out, w.data(), w.size() * 4);
+    return (int64_t)w.size();
+}
 int32_t vgpu_machine_eval_constraints(const vgpu_machine_t* m, uint32_t chip, const uint32_t* main_local, const uint32_t* main_next,
                                       const uint32_t* prep_local, const uint32_t* prep_next, uint32_t is_first, uint32_t is_last,
                                       uint32_t is_transition, uint32_t* out, uint32_t cap) {
