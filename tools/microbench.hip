@@ -13,9 +13,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include "kernels/keccak.hpp"  // -I valida_amd/csrc: the product's Keccak-f[1600]
 
 #define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(_e)); exit(2); } } while (0)
 
+__device__ uint64_t g_clk[2];  // (s_memtime ticks, wall_clock64 ticks) of thread 0 over its loop: the clock the kernel ran at
 constexpr int UNROLL = 64;  // VALU instructions per loop iteration (8 chains x 8)
 
 // REP8(body): the asm statement for chains 0..7
@@ -27,10 +29,13 @@ constexpr int UNROLL = 64;  // VALU instructions per loop iteration (8 chains x 
         uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;                                                 \
         uint32_t r[8], b = seed | 1u, c = seed * 2654435761u + t;                                           \
         for (int i = 0; i < 8; i++) r[i] = t * 2654435761u + i * 977u;                                      \
+        const uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();                              \
         for (int it = 0; it < iters; it++) { REP8(ASM_FOR_CHAIN) }                                          \
+        const uint64_t c1 = __builtin_readcyclecounter(), w1 = wall_clock64();                              \
         uint32_t x = 0;                                                                                     \
         for (int i = 0; i < 8; i++) x ^= r[i];                                                              \
         out[t] = x;                                                                                         \
+        if (t == 0) { g_clk[0] = c1 - c0; g_clk[1] = w1 - w0; }                                             \
     }
 
 #define OP_FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(c));
@@ -115,6 +120,29 @@ __global__ void __launch_bounds__(256) k_montgomery_mul(uint32_t* out, uint32_t 
     out[t] = x;
 }
 
+// The product's Keccak-f[1600] (kernels/keccak.hpp) on register-resident state, `iters` chained permutations per thread.
+template <bool DIGEST_ONLY> __global__ void __launch_bounds__(256) k_keccak_chain(uint32_t* out, uint32_t seed, int iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    vk::KState a;
+    for (int i = 0; i < 25; i++) { a.lo[i] = t * 2654435761u + i * seed; a.hi[i] = t * 40503u + i; }
+    const uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; it++) {
+        vk::keccak_f1600<DIGEST_ONLY>(a);
+        if (DIGEST_ONLY) { for (int i = 4; i < 25; i++) { a.lo[i] = a.lo[i & 3] ^ i; a.hi[i] = a.hi[i & 3] + i; } }  // the squeezed digest feeds the next block
+    }
+    const uint64_t c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    uint32_t x = 0;
+    for (int i = 0; i < 25; i++) x ^= a.lo[i] ^ a.hi[i];
+    out[t] = x;
+    if (t == 0) { g_clk[0] = c1 - c0; g_clk[1] = w1 - w0; }
+}
+
+static double last_kernel_clock_hz() {
+    uint64_t h[2];
+    CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk), 16));
+    return h[1] ? (double)h[0] / ((double)h[1] / 1e8) : 0.0;
+}
+
 template <class K> static double time_kernel(K kernel, int blocks, int iters, uint32_t* d) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -155,7 +183,22 @@ template <class K> static void rate_row(const char* name, K kernel, int per_iter
         if (rate > peak) peak = rate;
         printf("  %6.1f", rate / 1e9);
     }
-    printf("   peak %7.1f G wave-instr/s = %.2f cycles per instr per SIMD at %.2f GHz\n", peak / 1e9, (cu * 4.0) * clock_hz / peak, clock_hz / 1e9);
+    const double kclk = last_kernel_clock_hz();  // clock of the 8-waves-per-SIMD run itself (DVFS: depends on the instruction mix)
+    printf("   peak %7.1f G wave-instr/s = %.2f cycles per instr per SIMD at %.3f GHz (in-kernel clock)\n", peak / 1e9, (cu * 4.0) * (kclk > 0 ? kclk : clock_hz) / peak,
+           (kclk > 0 ? kclk : clock_hz) / 1e9);
+}
+
+template <class K> static void keccak_row(const char* name, K kernel, int cu, uint32_t* d) {
+    printf("%-20s", name);
+    const int iters = 256;
+    for (int wps : {1, 2, 3, 4, 5}) {  // 93 VGPRs admit 5 waves per SIMD
+        const int blocks = cu * wps;
+        const double ms = time_kernel(kernel, blocks, iters, d);
+        const double perms = (double)blocks * 256 * iters, clk = last_kernel_clock_hz();
+        const double simd_cycles = cu * 4.0 * clk * ms * 1e-3, wave_rounds = (double)blocks * 4 * iters * 24;
+        printf("  %5.2f G perm/s (%.0f cyc/round/wave, %.2f GHz)", perms / ms / 1e6, simd_cycles / wave_rounds, clk / 1e9);
+    }
+    printf("\n");
 }
 
 // ---- HBM copies of known byte counts (FETCH_SIZE / WRITE_SIZE calibration; run under rocprofv3 --pmc) ----
@@ -245,6 +288,10 @@ int main(int argc, char** argv) {
         rate_row("mad_u64 + add_u32 mix", k_mix_mad64_add, UNROLL, cu, d, clock_hz);
         // composite: 64 Montgomery products per iteration; per-product instruction mix from the disassembly (microbench.py)
         rate_row("montgomery_mul (x1)", k_montgomery_mul, 64, cu, d, clock_hz);
+        printf("Keccak-f[1600] of kernels/keccak.hpp, chained permutations in registers, at 1..5 waves per SIMD (SIMD-cycles per wave-round =\n"
+               "what one 178-instruction round costs the SIMD; 122 full-rate + 56 half-rate instructions would cost ~530 at the rates above)\n");
+        keccak_row("keccak_f1600 full", k_keccak_chain<false>, cu, d);
+        keccak_row("keccak_f1600 digest", k_keccak_chain<true>, cu, d);
         CHECK(hipFree(d)); CHECK(hipFree(dc));
     }
     if (!strcmp(what, "copies") || !strcmp(what, "all")) copy_rows();

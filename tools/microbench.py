@@ -20,7 +20,7 @@ def build():
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, "microbench")
     src = os.path.join(ROOT, "tools", "microbench.hip")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps=obj", src, "-o", exe], check=True, cwd=BUILD,
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps=obj", "-I", os.path.join(ROOT, "valida_amd", "csrc"), src, "-o", exe], check=True, cwd=BUILD,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return exe, os.path.join(BUILD, "microbench-hip-amdgcn-amd-amdhsa-gfx950.out")
 
@@ -29,7 +29,7 @@ def loop_bodies(code_object):
     """{kernel: {mnemonic: count}} for the instructions between the target of the last backward branch and that branch."""
     dis = subprocess.run([OBJDUMP, "-d", code_object], check=True, capture_output=True, text=True).stdout
     out = {}
-    for m in re.finditer(r"^[0-9a-f]+ <(_Z\d+(k_\w+?)P\w+)>:\n(.*?)(?=^\S|\Z)", dis, re.S | re.M):
+    for m in re.finditer(r"^[0-9a-f]+ <(_Z\d+(k_\w+?)(?:P\w+|ILb\d+E\w+))>:\n(.*?)(?=^\S|\Z)", dis, re.S | re.M):
         name, body = m.group(2), m.group(3)
         ins = []  # (address, mnemonic)
         for line in body.splitlines():
