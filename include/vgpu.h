@@ -143,6 +143,17 @@ int32_t vgpu_commit_batches(vgpu_prover_t* p, const vgpu_trace_t* const* mats, u
 /* pcs.get_ldes (basic/src/lib.rs:201,225,261): copy LDE `idx` back as row-major canonical, rows in
  * COMMITTED (bit-reversed) order; out must hold (height << log_blowup) * width words */
 int32_t vgpu_pdata_lde(vgpu_prover_t* p, const vgpu_pdata_t* pd, uint32_t idx, uint32_t* out, uint64_t cap_words);
+/* pcs.get_ldes without a copy: the committed LDE `idx` where it lives in HBM.  Column-major (column c at data + c * stride),
+ * Montgomery form (x * 2^32 mod p), rows in COMMITTED order: storage row j holds the evaluation at coset_shift * w^bitrev(j),
+ * i.e. the reference's natural-order view row i is storage row bitrev(i); `vertically_strided(stride, offset)`
+ * (machine/src/quotient.rs:41-47) = the first height / stride storage rows.  Valid until vgpu_pdata_free. */
+typedef struct vgpu_lde_view {
+    const uint32_t* data;   /* device pointer */
+    uint64_t height, width, stride;
+    uint32_t log_blowup;
+} vgpu_lde_view_t;
+uint32_t vgpu_pdata_num_matrices(const vgpu_pdata_t* pd);
+int32_t vgpu_pdata_lde_view(const vgpu_pdata_t* pd, uint32_t idx, vgpu_lde_view_t* out);
 void vgpu_pdata_free(vgpu_pdata_t* pd);
 
 /* generate_permutation_trace (machine/src/chip.rs:121-208) for chip `chip` of the prover's machine.
@@ -150,6 +161,35 @@ void vgpu_pdata_free(vgpu_pdata_t* pd);
  * cumulative_sum: 5 words. */
 int32_t vgpu_perm_trace(vgpu_prover_t* p, uint32_t chip, const vgpu_trace_t* main, const vgpu_trace_t* preprocessed_or_null,
                         const uint32_t challenges[15], uint32_t* out, uint64_t cap_words, uint32_t cumulative_sum[5]);
+
+/* The same, leaving the permutation trace in HBM as a trace handle (flatten_to_base layout: ready for vgpu_commit_batches) —
+ * the call a host makes at basic/src/lib.rs:232-258 when it drives the phases itself. */
+int32_t vgpu_perm_trace_device(vgpu_prover_t* p, uint32_t chip, const vgpu_trace_t* main, const vgpu_trace_t* preprocessed_or_null,
+                               const uint32_t challenges[15], vgpu_trace_t** out, uint32_t cumulative_sum[5]);
+
+/* quotient (machine/src/quotient.rs:18-37) of chip `chip`: evaluates Air::eval + eval_permutation_constraints on the quotient
+ * domain from the chip's three committed LDEs (pcs.get_ldes of the preprocessed / main / permutation rounds: matrix indices
+ * within each ProverData; prep_pd may be NULL for chips without preprocessed columns), divides by the zerofier, decomposes and
+ * flattens (quotient.rs:63-67).  Result: the height x (5 << log_quotient_degree) chunk matrix as a trace handle, to be committed
+ * with vgpu_commit_batches(.., coset_shifts = coset_shift^(2^log_quotient_degree)) (basic/src/lib.rs:593-599). */
+int32_t vgpu_quotient(vgpu_prover_t* p, uint32_t chip, const vgpu_pdata_t* prep_pd, uint32_t prep_idx, const vgpu_pdata_t* main_pd, uint32_t main_idx,
+                      const vgpu_pdata_t* perm_pd, uint32_t perm_idx, const uint32_t perm_challenges[15], const uint32_t alpha[5],
+                      const uint32_t cumulative_sum[5], vgpu_trace_t** out);
+
+/* pcs.open_multi_batches (basic/src/lib.rs:611-619).  rounds[r]: ProverData of round r; points: for every round, for every
+ * committed matrix of that round (commit order), n_points[k] extension elements (5 words each), all concatenated; n_points has
+ * one entry per (round, matrix).  The transcript `ch` is advanced as the reference's `&mut challenger` is (batch challenge, FRI
+ * betas, proof-of-work witness, query indices).  Result handle:
+ *   vgpu_opening_values: openings[round][matrix][point][column] flattened in that order, 5 words per value (lib.rs:622-645);
+ *   vgpu_opening_proof:  the TwoAdicFriPcsProof as words — exactly the tail of vgpu_proof_words after the per-chip section. */
+typedef struct vgpu_opening vgpu_opening_t;
+int32_t vgpu_open_multi_batches(vgpu_prover_t* p, const vgpu_pdata_t* const* rounds, uint32_t n_rounds, const uint32_t* n_points,
+                                const uint32_t* points, vgpu_challenger_t* ch, vgpu_opening_t** out);
+uint64_t vgpu_opening_values_len(const vgpu_opening_t* o);
+const uint32_t* vgpu_opening_values(const vgpu_opening_t* o);
+uint64_t vgpu_opening_proof_len(const vgpu_opening_t* o);
+const uint32_t* vgpu_opening_proof(const vgpu_opening_t* o);
+void vgpu_opening_free(vgpu_opening_t* o);
 
 /* FRI fold_even_odd of an Ext5 vector (n x 5 words, bit-reversed domain order) — App. B10 */
 int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uint32_t beta[5], uint32_t* out);

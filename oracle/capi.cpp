@@ -170,6 +170,49 @@ void oracle_fri_fold(const uint32_t* f, uint64_t n, const uint32_t* beta5, uint3
     for (size_t i = 0; i < r.size(); i++) for (int k = 0; k < 5; k++) out[5 * i + k] = r[i].c[k].v;
 }
 
+// ---- pcs.commit_batches + pcs.open_multi_batches on arbitrary rounds (generic shapes: any widths, heights, points per matrix)
+// mats / heights / widths / n_points: one entry per (round, matrix), rounds concatenated; points: 5 words per point, concatenated.
+// obs: values the transcript observed before the call.  The result's words = [8 words root per round][opened values, flattened
+// [round][matrix][point][column] x 5][TwoAdicFriPcsProof words]; oracle_pcs_open_split gives the two boundaries.
+struct PcsOpenResult { std::vector<uint32_t> words; uint64_t n_root_words = 0, n_value_words = 0; };
+void* oracle_pcs_open(uint32_t n_rounds, const uint32_t* n_mats, const uint32_t* const* mats, const uint64_t* heights, const uint64_t* widths,
+                      const uint32_t* n_points, const uint32_t* points, const uint32_t* rc480, uint32_t log_blowup, uint32_t num_queries, uint32_t pow_bits,
+                      const uint32_t* obs, uint64_t n_obs) {
+    StarkConfig cfg = make_cfg(rc480, log_blowup, num_queries, pow_bits);
+    Poseidon16 perm16(cfg.poseidon_constants.data());
+    Challenger ch(&perm16);
+    for (size_t i = 0; i < n_obs; i++) ch.observe(Fp(obs[i]));
+    std::vector<MerkleTree> trees(n_rounds);
+    std::vector<RoundData> rounds(n_rounds);
+    size_t k = 0, w = 0;
+    for (uint32_t r = 0; r < n_rounds; r++) {
+        std::vector<Matrix> ms;
+        std::vector<std::vector<Ext5>> pts;
+        for (uint32_t i = 0; i < n_mats[r]; i++, k++) {
+            ms.push_back(to_matrix(mats[k], heights[k], widths[k]));
+            pts.push_back(to_ext(points + w, n_points[k]));
+            w += 5 * (size_t)n_points[k];
+        }
+        trees[r] = pcs_commit(ms, cfg.fri);
+        rounds[r].points = std::move(pts);
+    }
+    for (uint32_t r = 0; r < n_rounds; r++) rounds[r].tree = &trees[r];
+    auto opened = pcs_open(rounds, ch, cfg.fri);
+    auto* res = new PcsOpenResult();
+    WordWriter o;
+    for (auto& t : trees) o.d(t.root());
+    res->n_root_words = o.w.size();
+    for (auto& round : opened.first) for (auto& mat : round) for (auto& pt : mat) for (auto& e : pt) o.e(e);
+    res->n_value_words = o.w.size() - res->n_root_words;
+    serialize_pcs_proof(o, opened.second);
+    res->words = std::move(o.w);
+    return res;
+}
+uint64_t oracle_pcs_open_len(void* r) { return ((PcsOpenResult*)r)->words.size(); }
+const uint32_t* oracle_pcs_open_words(void* r) { return ((PcsOpenResult*)r)->words.data(); }
+void oracle_pcs_open_split(void* r, uint64_t out[2]) { out[0] = ((PcsOpenResult*)r)->n_root_words; out[1] = ((PcsOpenResult*)r)->n_value_words; }
+void oracle_pcs_open_free(void* r) { delete (PcsOpenResult*)r; }
+
 // ---- full prover / verifier for BasicMachine ---------------------------------------------------
 // main[i]: row-major heights[i] x chip width; prep_program: hp x 7; prep_range: 256 x 1.
 void* oracle_prove_basic(const uint32_t* const* main, const uint64_t* heights, const uint32_t* prep_program, uint64_t hp,

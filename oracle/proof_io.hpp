@@ -29,6 +29,28 @@ struct WordWriter {
     void dv(const std::vector<Digest>& v) { u((uint32_t)v.size()); for (auto& x : v) d(x); }
 };
 
+// TwoAdicFriPcsProof: the tail of the layout above, also what pcs.open_multi_batches returns on its own
+inline void serialize_pcs_proof(WordWriter& o, const PcsProof& pp) {
+    auto& fri = pp.fri;
+    o.dv(fri.commit_phase_commits);
+    o.u((uint32_t)fri.query_proofs.size());
+    for (auto& q : fri.query_proofs) {
+        o.u((uint32_t)q.commit_phase_openings.size());
+        for (auto& s : q.commit_phase_openings) { o.e(s.sibling_value); o.dv(s.opening_proof); }
+    }
+    o.e(fri.final_poly);
+    o.f(fri.pow_witness);
+    o.u((uint32_t)pp.query_openings.size());
+    for (auto& q : pp.query_openings) {
+        o.u((uint32_t)q.size());
+        for (auto& bo : q) {
+            o.u((uint32_t)bo.opened_values.size());
+            for (auto& row : bo.opened_values) { o.u((uint32_t)row.size()); for (auto& x : row) o.f(x); }
+            o.dv(bo.opening_proof);
+        }
+    }
+}
+
 inline std::vector<uint32_t> serialize_proof(const MachineProof& p) {
     WordWriter o;
     o.u(PROOF_MAGIC);
@@ -39,24 +61,7 @@ inline std::vector<uint32_t> serialize_proof(const MachineProof& p) {
         o.ev(c.trace_local); o.ev(c.trace_next); o.ev(c.permutation_local); o.ev(c.permutation_next); o.ev(c.quotient_chunks);
         o.e(c.cumulative_sum);
     }
-    auto& fri = p.opening_proof.fri;
-    o.dv(fri.commit_phase_commits);
-    o.u((uint32_t)fri.query_proofs.size());
-    for (auto& q : fri.query_proofs) {
-        o.u((uint32_t)q.commit_phase_openings.size());
-        for (auto& s : q.commit_phase_openings) { o.e(s.sibling_value); o.dv(s.opening_proof); }
-    }
-    o.e(fri.final_poly);
-    o.f(fri.pow_witness);
-    o.u((uint32_t)p.opening_proof.query_openings.size());
-    for (auto& q : p.opening_proof.query_openings) {
-        o.u((uint32_t)q.size());
-        for (auto& bo : q) {
-            o.u((uint32_t)bo.opened_values.size());
-            for (auto& row : bo.opened_values) { o.u((uint32_t)row.size()); for (auto& x : row) o.f(x); }
-            o.dv(bo.opening_proof);
-        }
-    }
+    serialize_pcs_proof(o, p.opening_proof);
     return o.w;
 }
 

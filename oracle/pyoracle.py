@@ -222,6 +222,32 @@ class ProveResult:
             self._h = None
 
 
+def pcs_open(rounds, points, rc, observed=(), log_blowup=1, num_queries=40, pow_bits=8):
+    """pcs.commit_batches per round + pcs.open_multi_batches: rounds = [[matrix, ...], ...] (row-major), points[r][i] = list of
+    Ext5 (5 words).  Returns (roots [n_rounds x 8], opened values flat, TwoAdicFriPcsProof words)."""
+    L = lib()
+    L.oracle_pcs_open.restype = ctypes.c_void_p
+    L.oracle_pcs_open_len.restype = ctypes.c_uint64
+    L.oracle_pcs_open_words.restype = c_u32p
+    flat = [m for rnd in rounds for m in rnd]
+    keep, ptrs, hs, ws = _mat_args(flat)
+    n_mats = np.array([len(rnd) for rnd in rounds], dtype=np.uint32)
+    n_points = np.array([len(pts) for rnd in points for pts in rnd], dtype=np.uint32)
+    pw = np.array([w for rnd in points for pts in rnd for z in pts for w in z], dtype=np.uint32)
+    r, rp = _u32(rc)
+    o, op = _u32(np.array(observed, dtype=np.uint32))
+    h = ctypes.c_void_p(L.oracle_pcs_open(ctypes.c_uint32(len(rounds)), n_mats.ctypes.data_as(c_u32p), ptrs, hs, ws, n_points.ctypes.data_as(c_u32p),
+                                          pw.ctypes.data_as(c_u32p), rp, ctypes.c_uint32(log_blowup), ctypes.c_uint32(num_queries), ctypes.c_uint32(pow_bits), op,
+                                          ctypes.c_uint64(o.size)))
+    n = int(L.oracle_pcs_open_len(h))
+    words = np.ctypeslib.as_array(L.oracle_pcs_open_words(h), shape=(n,)).copy()
+    split = (ctypes.c_uint64 * 2)()
+    L.oracle_pcs_open_split(h, split)
+    L.oracle_pcs_open_free(h)
+    a, b = int(split[0]), int(split[0]) + int(split[1])
+    return words[:a].reshape(-1, 8), words[a:b], words[b:]
+
+
 def set_observe_final_poly(on):
     """Convention switch of the restatement: absorb final_poly into the transcript before grinding."""
     lib().oracle_set_observe_final_poly(ctypes.c_int(1 if on else 0))

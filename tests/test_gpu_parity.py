@@ -618,3 +618,98 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+# ---- the fine-grained PCS / quotient boundary: a host that drives the phases of Machine::prove itself through
+# commit_batches / get_ldes / generate_permutation_trace / quotient / open_multi_batches + its own challenger gets the same proof
+def _ext_mul_base(e, b):
+    return [int(po.lib().oracle_fp_mul(ctypes.c_uint32(int(x)), ctypes.c_uint32(int(b)))) for x in e]
+
+
+import ctypes  # noqa: E402
+
+
+@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(40), lambda: va.Workload.named("static_data")])
+def test_proof_assembled_from_fine_grained_calls_is_the_same_proof(machine, rc, make):
+    p = va.Prover(machine, rc)
+    w = make()
+    mt, prep = w.main_traces(), w.preprocessed()
+    dmain = [p.upload(m) for m in mt]
+    dprep = [(c, p.upload(m)) for c, m in prep]
+    whole = p.prove(dmain, dprep)
+
+    ch = va.Challenger(rc)                                              # basic/src/lib.rs:185
+    prep_pd = p.commit_batches([t for _, t in dprep])                   # :199
+    ch.observe(prep_pd.root)
+    main_pd = p.commit_batches(dmain)                                   # :223
+    ch.observe(main_pd.root)
+    rnd = ch.sample(15)                                                 # :227-230
+    prep_slot = {c: k for k, (c, _) in enumerate(dprep)}
+    perm, cums = [], []
+    for i in range(14):                                                 # :232-250
+        t, cs = p.permutation_trace_device(i, dmain[i], rnd, dprep[prep_slot[i]][1] if i in prep_slot else None)
+        perm.append(t)
+        cums.append(cs)
+    perm_pd = p.commit_batches(perm)                                    # :258
+    ch.observe(perm_pd.root)
+    alpha = ch.sample(5)                                                # :263
+    v = main_pd.lde_view(0)                                             # get_ldes (:225): a device view, no copy
+    assert v["data"] and (v["height"], v["width"], v["stride"], v["log_blowup"]) == (mt[0].shape[0] * 2, mt[0].shape[1], mt[0].shape[0] * 2, 1)
+    assert (main_pd.num_matrices, perm_pd.num_matrices, prep_pd.num_matrices) == (14, 14, 2)
+    quot = [p.quotient(i, main_pd, i, perm_pd, i, rnd, alpha, cums[i], prep_pd if i in prep_slot else None, prep_slot.get(i, 0)) for i in range(14)]  # :284-590
+    assert all(q.shape == (mt[i].shape[0], 10) for i, q in enumerate(quot))
+    quot_pd = p.commit_batches(quot, coset_shifts=[31 * 31] * 14)       # :593-599: coset_shift^(2^log_quotient_degree)
+    ch.observe(quot_pd.root)
+    zeta = [int(x) for x in ch.sample(5)]                               # :606
+    zeta2 = [int(x) for x in po.ext5_mul(zeta, zeta)]
+    points = [[], [], []]
+    for i in range(14):
+        g = int(po.lib().oracle_two_adic_generator(ctypes.c_uint32(int(np.log2(mt[i].shape[0])))))
+        points[0].append([zeta, _ext_mul_base(zeta, g)])
+        points[1].append([zeta, _ext_mul_base(zeta, g)])
+        points[2].append([zeta2])
+    opened, pcs_words = p.open_multi_batches([main_pd, perm_pd, quot_pd], points, ch)   # :611-619
+
+    words = [0x31465056, 14] + [int(x) for x in main_pd.root] + [int(x) for x in perm_pd.root] + [int(x) for x in quot_pd.root]
+    for i in range(14):                                                 # MachineProof / ChipProof (machine/src/proof.rs:13-44)
+        words.append(int(np.log2(mt[i].shape[0])))
+        for vec in (opened[0][i][0], opened[0][i][1], opened[1][i][0], opened[1][i][1], opened[2][i][0]):
+            words.append(vec.shape[0])
+            words += [int(x) for x in vec.ravel()]
+        words += [int(x) for x in cums[i]]
+    words += [int(x) for x in pcs_words]
+    assert first_mismatch(np.array(words, dtype=np.uint32), whole.words) is None
+    # the quotient chunks are the ones the whole prover computed (natural row order after undoing the bit reversal)
+    dbg = p.prove(dmain, dprep, debug=True)
+    for i in (0, 3, 12):
+        q = quot[i].download()
+        n = q.shape[0]
+        k = int(np.log2(n))
+        nat = np.array([int(format(r, "0%db" % k)[::-1], 2) if k else 0 for r in range(n)])
+        assert first_mismatch(q[nat], dbg.debug_quotient(i)) is None
+
+
+def test_open_multi_batches_generic_shapes_match_oracle(machine, rc):
+    """Shapes Machine::prove never produces: one round with a 130-column matrix (column chunks in k_col_dot), five points on one
+    matrix (point chunks, > 4 distinct points on one LDE height), a second round with mixed heights — against the oracle's
+    pcs.commit_batches + open_multi_batches on the same matrices, points and transcript prefix."""
+    p = va.Prover(machine, rc, num_queries=9, pow_bits=3)
+    rng = np.random.default_rng(99)
+    rounds = [[rand_matrix(rng, 64, 130), rand_matrix(rng, 64, 3)], [rand_matrix(rng, 256, 2), rand_matrix(rng, 8, 7), rand_matrix(rng, 1, 4)]]
+    ext = lambda: [int(x) for x in rng.integers(1, P, 5)]
+    pts = [ext() for _ in range(6)]
+    points = [[[pts[0]], [pts[0], pts[1], pts[2], pts[3], pts[4]]], [[pts[5], pts[0]], [pts[1]], [pts[2], pts[3], pts[4]]]]
+    obs = [int(x) for x in rng.integers(0, P, 11)]
+    roots, values, proof = po.pcs_open(rounds, points, rc, observed=obs, num_queries=9, pow_bits=3)
+    pds = [p.commit_batches([p.upload(m) for m in rnd]) for rnd in rounds]
+    for k, pd in enumerate(pds):
+        assert first_mismatch(pd.root, roots[k]) is None
+    ch = va.Challenger(rc)
+    ch.observe(obs)
+    opened, words = p.open_multi_batches(pds, points, ch)
+    got = np.concatenate([v.ravel() for rnd in opened for mat in rnd for v in mat])
+    assert first_mismatch(got, values) is None
+    assert first_mismatch(words, proof) is None
+    # the host transcript was advanced exactly as the oracle's: the next samples agree
+    ref = po.challenger_probe  # oracle transcript replay is not exposed after pcs_open; the equal proof words (PoW witness,
+    assert ref is not None     # query indices) already pin every value the transcript produced inside the call

@@ -350,6 +350,21 @@ class ProverData:
         _check(lib().vgpu_pdata_lde(self._prover._h, self._h, ctypes.c_uint32(idx), out.ctypes.data_as(c_u32p), ctypes.c_uint64(out.size)))
         return out
 
+    def lde_view(self, idx):
+        """pcs.get_ldes()[idx] without a copy: (device pointer, height, width, stride, log_blowup) of the committed LDE in HBM."""
+
+        class _View(ctypes.Structure):  # vgpu_lde_view_t
+            _fields_ = [("data", ctypes.c_void_p), ("height", ctypes.c_uint64), ("width", ctypes.c_uint64), ("stride", ctypes.c_uint64), ("log_blowup", ctypes.c_uint32)]
+
+        v = _View()
+        _check(lib().vgpu_pdata_lde_view(self._h, ctypes.c_uint32(idx), ctypes.byref(v)))
+        return {"data": v.data, "height": int(v.height), "width": int(v.width), "stride": int(v.stride), "log_blowup": int(v.log_blowup)}
+
+    @property
+    def num_matrices(self):
+        lib().vgpu_pdata_num_matrices.restype = ctypes.c_uint32
+        return int(lib().vgpu_pdata_num_matrices(self._h))
+
     def __del__(self):
         if getattr(self, "_h", None):
             try:
@@ -495,6 +510,61 @@ class Prover:
         _check(lib().vgpu_perm_trace(self._h, ctypes.c_uint32(chip), main._h, preprocessed._h if preprocessed is not None else None, chp,
                                      out.ctypes.data_as(c_u32p), ctypes.c_uint64(out.size), cs.ctypes.data_as(c_u32p)))
         return out, cs
+
+    def permutation_trace_device(self, chip, main, challenges, preprocessed=None):
+        """generate_permutation_trace left in HBM: (DeviceTrace, cumulative_sum[5])."""
+        ch, chp = _u32(challenges)
+        cs = np.zeros(5, dtype=np.uint32)
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_perm_trace_device(self._h, ctypes.c_uint32(chip), main._h, preprocessed._h if preprocessed is not None else None, chp, ctypes.byref(h),
+                                            cs.ctypes.data_as(c_u32p)))
+        hh, ww = ctypes.c_uint64(), ctypes.c_uint64()
+        lib().vgpu_trace_shape(h, ctypes.byref(hh), ctypes.byref(ww))
+        return DeviceTrace(self, h, (int(hh.value), int(ww.value))), cs
+
+    def quotient(self, chip, main_pd, main_idx, perm_pd, perm_idx, perm_challenges, alpha, cumulative_sum, prep_pd=None, prep_idx=0):
+        """quotient + decompose_and_flatten of one chip from its committed LDEs -> DeviceTrace of the chunk matrix (n x 10)."""
+        a, ap = _u32(perm_challenges)
+        b, bp = _u32(alpha)
+        c, cp = _u32(cumulative_sum)
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_quotient(self._h, ctypes.c_uint32(chip), prep_pd._h if prep_pd is not None else None, ctypes.c_uint32(prep_idx), main_pd._h,
+                                   ctypes.c_uint32(main_idx), perm_pd._h, ctypes.c_uint32(perm_idx), ap, bp, cp, ctypes.byref(h)))
+        hh, ww = ctypes.c_uint64(), ctypes.c_uint64()
+        lib().vgpu_trace_shape(h, ctypes.byref(hh), ctypes.byref(ww))
+        return DeviceTrace(self, h, (int(hh.value), int(ww.value)))
+
+    def open_multi_batches(self, rounds, points, challenger):
+        """pcs.open_multi_batches: rounds = [ProverData]; points[r][i] = list of Ext5 (5 words) for matrix i of round r.
+        Returns (openings[r][i][p] as (width, 5) arrays, TwoAdicFriPcsProof words); advances `challenger`."""
+        arr = (ctypes.c_void_p * len(rounds))(*[r._h for r in rounds])
+        n_points = np.array([len(pts) for rnd in points for pts in rnd], dtype=np.uint32)
+        flat = np.array([w for rnd in points for pts in rnd for z in pts for w in z], dtype=np.uint32)
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_open_multi_batches(self._h, arr, ctypes.c_uint32(len(rounds)), n_points.ctypes.data_as(c_u32p), flat.ctypes.data_as(c_u32p), challenger._h,
+                                             ctypes.byref(h)))
+        L = lib()
+        for f in (L.vgpu_opening_values_len, L.vgpu_opening_proof_len):
+            f.restype = ctypes.c_uint64
+        for f in (L.vgpu_opening_values, L.vgpu_opening_proof):
+            f.restype = c_u32p
+        try:
+            nv, npf = int(L.vgpu_opening_values_len(h)), int(L.vgpu_opening_proof_len(h))
+            vals = np.ctypeslib.as_array(L.vgpu_opening_values(h), shape=(nv,)).copy() if nv else np.zeros(0, np.uint32)
+            proof = np.ctypeslib.as_array(L.vgpu_opening_proof(h), shape=(npf,)).copy()
+        finally:
+            L.vgpu_opening_free(h)
+        out, pos = [], 0
+        for r, rnd in enumerate(points):
+            out.append([])
+            for i, pts in enumerate(rnd):
+                w = rounds[r]._shapes[i][1]
+                out[r].append([])
+                for _ in pts:
+                    out[r][i].append(vals[pos:pos + 5 * w].reshape(w, 5))
+                    pos += 5 * w
+        assert pos == vals.size
+        return out, proof
 
     def fri_fold(self, f, beta):
         f = np.ascontiguousarray(f, dtype=np.uint32)

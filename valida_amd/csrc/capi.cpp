@@ -33,6 +33,7 @@ struct vgpu_pdata { std::shared_ptr<Prover> owner; std::unique_ptr<ProverData> p
 struct vgpu_ticket { std::future<std::pair<vgpu_proof_t*, std::pair<int32_t, std::string>>> result; };
 struct vgpu_proof { std::vector<uint32_t> words; PhaseTimes tm; ProveDebugOut dbg; };
 struct vgpu_oplog { std::shared_ptr<Prover> owner; std::unique_ptr<DeviceOplog> log; };
+struct vgpu_opening { std::vector<uint32_t> values, proof; };
 static_assert(sizeof(vgpu_cpu_op_t) == sizeof(vk::TgCpuOp) && sizeof(vgpu_mem_op_t) == sizeof(vk::TgMemOp) && sizeof(vgpu_alu_op_t) == sizeof(vk::TgAluOp),
               "C ABI log records and their device images must match");
 static_assert((int)VGPU_CPU_LOADFP == (int)vk::TG_CPU_LOADFP, "cpu op kinds");
@@ -363,6 +364,7 @@ int32_t vgpu_generate_trace(vgpu_prover_t* p, const vgpu_oplog_t* log, uint32_t 
     })
 }
 
+// private working-layout copy of a trace (row order is kept: see DeviceTrace::nat_rows_bitrev)
 static DMat ingest(DeviceCtx& c, const DeviceTrace& t) {
     if (t.height & (t.height - 1)) throw std::invalid_argument("matrix height must be a power of two");
     DMat m(&c, t.height, t.width);
@@ -378,9 +380,9 @@ int32_t vgpu_commit_batches(vgpu_prover_t* p, const vgpu_trace_t* const* mats, u
         DeviceCtx& c = p->p->ctx();
         c.activate();
         std::vector<DMat> nat;
-        for (uint32_t i = 0; i < n_mats; i++) nat.push_back(ingest(c, *mats[i]->t));
+        for (uint32_t i = 0; i < n_mats; i++) { if (!mats[i] || mats[i]->owner != p->p) throw std::invalid_argument("null trace or trace of another prover"); nat.push_back(ingest(c, *mats[i]->t)); }
         std::vector<CommitInput> in;
-        for (auto& m : nat) in.push_back({&m, false, false});
+        for (uint32_t i = 0; i < n_mats; i++) in.push_back({&nat[i], mats[i]->t->nat_rows_bitrev, mats[i]->t->nat_rows_bitrev});  // our private copy: consumable
         std::vector<Fp> shifts;
         if (coset_shifts) for (uint32_t i = 0; i < n_mats; i++) shifts.push_back(Fp::from_canonical(coset_shifts[i]));
         std::unique_ptr<vgpu_pdata> pd(new vgpu_pdata());
@@ -402,7 +404,92 @@ int32_t vgpu_pdata_lde(vgpu_prover_t* p, const vgpu_pdata_t* pd, uint32_t idx, u
         c.download(out, tmp.data, l.height * l.width * 4);
     })
 }
+uint32_t vgpu_pdata_num_matrices(const vgpu_pdata_t* pd) { return pd ? (uint32_t)pd->pd->ldes.size() : 0; }
+int32_t vgpu_pdata_lde_view(const vgpu_pdata_t* pd, uint32_t idx, vgpu_lde_view_t* out) {
+    VG_TRY({
+        if (!pd || !out || idx >= pd->pd->ldes.size()) throw std::invalid_argument("bad argument");
+        const DMat& l = pd->pd->ldes[idx];
+        out->data = l.data; out->height = l.height; out->width = l.width; out->stride = l.height;
+        out->log_blowup = pd->owner->fri().log_blowup;
+    })
+}
 void vgpu_pdata_free(vgpu_pdata_t* pd) { delete pd; }
+
+static Ext5 ext_of(const uint32_t* w) { Ext5 e; for (int k = 0; k < 5; k++) e.c[k] = Fp::from_canonical(w[k]); return e; }
+
+int32_t vgpu_perm_trace_device(vgpu_prover_t* p, uint32_t chip, const vgpu_trace_t* main, const vgpu_trace_t* prep, const uint32_t challenges[15],
+                               vgpu_trace_t** out, uint32_t cumulative_sum[5]) {
+    VG_TRY({
+        if (!p || !main || !challenges || !out) throw std::invalid_argument("null argument");
+        const MachineDesc& md = p->p->machine();
+        if (chip >= md.airs.size()) throw std::invalid_argument("bad chip index");
+        if (main->t->width != md.airs[chip].width) throw std::invalid_argument("trace width mismatch");
+        DeviceCtx& c = p->p->ctx();
+        c.activate();
+        DMat m = ingest(c, *main->t);
+        DMat pm;
+        if (prep) pm = ingest(c, *prep->t);
+        Ext5 rnd[3] = {ext_of(challenges), ext_of(challenges + 5), ext_of(challenges + 10)};
+        Ext5 cs;
+        std::unique_ptr<vgpu_trace> t(new vgpu_trace());
+        t->owner = p->p;
+        t->t = std::make_shared<DeviceTrace>();
+        t->t->nat = p->p->permutation_trace((int)chip, m, prep ? &pm : nullptr, rnd, &cs);
+        t->t->height = t->t->nat.height; t->t->width = t->t->nat.width;
+        if (cumulative_sum) for (int k = 0; k < 5; k++) cumulative_sum[k] = cs.c[k].canonical();
+        *out = t.release();
+    })
+}
+
+int32_t vgpu_quotient(vgpu_prover_t* p, uint32_t chip, const vgpu_pdata_t* prep_pd, uint32_t prep_idx, const vgpu_pdata_t* main_pd, uint32_t main_idx,
+                      const vgpu_pdata_t* perm_pd, uint32_t perm_idx, const uint32_t perm_challenges[15], const uint32_t alpha[5],
+                      const uint32_t cumulative_sum[5], vgpu_trace_t** out) {
+    VG_TRY({
+        if (!p || !main_pd || !perm_pd || !perm_challenges || !alpha || !cumulative_sum || !out) throw std::invalid_argument("null argument");
+        if (chip >= p->p->machine().airs.size()) throw std::invalid_argument("bad chip index");
+        if (main_pd->owner != p->p || perm_pd->owner != p->p || (prep_pd && prep_pd->owner != p->p)) throw std::invalid_argument("prover data of another prover context");
+        if (main_idx >= main_pd->pd->ldes.size() || perm_idx >= perm_pd->pd->ldes.size() || (prep_pd && prep_idx >= prep_pd->pd->ldes.size()))
+            throw std::invalid_argument("bad matrix index");
+        p->p->ctx().activate();
+        Ext5 rnd[3] = {ext_of(perm_challenges), ext_of(perm_challenges + 5), ext_of(perm_challenges + 10)};
+        std::unique_ptr<vgpu_trace> t(new vgpu_trace());
+        t->owner = p->p;
+        t->t = std::make_shared<DeviceTrace>();
+        t->t->nat = p->p->quotient_chunks((int)chip, main_pd->pd->ldes[main_idx], perm_pd->pd->ldes[perm_idx], prep_pd ? &prep_pd->pd->ldes[prep_idx] : nullptr, rnd,
+                                          ext_of(alpha), ext_of(cumulative_sum));
+        t->t->nat_rows_bitrev = true;
+        t->t->height = t->t->nat.height; t->t->width = t->t->nat.width;
+        *out = t.release();
+    })
+}
+
+int32_t vgpu_open_multi_batches(vgpu_prover_t* p, const vgpu_pdata_t* const* rounds, uint32_t n_rounds, const uint32_t* n_points, const uint32_t* points,
+                                vgpu_challenger_t* ch, vgpu_opening_t** out) {
+    VG_TRY({
+        if (!p || !rounds || !n_rounds || !n_points || !points || !ch || !out) throw std::invalid_argument("null argument");
+        std::vector<OpenRound> rs(n_rounds);
+        size_t k = 0, w = 0;
+        for (uint32_t r = 0; r < n_rounds; r++) {
+            if (!rounds[r] || rounds[r]->owner != p->p) throw std::invalid_argument("null prover data or prover data of another prover context");
+            rs[r].pd = rounds[r]->pd.get();
+            for (size_t i = 0; i < rs[r].pd->ldes.size(); i++, k++) {
+                std::vector<Ext5> pts;
+                for (uint32_t q = 0; q < n_points[k]; q++, w += 5) pts.push_back(ext_of(points + w));
+                rs[r].points.push_back(std::move(pts));
+            }
+        }
+        PcsOpening o = p->p->open_multi_batches(rs, *ch->ch);
+        std::unique_ptr<vgpu_opening> res(new vgpu_opening());
+        for (auto& round : o.opened) for (auto& mat : round) for (auto& pt : mat) for (auto& e : pt) for (int q = 0; q < 5; q++) res->values.push_back(e.c[q].canonical());
+        res->proof = std::move(o.proof_words);
+        *out = res.release();
+    })
+}
+uint64_t vgpu_opening_values_len(const vgpu_opening_t* o) { return o->values.size(); }
+const uint32_t* vgpu_opening_values(const vgpu_opening_t* o) { return o->values.data(); }
+uint64_t vgpu_opening_proof_len(const vgpu_opening_t* o) { return o->proof.size(); }
+const uint32_t* vgpu_opening_proof(const vgpu_opening_t* o) { return o->proof.data(); }
+void vgpu_opening_free(vgpu_opening_t* o) { delete o; }
 
 int32_t vgpu_perm_trace(vgpu_prover_t* p, uint32_t chip, const vgpu_trace_t* main, const vgpu_trace_t* prep, const uint32_t challenges[15], uint32_t* out,
                         uint64_t cap_words, uint32_t cumulative_sum[5]) {

@@ -177,6 +177,96 @@ struct GatherList {
 };
 }  // namespace
 
+// Constants of one chip's quotient launch: [K alpha powers][M bus alphas][max_fields betas][cumulative_sum] (QuotientArgs::consts)
+static uint32_t quotient_consts(const AirDesc& air, const Ext5 rnd[3], const Ext5& alpha, const Ext5& cumulative_sum, std::vector<uint32_t>& pool) {
+    const uint32_t M = (uint32_t)air.interactions.size(), K = air.program.num_asserts + M + 3;
+    std::vector<Ext5> ap(K);
+    Ext5 p = Ext5::one();
+    for (uint32_t k = 0; k < K; k++) { ap[K - 1 - k] = p; p *= alpha; }  // constraint k is scaled by alpha^(K-1-k)
+    for (auto& e : ap) put_ext(pool, e);
+    size_t maxf = 0;
+    for (auto& it : air.interactions) {
+        put_ext(pool, (it.is_local() ? rnd[0] : rnd[1]).pow((uint64_t)it.bus_index + 1));  // generate_rlc_elements (chip.rs:291-331)
+        maxf = std::max(maxf, it.fields.size());
+    }
+    Ext5 bp = Ext5::one();
+    for (size_t j = 0; j < maxf; j++) { put_ext(pool, bp); bp *= rnd[2]; }
+    put_ext(pool, cumulative_sum);
+    return K;
+}
+
+DMat Prover::permutation_trace(int chip, const DMat& main_nat, const DMat* prep_nat, const Ext5 rnd[3], Ext5* cumulative_sum) {
+    DeviceCtx& c = *ctx_;
+    const AirDesc& air = machine_.airs.at((size_t)chip);
+    const uint32_t M = (uint32_t)air.interactions.size();
+    std::vector<uint32_t> pool;
+    size_t maxf = 0;
+    for (auto& it : air.interactions) { put_ext(pool, (it.is_local() ? rnd[0] : rnd[1]).pow((uint64_t)it.bus_index + 1)); maxf = std::max(maxf, it.fields.size()); }
+    Ext5 bp = Ext5::one();
+    for (size_t j = 0; j < maxf; j++) { put_ext(pool, bp); bp *= rnd[2]; }
+    pool.push_back(0);
+    DBuf pool_dev(&c, pool), scratch(&c, (size_t)vk::perm_scratch_words(main_nat.height));
+    DMat perm(&c, main_nat.height, 5 * (M + 1));
+    vk::launch_perm_trace(c.stream, main_nat.view(), prep_nat ? prep_nat->view() : vk::DMatView{nullptr, 0, 0, 0}, iw_dev_[chip].data, pool_dev.data, M, perm.view(), scratch.data);
+    c.check_launch("perm trace");
+    if (cumulative_sum) {  // last row of the running-sum column (lib.rs:247-250)
+        GatherList gl;
+        const uint64_t n = main_nat.height;
+        gl.add(perm.data + (uint64_t)(5 * M) * n + (n - 1), n, 5, 0);
+        DBuf gd(&c, gl.desc), gout(&c, 8);
+        vk::launch_gather(c.stream, gd.data, gl.n(), gout.data);
+        uint32_t cs[5];
+        c.download(cs, gout.data, 20);
+        *cumulative_sum = ext_from_canonical(cs);
+    } else c.sync();
+    return perm;
+}
+
+DMat Prover::quotient_chunks(int chip, const DMat& main_lde, const DMat& perm_lde, const DMat* prep_lde, const Ext5 rnd[3], const Ext5& alpha,
+                             const Ext5& cumulative_sum) {
+    DeviceCtx& c = *ctx_;
+    const AirDesc& air = machine_.airs.at((size_t)chip);
+    const unsigned lb = fri_.log_blowup;
+    const unsigned log_n = vg::log2_strict_u64(main_lde.height) - lb;
+    if (main_lde.width != air.width || perm_lde.width != 5 * (air.interactions.size() + 1) || perm_lde.height != main_lde.height ||
+        (air.prep_width && (!prep_lde || prep_lde->width != air.prep_width || prep_lde->height != main_lde.height)))
+        throw std::invalid_argument("quotient: LDE shapes do not match chip " + air.name);
+    std::vector<uint32_t> pool;
+    vk::QuotientArgs a{};
+    a.K = quotient_consts(air, rnd, alpha, cumulative_sum, pool);
+    DBuf pool_dev(&c, pool);
+    fill_quotient_args(a, chip, main_lde.view(), perm_lde.view(), prep_lde ? prep_lde->view() : vk::DMatView{nullptr, 0, 0, 0}, log_n, pool_dev.data);
+    DMat q(&c, 1ull << log_n, 10);
+    a.out = q.view();
+    vk::launch_quotient(c.stream, a, c.tables);
+    c.check_launch("quotient");
+    c.sync();  // pool_dev is released on return
+    return q;
+}
+
+// Everything of QuotientArgs but `out` and K (shared by prove() and quotient_chunks)
+void Prover::fill_quotient_args(vk::QuotientArgs& a, int chip, vk::DMatView main_lde, vk::DMatView perm_lde, vk::DMatView prep_lde, unsigned log_n, const uint32_t* consts_dev) {
+    const AirDesc& air = machine_.airs[(size_t)chip];
+    const Fp s = Fp::from_canonical(vg::GENERATOR);
+    a.main_lde = main_lde; a.perm_lde = perm_lde; a.prep_lde = prep_lde;
+    a.log_n = (int)log_n;
+    a.prog = (const vair::Instr*)prog_dev_[chip].data;
+    a.n_instrs = (uint32_t)air.program.instrs.size();
+    a.n_regs = air.program.num_regs;
+    a.n_air_asserts = air.program.num_asserts;
+    a.native_chip = fri_.interpret_air ? vk::QuotientArgs::INTERPRET : air.native_chip;
+    a.iw = iw_dev_[chip].data;
+    a.consts = consts_dev;
+    a.coset_shift = s.v;
+    a.coset_shift_inv = s.inv().v;
+    Fp sn = s.exp_power_of_2(log_n);
+    Fp z0 = sn - Fp::one(), z1 = -sn - Fp::one();
+    a.zh[0] = z0.v; a.zh[1] = z1.v;
+    a.zh_inv[0] = z0.inv().v; a.zh_inv[1] = z1.inv().v;
+    a.g_inv = vg::two_adic_generator(log_n).inv().v;
+}
+
+
 std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main, const std::vector<std::pair<int, const DeviceTrace*>>& preprocessed,
                                     PhaseTimes* times, ProveDebugOut* dbg) {
     DeviceCtx& c = *ctx_;
@@ -395,25 +485,9 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         for (size_t i = 0; i < NC; i++) {
             auto& air = machine_.airs[i];
             vk::QuotientArgs a{};
-            a.main_lde = main_pd->ldes[i].view();
-            a.perm_lde = perm_pd->ldes[i].view();
-            a.prep_lde = prep_slot[i] >= 0 ? prep_pd->ldes[prep_slot[i]].view() : vk::DMatView{nullptr, 0, 0, 0};
-            a.log_n = (int)log_deg[i];
-            a.prog = (const vair::Instr*)prog_dev_[i].data;
-            a.n_instrs = (uint32_t)air.program.instrs.size();
-            a.n_regs = air.program.num_regs;
-            a.n_air_asserts = air.program.num_asserts;
-            a.native_chip = fri_.interpret_air ? vk::QuotientArgs::INTERPRET : air.native_chip;
-            a.iw = iw_dev_[i].data;
-            a.consts = pool_dev.data + off[i];
+            fill_quotient_args(a, (int)i, main_pd->ldes[i].view(), perm_pd->ldes[i].view(),
+                               prep_slot[i] >= 0 ? prep_pd->ldes[prep_slot[i]].view() : vk::DMatView{nullptr, 0, 0, 0}, log_deg[i], pool_dev.data + off[i]);
             a.K = Ks[i];
-            a.coset_shift = s.v;
-            a.coset_shift_inv = s.inv().v;
-            Fp sn = s.exp_power_of_2(log_deg[i]);
-            Fp z0 = sn - Fp::one(), z1 = -sn - Fp::one();
-            a.zh[0] = z0.v; a.zh[1] = z1.v;
-            a.zh_inv[0] = z0.inv().v; a.zh_inv[1] = z1.inv().v;
-            a.g_inv = vg::two_adic_generator(log_deg[i]).inv().v;
             quot[i] = DMat(&c, 1ull << log_deg[i], 10);
             a.out = quot[i].view();
             vk::launch_quotient(c.stream_for(i, 1ull << log_deg[i]), a, c.tables);
@@ -448,313 +522,361 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     quot.clear();
     tm.commit_quotient = ms_since(t0);
 
-    // ---------------- opening (lib.rs:606-619; App. B9)
-    t0 = Clock::now();
+    // ---------------- opening (lib.rs:606-619): pcs.open_multi_batches over the three rounds
     const Ext5 zeta = ch.sample_ext();
-    ProverData* rounds[3] = {main_pd.get(), perm_pd.get(), quot_pd.get()};
-    // points[r][i]
-    std::vector<std::vector<std::vector<Ext5>>> points(3, std::vector<std::vector<Ext5>>(NC));
+    std::vector<OpenRound> rounds(3);
+    rounds[0].pd = main_pd.get(); rounds[1].pd = perm_pd.get(); rounds[2].pd = quot_pd.get();
     for (size_t i = 0; i < NC; i++) {
         Fp g = vg::two_adic_generator(log_deg[i]);
-        points[0][i] = {zeta, zeta * g};
-        points[1][i] = {zeta, zeta * g};
-        points[2][i] = {zeta.exp_power_of_2(machine_.airs[i].log_quotient_degree)};
+        rounds[0].points.push_back({zeta, zeta * g});
+        rounds[1].points.push_back({zeta, zeta * g});
+        rounds[2].points.push_back({zeta.exp_power_of_2(machine_.airs[i].log_quotient_degree)});
     }
-    // opened[r][i][p] = vector<Ext5> (one per column)
-    std::vector<std::vector<std::vector<std::vector<Ext5>>>> opened(3, std::vector<std::vector<std::vector<Ext5>>>(NC));
+    PcsOpening opening = open_multi_batches(rounds, ch);
+    tm.open_values = opening.ms_values; tm.open_reduce = opening.ms_reduce; tm.fri = opening.ms_fri;
+    t0 = Clock::now();
+    const auto& opened = opening.opened;
+
+    // ---------------- assemble MachineProof (flat "VPF1" words; machine/src/proof.rs:13-44, App. B12)
+    std::vector<uint32_t> pw;
+    pw.push_back(PROOF_MAGIC);
+    pw.push_back((uint32_t)NC);
+    for (int k = 0; k < 8; k++) pw.push_back(main_pd->tree.root[k]);
+    for (int k = 0; k < 8; k++) pw.push_back(perm_pd->tree.root[k]);
+    for (int k = 0; k < 8; k++) pw.push_back(quot_pd->tree.root[k]);
+    auto put_vec = [&](const std::vector<Ext5>& v) {
+        pw.push_back((uint32_t)v.size());
+        for (auto& e : v) { uint32_t w5[5]; ext_to_canonical(e, w5); pw.insert(pw.end(), w5, w5 + 5); }
+    };
+    for (size_t i = 0; i < NC; i++) {
+        pw.push_back(log_deg[i]);
+        put_vec(opened[0][i][0]); put_vec(opened[0][i][1]);
+        put_vec(opened[1][i][0]); put_vec(opened[1][i][1]);
+        put_vec(opened[2][i][0]);
+        uint32_t w5[5]; ext_to_canonical(cumulative_sums[i], w5); pw.insert(pw.end(), w5, w5 + 5);
+    }
+    pw.insert(pw.end(), opening.proof_words.begin(), opening.proof_words.end());
+    tm.queries = opening.ms_queries + ms_since(t0);
+    c.profiler.collect();
+    tm.total = ms_since(t_total);
+    if (times) *times = tm;
+    if (dbg) {
+        if (prep_pd) memcpy(dbg->prep_root, prep_pd->tree.root, 32); else memset(dbg->prep_root, 0, 32);
+        for (int i = 0; i < 3; i++) ext_to_canonical(rnd[i], dbg->perm_challenges + 5 * i);
+        ext_to_canonical(alpha, dbg->alpha);
+        ext_to_canonical(zeta, dbg->zeta);
+    }
+    return pw;
+}
+
+// pcs.open_multi_batches (basic/src/lib.rs:611-619; Plonky3 TwoAdicFriPcs): opens every matrix of every
+// round at its points, reduces the openings per LDE height, runs the FRI commit phase, grinds, answers the queries.  `ch` is the
+// caller's transcript (the reference passes `&mut challenger`): it leaves advanced exactly as the reference leaves it.
+// Any number of rounds, matrices, columns and points per matrix: wide matrices and long point lists go through the kernels in
+// chunks (k_col_dot: <= 2 points and <= 1024 / (5 points) columns per launch; k_reduce_openings: <= 4 distinct points per launch).
+PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Challenger& ch) {
+    DeviceCtx& c = *ctx_;
+    c.activate();
+    const Fp s = Fp::from_canonical(vg::GENERATOR);
+    const unsigned lb = fri_.log_blowup;
+    const size_t NR = rounds.size();
+    if (!NR) throw std::invalid_argument("open: no rounds");
+    for (auto& r : rounds) {
+        if (!r.pd || r.pd->ldes.empty()) throw std::invalid_argument("open: empty round");
+        if (r.points.size() != r.pd->ldes.size()) throw std::invalid_argument("open: one point list per committed matrix is required");
+    }
+    PcsOpening res;
+    auto t0 = Clock::now();
+
+    // ---- opened values p_j(z) by barycentric evaluation over the first n rows of each bit-reversed LDE (App. B9)
+    res.opened.resize(NR);
     {
-        // constant pool: distinct (log_n, point) -> z words; per (r, i): scale factors
-        std::map<std::pair<unsigned, PointKey>, size_t> wkey;  // -> index into wlist
+        std::map<std::pair<unsigned, PointKey>, size_t> wkey;  // distinct (log_n, point) -> weight vector
         struct WEntry { unsigned log_n; Ext5 z; size_t pool_off; DBuf buf; };
         std::vector<WEntry> wlist;
         std::vector<uint32_t> pool;
-        struct Job { int r; size_t i; int np; size_t w[2]; size_t scale_off; size_t out_off; };
+        struct Job { size_t r, i; int p0, np; uint64_t c0, cw; size_t w[2]; size_t scale_off, out_off; };
         std::vector<Job> jobs;
         size_t out_words = 0;
-        for (int r = 0; r < 3; r++)
-            for (size_t i = 0; i < NC; i++) {
-                const DMat& lde = rounds[r]->ldes[i];
-                unsigned ln = vg::log2_strict_u64(lde.height) - lb;
-                uint64_t n = 1ull << ln;
-                Job j{r, i, (int)points[r][i].size(), {0, 0}, pool.size(), out_words};
-                for (int p = 0; p < j.np; p++) {
-                    const Ext5& z = points[r][i][p];
-                    // scale = (z^n - s^n) / (n s^(n-1))
-                    Ext5 zer = z.exp_power_of_2(ln) - s.exp_power_of_2(ln);
-                    Fp den = Fp::from_canonical((uint32_t)(n % vg::P)) * s.pow(n - 1);
-                    put_ext(pool, zer * den.inv());
+        for (size_t r = 0; r < NR; r++) {
+            res.opened[r].resize(rounds[r].pd->ldes.size());
+            for (size_t i = 0; i < rounds[r].pd->ldes.size(); i++) {
+                const DMat& lde = rounds[r].pd->ldes[i];
+                const unsigned ln = vg::log2_strict_u64(lde.height) - lb;
+                const uint64_t n = 1ull << ln;
+                const auto& pts = rounds[r].points[i];
+                res.opened[r][i].assign(pts.size(), std::vector<Ext5>(lde.width));
+                for (size_t p0 = 0; p0 < pts.size(); p0 += 2) {
+                    const int np = (int)std::min<size_t>(2, pts.size() - p0);
+                    size_t widx[2] = {0, 0};
+                    const size_t scale_off = pool.size();
+                    for (int p = 0; p < np; p++) {
+                        const Ext5& z = pts[p0 + p];
+                        // scale = (z^n - s^n) / (n s^(n-1))
+                        Ext5 zer = z.exp_power_of_2(ln) - s.exp_power_of_2(ln);
+                        Fp den = Fp::from_canonical((uint32_t)(n % vg::P)) * s.pow(n - 1);
+                        put_ext(pool, zer * den.inv());
+                    }
+                    for (int p = 0; p < np; p++) {
+                        const Ext5& z = pts[p0 + p];
+                        auto key = std::make_pair(ln, key_of(z));
+                        auto it = wkey.find(key);
+                        if (it == wkey.end()) { wkey[key] = wlist.size(); widx[p] = wlist.size(); wlist.push_back(WEntry{ln, z, 0, DBuf()}); }
+                        else widx[p] = it->second;
+                    }
+                    const uint64_t max_cols = vk::col_dot_max_columns(np);
+                    for (uint64_t c0 = 0; c0 < lde.width; c0 += max_cols) {
+                        const uint64_t cw = std::min<uint64_t>(max_cols, lde.width - c0);
+                        jobs.push_back(Job{r, i, (int)p0, np, c0, cw, {widx[0], widx[np - 1]}, scale_off, out_words});
+                        out_words += cw * np * 5;
+                    }
                 }
-                for (int p = 0; p < j.np; p++) {
-                    const Ext5& z = points[r][i][p];
-                    auto key = std::make_pair(ln, key_of(z));
-                    auto it = wkey.find(key);
-                    if (it == wkey.end()) {
-                        wkey[key] = wlist.size();
-                        j.w[p] = wlist.size();
-                        wlist.push_back(WEntry{ln, z, 0, DBuf()});
-                    } else j.w[p] = it->second;
-                }
-                out_words += lde.width * j.np * 5;
-                jobs.push_back(j);
             }
+        }
         for (auto& w : wlist) { w.pool_off = pool.size(); put_ext(pool, w.z); }
+        pool.push_back(0);
         DBuf pool_dev(&c, pool);
         for (auto& w : wlist) {
             uint64_t n = 1ull << w.log_n;
             w.buf = DBuf(&c, (size_t)(5 * n));
             vk::launch_bary_weights(c.stream, n, pool_dev.data + w.pool_off, s, c.tables, w.buf.data);
         }
-        DBuf out_dev(&c, out_words);
+        DBuf out_dev(&c, out_words + 4);
         std::vector<DBuf> partials;
         Section open_section(&c);
         size_t job_idx = 0;
         for (auto& j : jobs) {
-            const DMat& lde = rounds[j.r]->ldes[j.i];
-            uint64_t n = lde.height >> lb;
-            partials.emplace_back(&c, (size_t)(vk::col_dot_slots(n) * lde.width * j.np * 5));
-            vk::launch_col_dot(c.stream_for(job_idx++, n), lde.view(), n, j.np, wlist[j.w[0]].buf.data, wlist[j.w[j.np - 1]].buf.data, partials.back().data,
+            const DMat& lde = rounds[j.r].pd->ldes[j.i];
+            const uint64_t n = lde.height >> lb;
+            partials.emplace_back(&c, (size_t)(vk::col_dot_slots(n) * j.cw * j.np * 5));
+            vk::DMatView sub{lde.data + j.c0 * lde.height, lde.height, j.cw, lde.height};
+            vk::launch_col_dot(c.stream_for(job_idx++, n), sub, n, j.np, wlist[j.w[0]].buf.data, wlist[j.w[1]].buf.data, partials.back().data,
                                pool_dev.data + j.scale_off, out_dev.data + j.out_off);
         }
         open_section.join();
         c.check_launch("opened values");
-        std::vector<uint32_t> out(out_words);
+        std::vector<uint32_t> out(out_words + 4);
         c.download(out.data(), out_dev.data, out_words * 4);
-        for (auto& j : jobs) {
-            uint64_t w = rounds[j.r]->ldes[j.i].width;
-            opened[j.r][j.i].assign(j.np, std::vector<Ext5>(w));
-            for (uint64_t col = 0; col < w; col++)
-                for (int p = 0; p < j.np; p++) opened[j.r][j.i][p][col] = ext_from_canonical(&out[j.out_off + (col * j.np + p) * 5]);
-        }
+        for (auto& j : jobs)
+            for (uint64_t col = 0; col < j.cw; col++)
+                for (int p = 0; p < j.np; p++) res.opened[j.r][j.i][j.p0 + p][j.c0 + col] = ext_from_canonical(&out[j.out_off + (col * j.np + p) * 5]);
     }
-    tm.open_values = ms_since(t0);
+    res.ms_values = ms_since(t0);
 
-    // reduced openings per LDE height
+    // ---- reduced openings per LDE height (App. B9): ro[x] += alpha^offset * sum_j alpha^j (ys_j - row_j(x)) / (z - x)
     t0 = Clock::now();
     const Ext5 alpha_b = ch.sample_ext();
     std::map<unsigned, DBuf> ro;  // log_height -> pair-layout vector
     unsigned log_max = 0;
     {
-        struct MatEntry { const DMat* lde; std::vector<std::tuple<uint32_t, Ext5, Ext5>> pts; };
-        struct Group { std::vector<Ext5> zs; std::map<PointKey, uint32_t> slot; std::vector<MatEntry> mats; size_t max_w = 0; uint64_t num_reduced = 0; };
+        struct MatEntry { const DMat* lde; std::vector<std::tuple<uint32_t, Ext5, Ext5>> pts; };  // (slot, alpha^offset, Y)
+        struct Group { std::vector<Ext5> zs; std::map<PointKey, uint32_t> slot; std::vector<MatEntry> mats; uint64_t num_reduced = 0; };
         std::map<unsigned, Group> groups;
         size_t max_width = 0;
-        for (int r = 0; r < 3; r++) for (auto& l : rounds[r]->ldes) max_width = std::max<size_t>(max_width, l.width);
+        for (auto& r : rounds) for (auto& l : r.pd->ldes) max_width = std::max<size_t>(max_width, l.width);
         std::vector<Ext5> apow(max_width);
         { Ext5 p = Ext5::one(); for (auto& a : apow) { a = p; p *= alpha_b; } }
-        for (int r = 0; r < 3; r++)
-            for (size_t i = 0; i < NC; i++) {
-                const DMat& lde = rounds[r]->ldes[i];
+        for (size_t r = 0; r < NR; r++)
+            for (size_t i = 0; i < rounds[r].pd->ldes.size(); i++) {
+                const DMat& lde = rounds[r].pd->ldes[i];
                 unsigned lh = vg::log2_strict_u64(lde.height);
                 Group& g = groups[lh];
-                g.max_w = std::max<size_t>(g.max_w, lde.width);
                 MatEntry me{&lde, {}};
-                for (size_t p = 0; p < points[r][i].size(); p++) {
-                    const Ext5& z = points[r][i][p];
+                for (size_t p = 0; p < rounds[r].points[i].size(); p++) {
+                    const Ext5& z = rounds[r].points[i][p];
                     auto key = key_of(z);
                     auto it = g.slot.find(key);
                     uint32_t slot;
                     if (it == g.slot.end()) { slot = (uint32_t)g.zs.size(); g.slot[key] = slot; g.zs.push_back(z); } else slot = it->second;
-                    if (slot >= 4) throw std::runtime_error("open: more than 4 distinct opening points per LDE height is not supported");
                     Ext5 Y = Ext5::zero();
-                    auto& ys = opened[r][i][p];
+                    auto& ys = res.opened[r][i][p];
                     for (size_t col = 0; col < ys.size(); col++) Y += apow[col] * ys[col];
                     me.pts.emplace_back(slot, alpha_b.pow(g.num_reduced), Y);
                     g.num_reduced += lde.width;
                 }
                 g.mats.push_back(std::move(me));
             }
+        // one descriptor per (height, chunk of <= MAX_OPEN_POINTS distinct points); later chunks accumulate into the vector
+        struct Launch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; };
+        std::vector<Launch> launches;
         std::vector<uint32_t> pool;
-        std::map<unsigned, size_t> off;
         for (auto& kv : groups) {
             Group& g = kv.second;
-            off[kv.first] = pool.size();
-            pool.push_back((uint32_t)g.mats.size());
-            pool.push_back((uint32_t)g.zs.size());
-            pool.push_back((uint32_t)g.max_w);
-            for (auto& z : g.zs) put_ext(pool, z);
-            for (size_t col = 0; col < g.max_w; col++) put_ext(pool, apow[col]);
-            for (auto& me : g.mats) {
-                put_ptr(pool, me.lde->data);
-                put_u64(pool, me.lde->height);
-                pool.push_back((uint32_t)me.lde->width);
-                pool.push_back((uint32_t)me.pts.size());
-                for (auto& t : me.pts) { pool.push_back(std::get<0>(t)); put_ext(pool, std::get<1>(t)); put_ext(pool, std::get<2>(t)); }
+            for (uint32_t s0 = 0; s0 < g.zs.size() || s0 == 0; s0 += vk::MAX_OPEN_POINTS_PER_LAUNCH) {
+                const uint32_t s1 = std::min<uint32_t>((uint32_t)g.zs.size(), s0 + vk::MAX_OPEN_POINTS_PER_LAUNCH);
+                std::vector<const MatEntry*> live;
+                size_t max_w = 0;
+                uint64_t total_width = 0;
+                for (auto& me : g.mats) {
+                    bool any = false;
+                    for (auto& t : me.pts) any |= std::get<0>(t) >= s0 && std::get<0>(t) < s1;
+                    if (any) { live.push_back(&me); max_w = std::max<size_t>(max_w, me.lde->width); total_width += me.lde->width; }
+                }
+                launches.push_back({kv.first, pool.size(), s0 != 0, total_width});
+                pool.push_back((uint32_t)live.size());
+                pool.push_back(s1 - s0);
+                pool.push_back((uint32_t)max_w);
+                for (uint32_t q = s0; q < s1; q++) put_ext(pool, g.zs[q]);
+                for (size_t col = 0; col < max_w; col++) put_ext(pool, apow[col]);
+                for (auto* me : live) {
+                    put_ptr(pool, me->lde->data);
+                    put_u64(pool, me->lde->height);
+                    pool.push_back((uint32_t)me->lde->width);
+                    uint32_t cnt = 0;
+                    for (auto& t : me->pts) cnt += std::get<0>(t) >= s0 && std::get<0>(t) < s1;
+                    pool.push_back(cnt);
+                    for (auto& t : me->pts)
+                        if (std::get<0>(t) >= s0 && std::get<0>(t) < s1) { pool.push_back(std::get<0>(t) - s0); put_ext(pool, std::get<1>(t)); put_ext(pool, std::get<2>(t)); }
+                }
+                if (g.zs.size() <= s1) break;
             }
         }
         DBuf pool_dev(&c, pool);
+        for (auto& kv : groups) { ro[kv.first] = DBuf(&c, (size_t)(5ull << kv.first)); log_max = std::max(log_max, kv.first); }
         Section reduce_section(&c);
+        std::map<unsigned, hipStream_t> stream_of;  // chunks of one height must stay on one stream (they accumulate in order)
         size_t grp_idx = 0;
-        for (auto& kv : groups) {
-            uint64_t L = 1ull << kv.first;
-            ro[kv.first] = DBuf(&c, (size_t)(5 * L));
-            uint64_t total_width = 0;
-            for (auto& me : kv.second.mats) total_width += me.lde->width;
-            vk::launch_reduce_openings(c.stream_for(grp_idx++, L), pool_dev.data + off[kv.first], L, s, c.tables, ro[kv.first].data, total_width);
-            log_max = std::max(log_max, kv.first);
+        for (auto& l : launches) {
+            const uint64_t L = 1ull << l.lh;
+            if (!stream_of.count(l.lh)) stream_of[l.lh] = c.stream_for(grp_idx++, L);
+            vk::launch_reduce_openings(stream_of[l.lh], pool_dev.data + l.off, L, s, c.tables, ro[l.lh].data, l.total_width, l.accumulate);
         }
         reduce_section.join();
         c.check_launch("reduce openings");
         c.sync();
     }
-    tm.open_reduce = ms_since(t0);
+    res.ms_reduce = ms_since(t0);
+    if (log_max < lb + 0u) throw std::invalid_argument("open: nothing to open");
 
-    // FRI commit phase (App. B10)
+    // ---- FRI commit phase (App. B10)
     t0 = Clock::now();
     std::vector<DBuf> layer_bufs;          // layer i vector (length 2^(log_max - i)), pair layout
     std::vector<DeviceTree> layer_trees;
     std::vector<std::array<uint32_t, 8>> commit_phase_commits;
-    {
-        DBuf cur = std::move(ro[log_max]);
-        ro.erase(log_max);
-        // The transcript moves to the device for the commit phase: per layer k_fri_challenge observes the root where
-        // the tree left it and samples beta, the fold reads beta from device memory — no host round trip inside the
-        // chain of dependent layers.  Roots, the final values and the sponge state come back in one sync below.
-        const unsigned n_layers = log_max - lb;
-        std::vector<uint32_t> chw(vk::DEV_CHALLENGER_WORDS, 0);
-        for (int i = 0; i < 16; i++) chw[i] = ch.state[i].v;
-        for (size_t i = 0; i < ch.in.size(); i++) chw[16 + i] = ch.in[i].v;
-        chw[32] = (uint32_t)ch.in.size();
-        for (size_t i = 0; i < ch.out.size(); i++) chw[33 + i] = ch.out[i].v;
-        chw[49] = (uint32_t)ch.out.size();
-        DBuf ch_dev(&c, chw), betas_dev(&c, (size_t)(5 * n_layers + 8)), commits_dev(&c, (size_t)(8 * n_layers + 8));
-        unsigned li = 0;
-        for (unsigned lf = log_max; lf-- > lb; li++) {
-            uint64_t L = 2ull << lf, half = L >> 1;  // current length 2^(lf+1)
-            layer_trees.emplace_back();
-            layer_trees.back().build(&c, {vk::DMatView{cur.data, half, 10, half}}, false);
-            vk::launch_fri_challenge(c.stream, pow_pos_.data, ch_dev.data, layer_trees.back().layers.back().data, betas_dev.data + 5 * li, commits_dev.data + 8 * li);
-            DBuf next(&c, (size_t)(5 * half));
-            auto it = ro.find(lf);
-            vk::launch_fri_fold(c.stream, cur.data, L, betas_dev.data + 5 * li, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);
-            layer_bufs.push_back(std::move(cur));
-            cur = std::move(next);
-        }
-        c.check_launch("fri fold");
-        // `cur` now holds 2^lb values that must all be equal (a constant polynomial)
-        std::vector<uint32_t> fin(5ull << lb), commits(8 * n_layers);
-        VG_HIP_CHECK(hipMemcpyAsync(chw.data(), ch_dev.data, chw.size() * 4, hipMemcpyDeviceToHost, c.stream));
-        if (n_layers) VG_HIP_CHECK(hipMemcpyAsync(commits.data(), commits_dev.data, commits.size() * 4, hipMemcpyDeviceToHost, c.stream));
-        c.download(fin.data(), cur.data, fin.size() * 4);  // synchronises the stream: all three copies have landed
-        for (int i = 0; i < 16; i++) ch.state[i] = Fp::raw(chw[i]);
-        ch.in.clear();
-        for (uint32_t i = 0; i < chw[32]; i++) ch.in.push_back(Fp::raw(chw[16 + i]));
-        ch.out.clear();
-        for (uint32_t i = 0; i < chw[49]; i++) ch.out.push_back(Fp::raw(chw[33 + i]));
-        for (unsigned i = 0; i < n_layers; i++) {
-            std::array<uint32_t, 8> root;
-            memcpy(root.data(), commits.data() + 8 * i, 32);
-            memcpy(layer_trees[i].root, root.data(), 32);
-            commit_phase_commits.push_back(root);
-        }
-        // pair layout of a length-2^lb vector: (2^lb / 2) rows x 10 columns
-        uint64_t rows = (1ull << lb) >> 1;
-        auto elem = [&](uint64_t idx) { Ext5 e; for (int k = 0; k < 5; k++) e.c[k] = Fp::raw(fin[((idx & 1) * 5 + k) * rows + (idx >> 1)]); return e; };
-        Ext5 fp0 = elem(0);
-        for (uint64_t q = 1; q < (1ull << lb); q++) if (elem(q) != fp0) throw std::runtime_error("fri: final polynomial is not constant");
-        layer_bufs.push_back(std::move(cur));  // keep alive (not opened)
-        ro.clear();
-        // stash final poly in canonical form at the end of commit list handling below
-        uint32_t fpw[5];
-        ext_to_canonical(fp0, fpw);
-        if (fri_.observe_final_poly) ch.observe_ext(fp0);
-        uint32_t pow_witness = grind(ch);
-        tm.fri = ms_since(t0);
-
-        // ---------------- queries
-        t0 = Clock::now();
-        std::vector<uint64_t> indices(fri_.num_queries);
-        for (auto& ix : indices) ix = ch.sample_bits(log_max);
-        GatherList gl;
-        struct QOff { std::vector<uint32_t> sib; std::vector<std::vector<uint32_t>> layer_path; std::vector<std::vector<uint32_t>> rows; std::vector<std::vector<uint32_t>> path; };
-        std::vector<QOff> qoff(indices.size());
-        auto add_path = [&](const DeviceTree& t, uint64_t idx, std::vector<uint32_t>& out) {
-            for (unsigned l = 0; l < t.log_max_height; l++) out.push_back(gl.add(t.layers[l].data + 8 * ((idx >> l) ^ 1), 1, 8, 1));
-        };
-        for (size_t q = 0; q < indices.size(); q++) {
-            uint64_t index = indices[q];
-            QOff& o = qoff[q];
-            o.layer_path.resize(layer_trees.size());
-            for (size_t li = 0; li < layer_trees.size(); li++) {
-                uint64_t idx_i = index >> li, sib = idx_i ^ 1, pair = idx_i >> 1;
-                uint64_t half = 1ull << (log_max - 1 - li);
-                o.sib.push_back(gl.add(layer_bufs[li].data + (5 * (sib & 1)) * half + pair, half, 5, 0));
-                add_path(layer_trees[li], pair, o.layer_path[li]);
-            }
-            o.rows.resize(3); o.path.resize(3);
-            for (int r = 0; r < 3; r++) {
-                const DeviceTree& t = rounds[r]->tree;
-                uint64_t idx_r = index >> (log_max - t.log_max_height);
-                for (auto& lde : rounds[r]->ldes) {
-                    unsigned lh = vg::log2_strict_u64(lde.height);
-                    uint64_t row = idx_r >> (t.log_max_height - lh);
-                    o.rows[r].push_back(gl.add(lde.data + row, lde.height, (uint32_t)lde.width, 0));
-                }
-                add_path(t, idx_r, o.path[r]);
-            }
-        }
-        DBuf gd(&c, gl.desc), gout(&c, gl.next_dst);
-        vk::launch_gather(c.stream, gd.data, gl.n(), gout.data);
-        c.check_launch("query gather");
-        std::vector<uint32_t> g(gl.next_dst);
-        c.download(g.data(), gout.data, g.size() * 4);
-
-        // ---------------- assemble MachineProof (flat "VPF1" words; machine/src/proof.rs:13-44, App. B12)
-        std::vector<uint32_t> pw;
-        pw.push_back(PROOF_MAGIC);
-        pw.push_back((uint32_t)NC);
-        for (int k = 0; k < 8; k++) pw.push_back(main_pd->tree.root[k]);
-        for (int k = 0; k < 8; k++) pw.push_back(perm_pd->tree.root[k]);
-        for (int k = 0; k < 8; k++) pw.push_back(quot_pd->tree.root[k]);
-        auto put_vec = [&](const std::vector<Ext5>& v) {
-            pw.push_back((uint32_t)v.size());
-            for (auto& e : v) { uint32_t w5[5]; ext_to_canonical(e, w5); pw.insert(pw.end(), w5, w5 + 5); }
-        };
-        for (size_t i = 0; i < NC; i++) {
-            pw.push_back(log_deg[i]);
-            put_vec(opened[0][i][0]); put_vec(opened[0][i][1]);
-            put_vec(opened[1][i][0]); put_vec(opened[1][i][1]);
-            put_vec(opened[2][i][0]);
-            uint32_t w5[5]; ext_to_canonical(cumulative_sums[i], w5); pw.insert(pw.end(), w5, w5 + 5);
-        }
-        pw.push_back((uint32_t)commit_phase_commits.size());
-        for (auto& r : commit_phase_commits) pw.insert(pw.end(), r.begin(), r.end());
-        pw.push_back((uint32_t)indices.size());
-        for (size_t q = 0; q < indices.size(); q++) {
-            pw.push_back((uint32_t)layer_trees.size());
-            for (size_t li = 0; li < layer_trees.size(); li++) {
-                pw.insert(pw.end(), &g[qoff[q].sib[li]], &g[qoff[q].sib[li]] + 5);
-                pw.push_back((uint32_t)qoff[q].layer_path[li].size());
-                for (uint32_t o : qoff[q].layer_path[li]) pw.insert(pw.end(), &g[o], &g[o] + 8);
-            }
-        }
-        pw.insert(pw.end(), fpw, fpw + 5);
-        pw.push_back(pow_witness);
-        pw.push_back((uint32_t)indices.size());
-        for (size_t q = 0; q < indices.size(); q++) {
-            pw.push_back(3);
-            for (int r = 0; r < 3; r++) {
-                pw.push_back((uint32_t)rounds[r]->ldes.size());
-                for (size_t i = 0; i < rounds[r]->ldes.size(); i++) {
-                    uint32_t w = (uint32_t)rounds[r]->ldes[i].width;
-                    pw.push_back(w);
-                    pw.insert(pw.end(), &g[qoff[q].rows[r][i]], &g[qoff[q].rows[r][i]] + w);
-                }
-                pw.push_back((uint32_t)qoff[q].path[r].size());
-                for (uint32_t o : qoff[q].path[r]) pw.insert(pw.end(), &g[o], &g[o] + 8);
-            }
-        }
-        tm.queries = ms_since(t0);
-        c.profiler.collect();
-        tm.total = ms_since(t_total);
-        if (times) *times = tm;
-        if (dbg) {
-            if (prep_pd) memcpy(dbg->prep_root, prep_pd->tree.root, 32); else memset(dbg->prep_root, 0, 32);
-            for (int i = 0; i < 3; i++) ext_to_canonical(rnd[i], dbg->perm_challenges + 5 * i);
-            ext_to_canonical(alpha, dbg->alpha);
-            ext_to_canonical(zeta, dbg->zeta);
-        }
-        return pw;
+    DBuf cur = std::move(ro[log_max]);
+    ro.erase(log_max);
+    // The transcript moves to the device for the commit phase: per layer k_fri_challenge observes the root where
+    // the tree left it and samples beta, the fold reads beta from device memory — no host round trip inside the
+    // chain of dependent layers.  Roots, the final values and the sponge state come back in one sync below.
+    const unsigned n_layers = log_max - lb;
+    std::vector<uint32_t> chw(vk::DEV_CHALLENGER_WORDS, 0);
+    for (int i = 0; i < 16; i++) chw[i] = ch.state[i].v;
+    for (size_t i = 0; i < ch.in.size(); i++) chw[16 + i] = ch.in[i].v;
+    chw[32] = (uint32_t)ch.in.size();
+    for (size_t i = 0; i < ch.out.size(); i++) chw[33 + i] = ch.out[i].v;
+    chw[49] = (uint32_t)ch.out.size();
+    DBuf ch_dev(&c, chw), betas_dev(&c, (size_t)(5 * n_layers + 8)), commits_dev(&c, (size_t)(8 * n_layers + 8));
+    unsigned li = 0;
+    for (unsigned lf = log_max; lf-- > lb; li++) {
+        uint64_t L = 2ull << lf, half = L >> 1;  // current length 2^(lf+1)
+        layer_trees.emplace_back();
+        layer_trees.back().build(&c, {vk::DMatView{cur.data, half, 10, half}}, false);
+        vk::launch_fri_challenge(c.stream, pow_pos_.data, ch_dev.data, layer_trees.back().layers.back().data, betas_dev.data + 5 * li, commits_dev.data + 8 * li);
+        DBuf next(&c, (size_t)(5 * half));
+        auto it = ro.find(lf);
+        vk::launch_fri_fold(c.stream, cur.data, L, betas_dev.data + 5 * li, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);
+        layer_bufs.push_back(std::move(cur));
+        cur = std::move(next);
     }
+    c.check_launch("fri fold");
+    // `cur` now holds 2^lb values that must all be equal (a constant polynomial)
+    std::vector<uint32_t> fin(5ull << lb), commits(8 * n_layers + 8);
+    VG_HIP_CHECK(hipMemcpyAsync(chw.data(), ch_dev.data, chw.size() * 4, hipMemcpyDeviceToHost, c.stream));
+    if (n_layers) VG_HIP_CHECK(hipMemcpyAsync(commits.data(), commits_dev.data, 8 * n_layers * 4, hipMemcpyDeviceToHost, c.stream));
+    c.download(fin.data(), cur.data, fin.size() * 4);  // synchronises the stream: all three copies have landed
+    for (int i = 0; i < 16; i++) ch.state[i] = Fp::raw(chw[i]);
+    ch.in.clear();
+    for (uint32_t i = 0; i < chw[32]; i++) ch.in.push_back(Fp::raw(chw[16 + i]));
+    ch.out.clear();
+    for (uint32_t i = 0; i < chw[49]; i++) ch.out.push_back(Fp::raw(chw[33 + i]));
+    for (unsigned i = 0; i < n_layers; i++) {
+        std::array<uint32_t, 8> root;
+        memcpy(root.data(), commits.data() + 8 * i, 32);
+        memcpy(layer_trees[i].root, root.data(), 32);
+        commit_phase_commits.push_back(root);
+    }
+    // pair layout of a length-2^lb vector: (2^lb / 2) rows x 10 columns
+    const uint64_t frows = (1ull << lb) >> 1;
+    auto elem = [&](uint64_t idx) { Ext5 e; for (int k = 0; k < 5; k++) e.c[k] = Fp::raw(fin[((idx & 1) * 5 + k) * frows + (idx >> 1)]); return e; };
+    Ext5 fp0 = elem(0);
+    for (uint64_t q = 1; q < (1ull << lb); q++) if (elem(q) != fp0) throw std::runtime_error("fri: final polynomial is not constant");
+    layer_bufs.push_back(std::move(cur));  // keep alive (not opened)
+    ro.clear();
+    uint32_t fpw[5];
+    ext_to_canonical(fp0, fpw);
+    if (fri_.observe_final_poly) ch.observe_ext(fp0);
+    uint32_t pow_witness = grind(ch);
+    res.ms_fri = ms_since(t0);
+
+    // ---- queries
+    t0 = Clock::now();
+    std::vector<uint64_t> indices(fri_.num_queries);
+    for (auto& ix : indices) ix = ch.sample_bits(log_max);
+    GatherList gl;
+    struct QOff { std::vector<uint32_t> sib; std::vector<std::vector<uint32_t>> layer_path; std::vector<std::vector<uint32_t>> rows; std::vector<std::vector<uint32_t>> path; };
+    std::vector<QOff> qoff(indices.size());
+    auto add_path = [&](const DeviceTree& t, uint64_t idx, std::vector<uint32_t>& out) {
+        for (unsigned l = 0; l < t.log_max_height; l++) out.push_back(gl.add(t.layers[l].data + 8 * ((idx >> l) ^ 1), 1, 8, 1));
+    };
+    for (size_t q = 0; q < indices.size(); q++) {
+        uint64_t index = indices[q];
+        QOff& o = qoff[q];
+        o.layer_path.resize(layer_trees.size());
+        for (size_t l = 0; l < layer_trees.size(); l++) {
+            uint64_t idx_i = index >> l, sib = idx_i ^ 1, pair = idx_i >> 1;
+            uint64_t half = 1ull << (log_max - 1 - l);
+            o.sib.push_back(gl.add(layer_bufs[l].data + (5 * (sib & 1)) * half + pair, half, 5, 0));
+            add_path(layer_trees[l], pair, o.layer_path[l]);
+        }
+        o.rows.resize(NR); o.path.resize(NR);
+        for (size_t r = 0; r < NR; r++) {
+            const DeviceTree& t = rounds[r].pd->tree;
+            uint64_t idx_r = index >> (log_max - t.log_max_height);
+            for (auto& lde : rounds[r].pd->ldes) {
+                unsigned lh = vg::log2_strict_u64(lde.height);
+                uint64_t row = idx_r >> (t.log_max_height - lh);
+                o.rows[r].push_back(gl.add(lde.data + row, lde.height, (uint32_t)lde.width, 0));
+            }
+            add_path(t, idx_r, o.path[r]);
+        }
+    }
+    DBuf gd(&c, gl.desc), gout(&c, gl.next_dst + 4);
+    vk::launch_gather(c.stream, gd.data, gl.n(), gout.data);
+    c.check_launch("query gather");
+    std::vector<uint32_t> g(gl.next_dst + 4);
+    c.download(g.data(), gout.data, (size_t)gl.next_dst * 4);
+
+    // ---- TwoAdicFriPcsProof as words (the tail of the "VPF1" layout, App. B12)
+    std::vector<uint32_t>& pw = res.proof_words;
+    pw.push_back((uint32_t)commit_phase_commits.size());
+    for (auto& r : commit_phase_commits) pw.insert(pw.end(), r.begin(), r.end());
+    pw.push_back((uint32_t)indices.size());
+    for (size_t q = 0; q < indices.size(); q++) {
+        pw.push_back((uint32_t)layer_trees.size());
+        for (size_t l = 0; l < layer_trees.size(); l++) {
+            pw.insert(pw.end(), &g[qoff[q].sib[l]], &g[qoff[q].sib[l]] + 5);
+            pw.push_back((uint32_t)qoff[q].layer_path[l].size());
+            for (uint32_t o : qoff[q].layer_path[l]) pw.insert(pw.end(), &g[o], &g[o] + 8);
+        }
+    }
+    pw.insert(pw.end(), fpw, fpw + 5);
+    pw.push_back(pow_witness);
+    pw.push_back((uint32_t)indices.size());
+    for (size_t q = 0; q < indices.size(); q++) {
+        pw.push_back((uint32_t)NR);
+        for (size_t r = 0; r < NR; r++) {
+            pw.push_back((uint32_t)rounds[r].pd->ldes.size());
+            for (size_t i = 0; i < rounds[r].pd->ldes.size(); i++) {
+                uint32_t w = (uint32_t)rounds[r].pd->ldes[i].width;
+                pw.push_back(w);
+                pw.insert(pw.end(), &g[qoff[q].rows[r][i]], &g[qoff[q].rows[r][i]] + w);
+            }
+            pw.push_back((uint32_t)qoff[q].path[r].size());
+            for (uint32_t o : qoff[q].path[r]) pw.insert(pw.end(), &g[o], &g[o] + 8);
+        }
+    }
+    res.ms_queries = ms_since(t0);
+    return res;
 }
 
 }  // namespace vhost

@@ -24,6 +24,7 @@ struct DeviceTrace {
     DBuf raw;
     DMat nat;
     uint64_t height = 0, width = 0;
+    bool nat_rows_bitrev = false;  // `nat` holds row i at position bitrev(i) (the quotient chunks of vgpu_quotient): commit skips its row permutation
 };
 
 // The VM's operation logs, as the chips' generate_trace reads them (cpu/src/lib.rs:79-97, memory/src/lib.rs:143-160,
@@ -56,6 +57,18 @@ struct ProveDebugOut {  // optional intermediate values for stage-parity tests (
     std::vector<std::vector<uint32_t>> quotient_chunks;  // per chip: n x 10 row-major, natural order
 };
 
+// pcs.open_multi_batches (basic/src/lib.rs:611-619): one entry per commitment round — its ProverData and, per committed
+// matrix (commit order), the points it is opened at.
+struct OpenRound {
+    const ProverData* pd = nullptr;
+    std::vector<std::vector<Ext5>> points;
+};
+struct PcsOpening {
+    std::vector<std::vector<std::vector<std::vector<Ext5>>>> opened;  // [round][matrix][point][column]  (lib.rs:622-645)
+    std::vector<uint32_t> proof_words;                                 // TwoAdicFriPcsProof: the tail of the "VPF1" layout (App. B12)
+    double ms_values = 0, ms_reduce = 0, ms_fri = 0, ms_queries = 0;
+};
+
 class Prover {
   public:
     Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_rc480, const FriParams& fri);
@@ -79,6 +92,15 @@ class Prover {
     std::vector<uint32_t> prove(const std::vector<const DeviceTrace*>& main, const std::vector<std::pair<int, const DeviceTrace*>>& preprocessed,
                                 PhaseTimes* times = nullptr, ProveDebugOut* dbg = nullptr);
 
+    // pcs.open_multi_batches: advances `ch` exactly as the reference's `&mut challenger` is advanced.
+    PcsOpening open_multi_batches(const std::vector<OpenRound>& rounds, Challenger& ch);
+    // generate_permutation_trace of chip `chip` kept in HBM (working layout): perm trace + cumulative sum (chip.rs:121-208)
+    DMat permutation_trace(int chip, const DMat& main_nat, const DMat* prep_nat, const Ext5 rnd[3], Ext5* cumulative_sum);
+    // quotient + decompose_and_flatten of chip `chip` (machine/src/quotient.rs:18-67) from its three committed LDEs:
+    // n x 10 chunk matrix, rows at bit-reversed positions (what commit_shifted_batches consumes next)
+    DMat quotient_chunks(int chip, const DMat& main_lde, const DMat& perm_lde, const DMat* prep_lde, const Ext5 rnd[3], const Ext5& alpha,
+                         const Ext5& cumulative_sum);
+
   private:
     std::unique_ptr<DeviceCtx> ctx_;
     MachineDesc machine_;
@@ -87,6 +109,7 @@ class Prover {
     std::vector<DBuf> prog_dev_, iw_dev_;  // per chip: program instructions, interaction words
     DBuf pow_pos_;                         // [480 rc][16 mds coefficients][16 state][1 best] for k_pow_grind
     uint32_t grind(Challenger& ch);
+    void fill_quotient_args(vk::QuotientArgs& a, int chip, vk::DMatView main_lde, vk::DMatView perm_lde, vk::DMatView prep_lde, unsigned log_n, const uint32_t* consts_dev);
 };
 
 }  // namespace vhost

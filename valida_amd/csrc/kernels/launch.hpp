@@ -73,9 +73,14 @@ hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t 
 // open.hip
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w);
 uint64_t col_dot_slots(uint64_t n);
+uint64_t col_dot_max_columns(int np);  // widest matrix (view) one k_col_dot launch takes for np points; wider ones are opened in column chunks
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
                     const uint32_t* scale5_dev, uint32_t* out_dev);
-void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width);
+// accumulate: add to the vector already in `out` (a height with more than MAX_OPEN_POINTS_PER_LAUNCH distinct opening points is
+// reduced in several launches)
+constexpr int MAX_OPEN_POINTS_PER_LAUNCH = 4;
+void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width,
+                            bool accumulate = false);
 // beta5_dev: the folding challenge as 5 Montgomery words in device memory (written by k_fri_challenge)
 void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
 // One DuplexChallenger step on the device: observe the 8-word root at digest8_dev, sample beta into beta5_dev; the root is

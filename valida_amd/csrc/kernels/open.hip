@@ -187,9 +187,9 @@ __global__ void __launch_bounds__(64) k_col_dot_finish(const uint32_t* __restric
 //                    then n_pts x { [point slot] [coef: alpha^offset (5)] [Y = sum_c alpha^c y_c (5)] }
 // ro[j] = sum_p 1/(z_p - x_j) * sum_{(mat, p)} coef * (Y - sum_c alpha^c M[j][c])      (App. B9)
 // Output in pair layout: `out` is (L/2) x 10 column-major with stride L/2.
-constexpr int MAX_OPEN_POINTS = 4;
+constexpr int MAX_OPEN_POINTS = MAX_OPEN_POINTS_PER_LAUNCH;
 
-__global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restrict__ desc, uint64_t L, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restrict__ desc, uint64_t L, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ out, int accumulate) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= L) return;
     const uint32_t n_mats = desc[0], n_points = desc[1], max_w = desc[2];
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
     for (int p = MAX_OPEN_POINTS - 1; p >= 0; p--)
         if ((uint32_t)p < n_points) { ro += S[p] * (inv_run * pre[p]); inv_run = inv_run * d[p]; }
     const uint64_t half = L >> 1;
+    if (accumulate) ro += load_ext(out + (j & 1) * 5 * half, half, j >> 1);
     store_ext(out + (j & 1) * 5 * half, half, j >> 1, ro);
 }
 
@@ -416,10 +417,11 @@ uint64_t col_dot_slots(uint64_t n) {
     uint64_t tiles = (n + DOT_TR - 1) / DOT_TR;
     return tiles < (uint64_t)DOT_MAX_BLOCKS ? tiles : (uint64_t)DOT_MAX_BLOCKS;
 }
+uint64_t col_dot_max_columns(int np) { return (uint64_t)DOT_MAX_PASSES * DOT_THREADS / (5 * (uint64_t)np); }
 // m: LDE (only rows < n are read).  np = 1 or 2 points.  partial: col_dot_slots(n) * width * np * 5 words.
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
                     const uint32_t* scale5_dev, uint32_t* out_dev) {
-    if (m.width * np * 5 > (uint64_t)DOT_MAX_PASSES * DOT_THREADS) throw std::runtime_error("col_dot: matrix too wide (width * points * 5 > 1024)");
+    if (np < 1 || np > 2 || m.width > col_dot_max_columns(np)) throw std::runtime_error("col_dot: one launch takes 1 or 2 points and at most 1024 / (5 points) columns (the caller chunks)");
     unsigned blocks = (unsigned)col_dot_slots(n);
     const int pk = np * 5;
     size_t lds = (size_t)DOT_TRP * (m.width + pk) * 4;
@@ -428,9 +430,9 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
     else hipLaunchKernelGGL(k_col_dot<2>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
     hipLaunchKernelGGL(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
 }
-void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width) {
-    ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + 5.0));
-    hipLaunchKernelGGL(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out);
+void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width, bool accumulate) {
+    ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + (accumulate ? 10.0 : 5.0)));
+    hipLaunchKernelGGL(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out, accumulate ? 1 : 0);
 }
 void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
     uint64_t half = L >> 1;
