@@ -35,7 +35,11 @@ enum {
     VGPU_ERR_UNSUPPORTED = -4,
     VGPU_ERR_INTERNAL = -5
 };
-enum { VGPU_HASH_KECCAK256 = 0 /* reference configuration, basic/tests/test_prover.rs:424-431 */ };
+enum {
+    VGPU_HASH_KECCAK256 = 0,  /* the reference's MMCS: SerializingHasher32<Keccak256Hash> + CompressionFunctionFromHasher (basic/tests/test_prover.rs:424-431) */
+    VGPU_HASH_POSEIDON16 = 1  /* BASELINE.json north-star variant: PaddingFreeSponge<Perm16, 16, 8, 8> + TruncatedPermutation<Perm16, 2, 8, 16> over the
+                                 challenger's Poseidon-16 (same round constants); the reference never instantiates it */
+};
 
 const char* vgpu_last_error(void);
 const char* vgpu_version(void);
@@ -46,7 +50,7 @@ typedef struct vgpu_config {
     uint32_t log_blowup;           /* FriConfig.log_blowup      (test_prover.rs:443) */
     uint32_t num_queries;          /* FriConfig.num_queries     (:444) */
     uint32_t pow_bits;             /* FriConfig.proof_of_work_bits (:445) */
-    uint32_t hash_kind;            /* VGPU_HASH_KECCAK256 */
+    uint32_t hash_kind;            /* VGPU_HASH_KECCAK256 | VGPU_HASH_POSEIDON16 */
     uint32_t observe_final_poly;   /* convention switch, default 0 */
     uint32_t poseidon_rc[480];     /* Poseidon<_,CosetMds<16>,16,5> round constants (test_prover.rs:418-422), canonical */
     uint32_t interpret_air;        /* 0: BasicMachine chips run their ahead-of-time compiled eval kernels; 1: every AIR, in-tree

@@ -37,6 +37,13 @@ StarkConfig make_cfg(const uint32_t* rc, uint32_t log_blowup, uint32_t num_queri
 
 extern "C" {
 void oracle_set_observe_final_poly(int on) { g_observe_final_poly = on != 0; }
+// MMCS hash of every commitment made after the call: 0 = Keccak (reference), 1 = Poseidon-16 sponge / truncated permutation with
+// the given round constants (hash.hpp "MMCS hash selection")
+void oracle_set_mmcs_hash(int kind, const uint32_t* rc480) {
+    static std::unique_ptr<Poseidon16> keep;
+    if (kind == 1) { keep.reset(new Poseidon16(rc480)); mmcs_hash().poseidon = keep.get(); }
+    mmcs_hash().kind = kind == 1 ? 1 : 0;
+}
 
 uint32_t oracle_two_adic_generator(uint32_t bits) { return two_adic_generator(bits).v; }
 uint32_t oracle_fp_mul(uint32_t a, uint32_t b) { return (Fp(a) * Fp(b)).v; }

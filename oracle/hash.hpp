@@ -76,7 +76,7 @@ using Digest = std::array<Fp, 8>;
 
 // SerializingHasher32<Keccak256Hash>::hash_iter: canonical u32 LE bytes in, digest bytes mapped to 8
 // field elements by from_wrapped_u32 of each LE word (App. B6).
-inline Digest hash_elems(const Fp* e, size_t n) {
+inline Digest keccak_hash_elems(const Fp* e, size_t n) {
     std::vector<uint8_t> bytes(4 * n);
     for (size_t i = 0; i < n; i++) { uint32_t v = e[i].v; memcpy(&bytes[4 * i], &v, 4); }  // little-endian host
     uint8_t out[32];
@@ -85,13 +85,11 @@ inline Digest hash_elems(const Fp* e, size_t n) {
     for (int i = 0; i < 8; i++) { uint32_t w; memcpy(&w, out + 4 * i, 4); d[i] = Fp(w); }
     return d;
 }
-inline Digest hash_elems(const std::vector<Fp>& e) { return hash_elems(e.data(), e.size()); }
-
 // CompressionFunctionFromHasher<Val, MyHash, 2, 8>: C(a, b) = H(a || b)
-inline Digest compress(const Digest& a, const Digest& b) {
+inline Digest keccak_compress(const Digest& a, const Digest& b) {
     Fp buf[16];
     for (int i = 0; i < 8; i++) { buf[i] = a[i]; buf[8 + i] = b[i]; }
-    return hash_elems(buf, 16);
+    return keccak_hash_elems(buf, 16);
 }
 
 // ---------------------------------------------------------------- Poseidon-16 / CosetMds
@@ -129,6 +127,38 @@ struct Poseidon16 {
         }
     }
 };
+
+// ---------------------------------------------------------------- MMCS hash selection
+// kind 0 (default): the reference's Keccak MMCS above.  kind 1: the north-star Poseidon variant, which the reference never
+// instantiates — PaddingFreeSponge<Perm16, 16, 8, 8> (hash_iter: for each chunk of RATE = 8 inputs OVERWRITE state[0..len) with
+// the chunk, permute; output state[0..8)) and TruncatedPermutation<Perm16, 2, 8, 16> (permute left || right, keep the first 8),
+// as p3-symmetric defines them ([P3-RECALL], unpinned).  A process-wide switch: this is test infrastructure.
+struct MmcsHash { int kind = 0; const Poseidon16* poseidon = nullptr; };
+inline MmcsHash& mmcs_hash() { static MmcsHash h; return h; }
+
+inline Digest hash_elems(const Fp* e, size_t n) {
+    const MmcsHash& h = mmcs_hash();
+    if (h.kind == 0) return keccak_hash_elems(e, n);
+    Fp st[16];
+    for (size_t base = 0; base < n; base += 8) {
+        for (size_t k = 0; k < 8 && base + k < n; k++) st[k] = e[base + k];
+        h.poseidon->permute(st);
+    }
+    Digest d;
+    for (int i = 0; i < 8; i++) d[i] = st[i];
+    return d;
+}
+inline Digest hash_elems(const std::vector<Fp>& e) { return hash_elems(e.data(), e.size()); }
+inline Digest compress(const Digest& a, const Digest& b) {
+    const MmcsHash& h = mmcs_hash();
+    if (h.kind == 0) return keccak_compress(a, b);
+    Fp st[16];
+    for (int i = 0; i < 8; i++) { st[i] = a[i]; st[8 + i] = b[i]; }
+    h.poseidon->permute(st);
+    Digest d;
+    for (int i = 0; i < 8; i++) d[i] = st[i];
+    return d;
+}
 
 // DuplexChallenger<Val, Perm16, 16> (App. B8): rate = full width, outputs popped from the END.
 struct Challenger {

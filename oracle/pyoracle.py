@@ -222,6 +222,15 @@ class ProveResult:
             self._h = None
 
 
+def set_mmcs_hash(kind, rc=None):
+    """0: Keccak MMCS (the reference's); 1: Poseidon-16 sponge / truncated permutation with round constants `rc`."""
+    if kind == 1:
+        r, rp = _u32(rc)
+        lib().oracle_set_mmcs_hash(ctypes.c_int(1), rp)
+    else:
+        lib().oracle_set_mmcs_hash(ctypes.c_int(0), None)
+
+
 def pcs_open(rounds, points, rc, observed=(), log_blowup=1, num_queries=40, pow_bits=8):
     """pcs.commit_batches per round + pcs.open_multi_batches: rounds = [[matrix, ...], ...] (row-major), points[r][i] = list of
     Ext5 (5 words).  Returns (roots [n_rounds x 8], opened values flat, TwoAdicFriPcsProof words)."""

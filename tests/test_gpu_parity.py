@@ -713,3 +713,38 @@ def test_open_multi_batches_generic_shapes_match_oracle(machine, rc):
     # the host transcript was advanced exactly as the oracle's: the next samples agree
     ref = po.challenger_probe  # oracle transcript replay is not exposed after pcs_open; the equal proof words (PoW witness,
     assert ref is not None     # query indices) already pin every value the transcript produced inside the call
+
+
+# ---- Poseidon-16 MMCS (vgpu_config.hash_kind = VGPU_HASH_POSEIDON16): BASELINE.json's north-star Merkle variant ---------------
+@pytest.fixture
+def poseidon_oracle(rc):
+    po.set_mmcs_hash(1, rc)
+    yield
+    po.set_mmcs_hash(0)
+
+
+def test_poseidon_mmcs_commit_roots(machine, rc, poseidon_oracle):
+    p = va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16)
+    rng = np.random.default_rng(5)
+    # widths around the sponge rate (8), mixed heights with injections at several layers, a one-row matrix, a tall one (2^13 rows:
+    # separate compress launches above the 1024-parent top kernel)
+    batches = [[rand_matrix(rng, 16, 7)], [rand_matrix(rng, 16, 8)], [rand_matrix(rng, 16, 9)], [rand_matrix(rng, 1, 3)],
+               [rand_matrix(rng, 64, 17), rand_matrix(rng, 64, 5), rand_matrix(rng, 16, 30), rand_matrix(rng, 2, 4), rand_matrix(rng, 1, 11)],
+               [rand_matrix(rng, 1 << 13, 3), rand_matrix(rng, 1 << 11, 20)]]
+    for mats in batches:
+        pd = p.commit_batches([p.upload(m) for m in mats])
+        assert first_mismatch(pd.root, po.commit_root(mats)) is None, [m.shape for m in mats]
+
+
+@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(40), lambda: va.Workload.fib(582)])
+def test_poseidon_mmcs_proof_bytes(machine, rc, poseidon_oracle, make):
+    p = va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16)
+    w = make()
+    mt, prep = w.main_traces(), w.preprocessed()
+    proof = p.prove([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep])
+    ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc)
+    assert first_mismatch(proof.transcript, ref.transcript) is None
+    assert first_mismatch(proof.words, ref.words) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc) is None
+    po.set_mmcs_hash(0)  # the Keccak verifier must not accept a Poseidon-committed proof
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc) is not None

@@ -21,6 +21,9 @@ c_u32p = ctypes.POINTER(ctypes.c_uint32)
 c_u64p = ctypes.POINTER(ctypes.c_uint64)
 
 
+HASH_KECCAK256, HASH_POSEIDON16 = 0, 1  # vgpu_config.hash_kind
+
+
 class VgpuError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("vgpu error %d: %s" % (code, msg))
@@ -457,10 +460,10 @@ class Ticket:
 class Prover:
     """One MI355X: StarkConfig + Machine -> prove().  Mirrors machine.prove(&config)."""
 
-    def __init__(self, machine, rc, device=0, log_blowup=1, num_queries=40, pow_bits=8, observe_final_poly=False, interpret_air=False):
+    def __init__(self, machine, rc, device=0, log_blowup=1, num_queries=40, pow_bits=8, observe_final_poly=False, interpret_air=False, hash_kind=HASH_KECCAK256):
         cfg = VgpuConfig()
         cfg.device, cfg.log_blowup, cfg.num_queries, cfg.pow_bits = device, log_blowup, num_queries, pow_bits
-        cfg.hash_kind, cfg.observe_final_poly, cfg.interpret_air = 0, int(observe_final_poly), int(interpret_air)
+        cfg.hash_kind, cfg.observe_final_poly, cfg.interpret_air = int(hash_kind), int(observe_final_poly), int(interpret_air)
         rc = np.ascontiguousarray(rc, dtype=np.uint32)
         assert rc.size == 480
         ctypes.memmove(cfg.poseidon_rc, rc.ctypes.data, 480 * 4)

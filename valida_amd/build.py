@@ -17,6 +17,7 @@ SOURCES = [
     "kernels/ntt.hip",
     "kernels/layout.hip",
     "kernels/merkle.hip",
+    "kernels/poseidon_mmcs.hip",
     "kernels/perm.hip",
     "kernels/quotient.hip",
     "kernels/open.hip",

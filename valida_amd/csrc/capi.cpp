@@ -242,13 +242,14 @@ void vgpu_poseidon16_permute(const uint32_t rc[480], uint32_t state[16]) {
 int32_t vgpu_prover_create(const vgpu_config_t* cfg, const vgpu_machine_t* machine, vgpu_prover_t** out) {
     VG_TRY({
         if (!cfg || !machine || !out) throw std::invalid_argument("null argument");
-        if (cfg->hash_kind != VGPU_HASH_KECCAK256) { g_err = "only VGPU_HASH_KECCAK256 is implemented"; return VGPU_ERR_UNSUPPORTED; }
+        if (cfg->hash_kind != VGPU_HASH_KECCAK256 && cfg->hash_kind != VGPU_HASH_POSEIDON16) { g_err = "hash_kind must be VGPU_HASH_KECCAK256 or VGPU_HASH_POSEIDON16"; return VGPU_ERR_UNSUPPORTED; }
         if (cfg->log_blowup < 1 || cfg->log_blowup > 4) throw std::invalid_argument("log_blowup must be in 1..4");
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= cfg->device) throw std::runtime_error("hip: no usable device (the product path has no CPU fallback)");
         FriParams fp;
         fp.log_blowup = cfg->log_blowup; fp.num_queries = cfg->num_queries; fp.pow_bits = cfg->pow_bits; fp.observe_final_poly = cfg->observe_final_poly != 0;
         fp.interpret_air = cfg->interpret_air != 0;
+        fp.hash_kind = (int)cfg->hash_kind;
         auto* p = new vgpu_prover();
         p->p.reset(new Prover(cfg->device, machine->desc, cfg->poseidon_rc, fp));
         *out = p;

@@ -16,6 +16,7 @@ struct FriParams {
     unsigned log_blowup = 1, num_queries = 40, pow_bits = 8;
     bool observe_final_poly = false;
     bool interpret_air = false;  // quotient: force the register-program interpreter even for the in-tree chips
+    int hash_kind = 0;           // MMCS hash: 0 Keccak-256 (reference), 1 Poseidon-16 sponge / truncated permutation (north-star variant)
 };
 
 // One Merkle tree over column-major device matrices of mixed heights (FieldMerkleTreeMmcs, App. B5).
@@ -61,7 +62,12 @@ struct DeviceTree {
         layers.clear(); layer_len.clear();
         layers.emplace_back(c, (size_t)maxh * 8);
         layer_len.push_back(maxh);
-        if (single) vk::launch_keccak_leaves_strided(c->stream, mats[0].data, mats[0].stride, (int)mats[0].width, maxh, layers[0].data);
+        const bool pos = c->hash_kind == 1;
+        const uint32_t* tab = c->poseidon_tab;
+        if (pos) {
+            if (single) vk::launch_poseidon_leaves_strided(c->stream, tab, mats[0].data, mats[0].stride, (int)mats[0].width, maxh, layers[0].data);
+            else vk::launch_poseidon_leaves(c->stream, tab, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
+        } else if (single) vk::launch_keccak_leaves_strided(c->stream, mats[0].data, mats[0].stride, (int)mats[0].width, maxh, layers[0].data);
         else vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
         vk::KeccakTopArgs top{};
@@ -70,8 +76,9 @@ struct DeviceTree {
             layer_len.push_back(len);
             const Group* inj = (gi < groups.size() && groups[gi].height == len) ? &groups[gi] : nullptr;
             if (len > 1024) {
-                vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
-                                           layers.back().data);
+                if (pos) vk::launch_poseidon_compress(c->stream, tab, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
+                else vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
+                                                layers.back().data);
             } else {  // the last <= 11 layers go into one launch
                 if (top.levels == 0) { top.prev = layers[layers.size() - 2].data; top.first_len = len; }
                 top.out[top.levels] = layers.back().data;
@@ -82,7 +89,7 @@ struct DeviceTree {
             if (inj) gi++;
             if (len == 1) break;
         }
-        if (top.levels) vk::launch_keccak_top(c->stream, top);
+        if (top.levels) { if (pos) vk::launch_poseidon_top(c->stream, tab, top); else vk::launch_keccak_top(c->stream, top); }
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
         c->check_launch("mmcs build");
         if (fetch_root) c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished

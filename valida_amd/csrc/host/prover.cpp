@@ -30,6 +30,8 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
         pos[480 + d] = acc.v;
     }
     pow_pos_ = DBuf(ctx_.get(), pos);
+    ctx_->hash_kind = fri_.hash_kind;
+    ctx_->poseidon_tab = pow_pos_.data;
 }
 
 // challenger.grind(bits) with the search on the device; canonical rule = smallest witness.

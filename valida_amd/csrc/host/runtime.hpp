@@ -28,6 +28,10 @@ struct DeviceCtx {
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
     vk::Profiler profiler;
+    // MMCS hash of this context (vgpu_config.hash_kind): 0 = Keccak-256 (the reference's configuration), 1 = Poseidon-16 sponge /
+    // truncated permutation; poseidon_tab = [480 round constants][16 MDS coefficients] on the device (owned by the Prover)
+    int hash_kind = 0;
+    const uint32_t* poseidon_tab = nullptr;
     // Auxiliary streams for fork/join sections: independent per-chip pipelines (tiny matrices are
     // latency-bound single-block launches) overlap with the big chips' kernels on the main stream.
     // One auxiliary stream.  The device exposes a handful of hardware queues (4 by default) that streams take in creation

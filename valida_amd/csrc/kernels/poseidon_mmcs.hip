@@ -1,0 +1,183 @@
+// Poseidon-16 Merkle commitment kernels: the MMCS of BASELINE.json's north-star configuration ("batched Poseidon permutations
+// for Merkle-tree commitment"), selected with vgpu_config.hash_kind = VGPU_HASH_POSEIDON16.  The reference itself instantiates
+// Poseidon only inside the challenger (basic/tests/test_prover.rs:418-431) and commits with Keccak (merkle.hip); this variant
+// is FieldMerkleTreeMmcs<BabyBear, PaddingFreeSponge<Perm16, 16, 8, 8>, TruncatedPermutation<Perm16, 2, 8, 16>, 8> over the same
+// Poseidon<BabyBear, CosetMds<16>, 16, 5> permutation (conventions of p3-symmetric, recalled — unpinned
+// like every Plonky3 convention):
+//   leaf digest(row)  = sponge: for each chunk of 8 row elements OVERWRITE state[0..len) with it, permute; output state[0..8)
+//   parent            = first 8 elements of Perm16(left || right)
+//   injection         = C(parent, H(rows)) exactly as in the Keccak tree (FieldMerkleTree, App. B5)
+// One thread per leaf / parent, the 16-element state in VGPRs in Montgomery form (LDE elements are absorbed as they lie in HBM,
+// no conversion); digests are 8 canonical words like the Keccak ones.  The 480 round constants and the 16 circulant MDS
+// coefficients are wave-uniform: they are read through the scalar cache (s_load_dwordx16 per round) rather than staged in LDS —
+// a uniform LDS read still costs a ds_read per value per wave, a scalar load costs no VALU/LDS issue slot at all.
+// Integer-VALU-bound: ~0.8 k instructions per round (16 x 16 lazily accumulated products), 30 rounds.
+#include "launch.hpp"
+
+namespace vk {
+
+struct PoseidonTab {
+    const uint32_t* __restrict__ rc;   // [30][16] Montgomery
+    const uint32_t* __restrict__ mds;  // [16] circulant coefficients: M[j][i] = mds[(j - i) & 15]
+};
+
+// y = M x with M circulant; four products share one Montgomery reduction (4 p^2 < 2^64)
+__device__ __forceinline__ void poseidon_mds(Fp (&st)[16], const uint32_t (&m)[16]) {
+    Fp out[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        Fp acc = Fp::zero();
+#pragma unroll
+        for (int i0 = 0; i0 < 16; i0 += 4) {
+            uint64_t t = 0;
+#pragma unroll
+            for (int i = i0; i < i0 + 4; i++) t += (uint64_t)m[(j - i) & 15] * st[i].v;
+            acc += Fp::raw(vg::monty_reduce_wide(t));
+        }
+        out[j] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) st[i] = out[i];
+}
+
+__device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonTab& tab) {
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        const uint32_t* rc = tab.rc + 16 * r;
+#pragma unroll
+        for (int i = 0; i < 16; i++) st[i] += Fp::raw(rc[i]);
+        if (r < 4 || r >= 26) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) { const Fp x2 = st[i] * st[i]; st[i] = x2 * x2 * st[i]; }
+        } else {
+            const Fp x2 = st[0] * st[0];
+            st[0] = x2 * x2 * st[0];
+        }
+        poseidon_mds(st, m);
+    }
+}
+
+struct PPtrCols {
+    const uint32_t* const* p;
+    __device__ __forceinline__ const uint32_t* operator[](int k) const { return p[k]; }
+};
+struct PStridedCols {
+    const uint32_t* base;
+    uint64_t stride;
+    __device__ __forceinline__ const uint32_t* operator[](int k) const { return base + (uint64_t)k * stride; }
+};
+
+// PaddingFreeSponge<Perm16, 16, 8, 8>::hash_iter over one row
+template <class Cols>
+__device__ __forceinline__ void poseidon_hash_row(const Cols cols, int n_elems, uint64_t r, const PoseidonTab& tab, uint32_t (&out)[8]) {
+    Fp st[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) st[i] = Fp::zero();
+    for (int base = 0; base < n_elems; base += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (base + k < n_elems) st[k] = Fp::raw(cols[base + k][r]);
+        poseidon16_permute(st, tab);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i].canonical();
+}
+// TruncatedPermutation<Perm16, 2, 8, 16>::compress
+__device__ __forceinline__ void poseidon_compress2(const uint32_t (&l)[8], const uint32_t (&r)[8], const PoseidonTab& tab, uint32_t (&out)[8]) {
+    Fp st[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { st[i] = Fp::from_canonical(l[i]); st[8 + i] = Fp::from_canonical(r[i]); }
+    poseidon16_permute(st, tab);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i].canonical();
+}
+
+__device__ __forceinline__ void p_load_digest(const uint32_t* p, uint32_t (&d)[8]) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w; d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
+}
+__device__ __forceinline__ void p_store_digest(uint32_t* p, const uint32_t (&d)[8]) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    q[1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+template <class Cols>
+__global__ void __launch_bounds__(256) k_poseidon_leaves(const Cols cols, int n_elems, uint64_t n_rows, PoseidonTab tab, uint32_t* __restrict__ digests) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint32_t d[8];
+    poseidon_hash_row(cols, n_elems, r, tab, d);
+    p_store_digest(digests + 8 * r, d);
+}
+
+__device__ __forceinline__ void poseidon_node(const uint32_t* __restrict__ prev, const uint32_t* const* cols, int n_elems, uint64_t i, const PoseidonTab& tab,
+                                              uint32_t* __restrict__ next) {
+    uint32_t l[8], r[8], d[8];
+    p_load_digest(prev + 16 * i, l);
+    p_load_digest(prev + 16 * i + 8, r);
+    poseidon_compress2(l, r, tab, d);
+    if (n_elems > 0) {
+        uint32_t h[8], d2[8];
+        poseidon_hash_row(PPtrCols{cols}, n_elems, i, tab, h);
+        poseidon_compress2(d, h, tab, d2);
+        p_store_digest(next + 8 * i, d2);
+    } else {
+        p_store_digest(next + 8 * i, d);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_poseidon_compress(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int n_elems, uint64_t n_out,
+                                                           PoseidonTab tab, uint32_t* __restrict__ next) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    poseidon_node(prev, cols, n_elems, i, tab, next);
+}
+
+// the last <= 11 levels of a tree in one launch (one 1024-thread workgroup, a barrier per level), as k_keccak_top
+__global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, PoseidonTab tab) {
+    const uint32_t* prev = a.prev;
+    for (int l = 0; l < a.levels; l++) {
+        const uint64_t len = a.first_len >> l;
+        if (threadIdx.x < len) poseidon_node(prev, a.cols[l], a.n_elems[l], threadIdx.x, tab, a.out[l]);
+        __threadfence_block();
+        __syncthreads();
+        prev = a.out[l];
+    }
+}
+
+// algorithmic VALU work: permutations x 30 rounds x (16 x 16 products + 64 reductions of 7 + S-boxes) / 64 lanes — a model for
+// the profiler's valu_ops column, like KECCAK_VALU_PER_PERM
+constexpr double POSEIDON_VALU_PER_PERM = 30.0 * (256.0 + 64.0 * 7.0 + 16.0 * 9.0 + 48.0) + 8.0 * 16.0 * 18.0 + 22.0 * 18.0;
+static double p_row_perms(int n_elems) { return (double)((n_elems + 7) / 8); }
+static double p_node_perms(int n_inject) { return n_inject > 0 ? 2.0 + p_row_perms(n_inject) : 1.0; }
+static PoseidonTab tab_of(const uint32_t* pos_dev) { return PoseidonTab{pos_dev, pos_dev + 480}; }
+
+void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
+    ProfScope ps("k_poseidon_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * p_row_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
+    hipLaunchKernelGGL(k_poseidon_leaves<PPtrCols>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, PPtrCols{cols_dev}, n_elems, n_rows, tab_of(pos_dev), digests);
+}
+void launch_poseidon_leaves_strided(hipStream_t st, const uint32_t* pos_dev, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests) {
+    ProfScope ps("k_poseidon_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * p_row_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
+    hipLaunchKernelGGL(k_poseidon_leaves<PStridedCols>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, PStridedCols{base, stride}, n_elems, n_rows,
+                       tab_of(pos_dev), digests);
+}
+void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
+    ProfScope ps("k_poseidon_compress", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * p_node_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
+    hipLaunchKernelGGL(k_poseidon_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, tab_of(pos_dev), next);
+}
+void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, const KeccakTopArgs& a) {
+    double bytes = 0, perms = 0;
+    for (int l = 0; l < a.levels; l++) {
+        bytes += (double)(a.first_len >> l) * (96.0 + 4.0 * a.n_elems[l]);
+        perms += (double)(a.first_len >> l) * p_node_perms(a.n_elems[l]);
+    }
+    ProfScope ps("k_poseidon_top", st, bytes, perms * POSEIDON_VALU_PER_PERM / 64.0);
+    hipLaunchKernelGGL(k_poseidon_top, dim3(1), dim3(1024), 0, st, a, tab_of(pos_dev));
+}
+
+}  // namespace vk
