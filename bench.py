@@ -5,8 +5,9 @@ configs[1] = workload C2 of SURVEY.md §8), one proof per GPU per step.
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one complete proof per rank (from HBM-resident main traces to the assembled proof words on
-the host) + one RCCL all-gather of the three 32-byte commitment roots over xGMI when N > 1 (segments are
-independent).  Rank 0 prints ONE JSON line.  Scaling is weak (one segment per GPU).
+the host) + one RCCL all-gather of that proof's three 32-byte commitment roots over xGMI when N > 1, issued
+as soon as the rank's proof is complete (segments are independent).  Rank 0 prints ONE JSON
+line.  Scaling is weak (one segment per GPU).
 """
 import argparse
 import json
@@ -40,23 +41,66 @@ def algorithmic_bytes_per_proof(shapes, log_blowup=1):
     return float(total)
 
 
-VALU_PEAK_WAVE_INSTR_S = 5.4e11  # measured integer-VALU issue peak (tools/microbench.hip; DESIGN.md "Measured hardware facts")
+# Integer-VALU facts of the MI355X, measured by tools/microbench.py (profiles/rNN_microbench.txt; these defaults are the r02
+# numbers and are replaced by whatever the newest committed report says): G wave64-instr/s over the chip for the instruction
+# classes the prover is made of, and the in-register ceiling of the product's own Keccak-f[1600].
+MICROBENCH_DEFAULTS = {"full_rate": 1.03e12,   # v_add_u32 / v_sub_u32 / v_xor_b32 / v_bitop3_b32 / v_fma_f32: ~2.4 cycles per SIMD
+                       "half_rate": 0.586e12,  # v_alignbit_b32, v_mul_lo/hi_u32, v_mad_u64_u32, v_min_u32, shifts: ~4.2 cycles per SIMD
+                       "keccak_perm_per_s": 9.9e9, "clock_hz": 2.35e9, "source": "defaults (r02 measurement)"}
+KECCAK_VALU_PER_PERM = 23 * 178 + 58  # kernels/merkle.hip: instructions of one digest-only permutation
+KECCAK_FULL_RATE_PER_ROUND, KECCAK_HALF_RATE_PER_ROUND = 122, 56  # bitop3/xor vs alignbit per round
+
+
+def microbench_facts():
+    """Peaks from the newest profiles/r*_microbench.txt (tools/microbench.py output), else the r02 defaults."""
+    import glob
+    import re
+
+    facts = dict(MICROBENCH_DEFAULTS)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_microbench.txt")))
+    if not files:
+        return facts
+    try:
+        txt = open(files[-1]).read()
+        rate = {m.group(1): float(m.group(2)) * 1e9 for m in re.finditer(r"^(v_\w+)\s.*peak\s+([0-9.]+) G wave-instr/s", txt, re.M)}
+        full = [rate[k] for k in ("v_add_u32", "v_xor_b32", "v_bitop3_b32") if k in rate]
+        half = [rate[k] for k in ("v_alignbit_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32") if k in rate]
+        if full and half:
+            facts["full_rate"], facts["half_rate"] = sum(full) / len(full), sum(half) / len(half)
+        k = re.search(r"^keccak_f1600 digest(.*)$", txt, re.M)
+        if k:
+            perms = [float(x) * 1e9 for x in re.findall(r"([0-9.]+) G perm/s", k.group(1))]
+            clocks = [float(x) * 1e9 for x in re.findall(r"([0-9.]+) GHz", k.group(1))]
+            facts["keccak_perm_per_s"], facts["clock_hz"] = max(perms), clocks[perms.index(max(perms))]
+        facts["source"] = os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        pass
+    return facts
+
+
+def pmc_file():
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, {}
+    try:
+        with open(files[-1]) as f:
+            return os.path.relpath(files[-1], ROOT), json.load(f)["kernels"]
+    except (KeyError, ValueError, OSError):
+        return None, {}
 
 
 def pmc_traffic_per_launch(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (profiles/rNN_pmc.json, written
-    by tools/summarize_prof.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc.json")))
-    if not files:
-        return None
+    by tools/summarize_prof.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None.
+    NOT measured in this run: the line says where it comes from (roofline.traffic_source)."""
+    src, kernels = pmc_file()
+    k = kernels.get(kernel)
     try:
-        with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(kernel)
-        return k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"] if k else None
-    except (KeyError, ValueError, OSError):
-        return None
+        return (k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"], src) if k else (None, src)
+    except KeyError:
+        return None, src
 
 
 def segment_loop_bound(log_rows, rank):
@@ -77,23 +121,30 @@ def exchange_roots(dist, torch, commitments, device):
     return out.reshape(world, local.numel())
 
 
-def cpu_baseline(log_rows, rc):
-    """Oracle (CPU restatement, OpenMP) timed on a bounded sample of the same workload."""
+def cpu_baseline(log_rows, rc, headline_log_rows):
+    """The oracle (CPU restatement of the reference's algorithm, C++/OpenMP on every host core) timed on the SAME workload the GPU
+    is timed on — the headline 2^20-row segment itself by default, one proof, no extrapolation.  It is a port ("kind": "port"):
+    scalar `% p` field arithmetic, none of Plonky3's packed AVX field code, so the GPU/CPU ratio overstates the advantage over
+    the real reference prover."""
     from oracle import pyoracle as po
     import valida_amd as va
 
     w = va.Workload.fib(FIB_N[log_rows])
     prep = w.preprocessed()
     res = po.prove_basic(w.main_traces(), prep[0][1], prep[1][1], rc)
-    # scale proofs/sec linearly in trace rows to the 2^20-row workload (n log n work: optimistic for the CPU)
-    scale = float(1 << (20 - log_rows))
-    return {
-        "value": 1.0 / (res.seconds * scale),
+    out = {
+        "value": 1.0 / res.seconds,
         "unit": "proofs/s",
-        "cores": os.cpu_count(),
+        "seconds_per_proof": res.seconds,
+        "cores": po.usable_cores(),
         "kind": "port",
-        "sample": "oracle (C++/OpenMP restatement, not Plonky3) proving fib with 2^%d cpu rows in %.2f s, scaled x%d to 2^20 rows" % (log_rows, res.seconds, int(scale)),
+        "sample": "oracle (C++/OpenMP restatement, not Plonky3) proving ONE fib segment with 2^%d cpu rows (mem 2^%d) in %.1f s on %d host cores"
+                  % (log_rows, log_rows + 2, res.seconds, po.usable_cores()),
     }
+    if log_rows != headline_log_rows:  # a smaller sample was asked for: say so, and give the linear-in-rows estimate separately
+        out["note"] = "sample is 2^%d rows, not the 2^%d-row workload of `value`; linear scaling would give %.4f proofs/s" % (
+            log_rows, headline_log_rows, 1.0 / (res.seconds * (1 << (headline_log_rows - log_rows))))
+    return out
 
 
 def main():
@@ -102,7 +153,7 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 of the padded CPU-chip height (20 = the headline workload)")
-    ap.add_argument("--cpu-log-rows", type=int, default=17, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-log-rows", type=int, default=None, help="size of the CPU-baseline proof (default: the workload's own size, capped at 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="proofs in flight per GPU: M prover contexts (own HIP streams and pool), one asynchronous proof outstanding on each "
@@ -176,6 +227,25 @@ def main():
     upload_bytes = sum(m.nbytes for m in mt)
 
     all_roots = [None]
+    # The path's one collective is issued by the LIBRARY (vgpu_comm_*: RCCL loaded and driven by libvgpu.so, so a non-Python host
+    # owns it); the 128-byte communicator id travels through the launcher's own channel (here torch.distributed's).  Any failure
+    # falls back to torch.distributed's all_gather and says so in the JSON line.
+    lib_comm, comm_note = None, "torch.distributed all_gather_into_tensor"
+    if world > 1 and backend == "nccl" and os.environ.get("VGPU_BENCH_COMM", "library") == "library":
+        try:
+            ids = [va.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            lib_comm = va.Comm(prover, ids[0], rank, world)
+            comm_note = "vgpu_comm_allgather_roots (RCCL driven by libvgpu.so)"
+        except Exception as e:  # noqa: BLE001 - the scaling run must not die on the optional route
+            lib_comm, comm_note = None, "torch.distributed all_gather_into_tensor (library communicator failed: %s)" % e
+        flags = [lib_comm is not None]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, flags[0])
+        if not all(gathered):  # all ranks take the same route
+            lib_comm = None
+            if "failed" not in comm_note:
+                comm_note = "torch.distributed all_gather_into_tensor (library communicator failed on another rank)"
 
     oplog = wl.oplog()
     small = [i for i in range(va.NUM_CHIPS) if i not in va.GENERATED_CHIPS]
@@ -199,17 +269,22 @@ def main():
 
         # one caller thread, one outstanding ticket per prover context (vgpu_prove_async): step i runs on context i % M
         tickets = [None] * len(provers)
+
+        def finish(j, t):
+            done[j] = t.wait()
+            if world > 1:  # the path's one collective, once per proof: every rank's three roots to every rank (96 B per rank)
+                if lib_comm is not None:
+                    all_roots[0] = lib_comm.allgather_roots(done[j].words[2:26])
+                else:
+                    all_roots[0] = exchange_roots(dist, torch, done[j].words[2:26], coll_device)
+
         for i in range(k):
             slot = i % len(provers)
             if tickets[slot] is not None:
-                j, t = tickets[slot]
-                done[j] = t.wait()
+                finish(*tickets[slot])
             tickets[slot] = (i, start(slot))
-        for tk in tickets:
-            if tk is not None:
-                done[tk[0]] = tk[1].wait()
-        if world > 1 and k:
-            all_roots[0] = exchange_roots(dist, torch, np.concatenate([p.words[2:26] for p in done]), coll_device)
+        for tk in sorted((t for t in tickets if t is not None), key=lambda t: t[0]):
+            finish(*tk)
         return done
 
     def fence():
@@ -278,7 +353,30 @@ def main():
         name, (launches, ms, nbytes, valu_ops) = max(prof.items(), key=lambda kv: kv[1][1])
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         valu_rate = valu_ops / (ms * 1e-3) if ms > 0 else 0.0
-        traffic = pmc_traffic_per_launch(name)
+        traffic, traffic_src = pmc_traffic_per_launch(name)
+        mb = microbench_facts()
+        simds = 1024
+        # Keccak kernels: permutations per second against (a) the product's own permutation running in registers with nothing else
+        # (tools/microbench: the ceiling this code can reach) and (b) the sum of its instructions at their isolated issue rates
+        def keccak_roofline(stat):
+            launches_, ms_, _, valu_ = stat
+            if not valu_ or not ms_:
+                return None
+            perms = valu_ * 64.0 / KECCAK_VALU_PER_PERM
+            rate = perms / (ms_ * 1e-3)
+            cycles_per_perm = 24 * (KECCAK_FULL_RATE_PER_ROUND * simds * mb["clock_hz"] / mb["full_rate"] + KECCAK_HALF_RATE_PER_ROUND * simds * mb["clock_hz"] / mb["half_rate"])
+            model = simds * mb["clock_hz"] * 64.0 / cycles_per_perm
+            return {"achieved": rate, "unit": "Keccak-f[1600] permutations/s", "peak": mb["keccak_perm_per_s"], "frac": rate / mb["keccak_perm_per_s"],
+                    "peak_is": "the same permutation code chained in registers, 5 waves per SIMD, no memory traffic (tools/microbench.hip)",
+                    "issue_model_peak": model, "frac_of_issue_model": rate / model,
+                    "issue_model": "24 rounds x (122 full-rate + 56 half-rate VALU instructions) at their isolated issue rates"}
+        # whole proof: VALU wave-instructions per proof from the committed PMC pass x this run's step time
+        _, pmc_kernels = pmc_file()
+        proof_instr = None
+        try:
+            proof_instr = sum(pmc_kernels[k]["valu_wave_instr_per_launch"] * v[0] / args.steps for k, v in prof.items() if k in pmc_kernels and "valu_wave_instr_per_launch" in pmc_kernels[k])
+        except (KeyError, TypeError):
+            proof_instr = None
         b_alg = algorithmic_bytes_per_proof(shapes, prover.log_blowup)
         kernel_ms_total = sum(v[1] for v in prof.values()) / args.steps
         out = {
@@ -295,33 +393,38 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",  # BabyBear mod p in Montgomery form; Keccak lanes as pairs of u32
-            "data": "synthetic: %s traces generated by the in-tree VM, deterministic; Poseidon constants SplitMix64(0x56414C494441)" % data,
+            "data": "synthetic: %s traces generated by the in-tree VM, deterministic; Poseidon constants SplitMix64(0x56414C494441); every step proves the SAME "
+                    "device-resident trace from scratch (nothing is cached between proofs); ranks differ by their loop bound" % data,
             "config": {
                 "workload": wl_name + ", 14 chips, one proof per GPU",
                 "field": "BabyBear / Ext5", "mmcs": "Keccak-256", "fri_blowup": 1 << prover.log_blowup,
                 "log_blowup": prover.log_blowup, "num_queries": prover.num_queries, "pow_bits": prover.pow_bits,
-                "parallelism": "segments: one independent proof per GPU + all-gather of 3 roots" if world > 1 else "single GPU",
+                "parallelism": ("segments: one independent proof per GPU + all-gather of 3 roots per proof via " + comm_note) if world > 1 else "single GPU",
                 "proofs_in_flight_per_gpu": len(provers),
             },
             "roofline": {
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "launches_per_step": launches / args.steps, "avg_launch_ms": ms / launches if launches else None,
+                "traffic": traffic, "traffic_source": "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)" % traffic_src,
+                "limited_by": "integer VALU issue, not HBM: see valu_roofline" if valu_ops > 0 else "hbm",
+                "launches_per_step": launches / args.steps, "avg_launch_ms": ms / launches if launches else None,
                 "algorithmic_bytes_per_launch": nbytes / launches if launches else None,
             },
-            # The dominant kernel is Keccak-f[1600] over Merkle nodes: 32-bit integer VALU work, ~4200 ops per 96 B moved,
-            # so its binding roofline is the VALU issue rate, not HBM (SURVEY.md §8(d) caveat; DESIGN.md "Rooflines").
-            "valu_roofline": {
-                "kernel": name, "achieved": valu_rate, "peak": VALU_PEAK_WAVE_INSTR_S, "unit": "wave64 VALU instr/s",
-                "frac": valu_rate / VALU_PEAK_WAVE_INSTR_S, "algorithmic_valu_instr_per_launch": valu_ops / launches if launches else None,
-                "peak_source": "tools/microbench.hip on MI355X: 1 integer VALU instr / 4 cycles / SIMD, 1024 SIMDs, ~2.1 GHz sustained",
-            } if valu_ops > 0 else None,
-            # The same kernel when its proof has the GPU to itself (the 4-proof latency leg): with two proofs in flight
-            # kernels of both proofs share the CUs, so the per-launch durations above are not exclusive-use figures.
+            # The dominant kernel is Keccak-f[1600] over Merkle nodes: 32-bit integer VALU work, ~4200 instructions per 96 B moved, so
+            # its binding roofline is the VALU issue rate, not HBM (SURVEY.md §8(d) caveat; DESIGN.md "Rooflines").
+            "valu_roofline": None if valu_ops <= 0 else dict(keccak_roofline(prof[name]), kernel=name, microbench=mb["source"],
+                                                            wave64_valu_instr_per_s=valu_rate, full_rate_peak=mb["full_rate"], half_rate_peak=mb["half_rate"]),
+            # The same kernel when its proof has the GPU to itself (the 4-proof latency leg): with several proofs in flight kernels
+            # of all of them share the CUs, so the per-launch durations above are not exclusive-use figures.
             "roofline_one_proof_in_flight": None if not prof1 else {
                 "kernel": name, "avg_launch_ms": prof1[name][1] / prof1[name][0],
                 "hbm_achieved_GBs": prof1[name][2] / (prof1[name][1] * 1e-3) / 1e9, "hbm_frac": prof1[name][2] / (prof1[name][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "valu_achieved": prof1[name][3] / (prof1[name][1] * 1e-3), "valu_frac": prof1[name][3] / (prof1[name][1] * 1e-3) / VALU_PEAK_WAVE_INSTR_S,
+                "valu": keccak_roofline(prof1[name]),
             },
+            "proof_valu_roofline": None if not proof_instr else {
+                "wave64_valu_instr_per_proof": proof_instr, "achieved_instr_per_s": proof_instr / (ms_per_step * 1e-3),
+                "frac_of_full_rate_peak": proof_instr / (ms_per_step * 1e-3) / mb["full_rate"], "frac_of_half_rate_peak": proof_instr / (ms_per_step * 1e-3) / mb["half_rate"],
+                "note": "instruction counts from the committed PMC pass (SQ_INSTS_VALU per launch) x this run's launches per step; the proof's mix of full- and "
+                        "half-rate instructions puts its issue peak between the two"},
             "proof_roofline": {"algorithmic_bytes_per_proof": b_alg, "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "phase_ms": {k: v / args.steps for k, v in phase.items()},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
@@ -340,7 +443,8 @@ def main():
             "hbm_pool_peak_bytes": sum(p_.memory()[1] for p_ in provers),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_log_rows, rc)
+            headline = min(args.log_rows, 20)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_log_rows if args.cpu_log_rows else headline, rc, args.log_rows)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

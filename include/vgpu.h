@@ -229,6 +229,28 @@ int64_t vgpu_proof_debug_perm_trace(const vgpu_proof_t* pr, uint32_t chip, uint3
 int64_t vgpu_proof_debug_quotient(const vgpu_proof_t* pr, uint32_t chip, uint32_t* out, uint64_t cap_words);
 void vgpu_proof_free(vgpu_proof_t* pr);
 
+/* ---- RCCL inside the library: one process per GPU; the host's launcher distributes the 128-byte id that rank 0
+ * obtains from vgpu_comm_unique_id (any out-of-band channel: MPI, a file, the Rust host's own RPC), every rank then calls
+ * vgpu_comm_init with its prover.  vgpu_comm_allgather_roots is the path's one collective: each segment's commitment roots
+ * (3 x 8 words after vgpu_prove) to every rank over xGMI; out holds world * n_words words, rank-major. ---- */
+typedef struct vgpu_comm vgpu_comm_t;
+#define VGPU_COMM_ID_BYTES 128
+int32_t vgpu_comm_unique_id(uint8_t id[VGPU_COMM_ID_BYTES]);
+int32_t vgpu_comm_init(vgpu_prover_t* p, const uint8_t id[VGPU_COMM_ID_BYTES], uint32_t rank, uint32_t world, vgpu_comm_t** out);
+int32_t vgpu_comm_allgather_roots(vgpu_comm_t* c, const uint32_t* words, uint32_t n_words, uint32_t* out);
+void vgpu_comm_destroy(vgpu_comm_t* c);
+
+/* ---- ONE proof sharded over several GPUs, first step: pcs.commit_batches of one round sharded over the
+ * ranks of `comm` — column-sharded LDEs, an all-to-all into row-range shards, a subtree per rank, an all-gather of the subtree
+ * roots.  Every rank passes the SAME matrices (only its own columns are extended) and receives the SAME root that
+ * vgpu_commit_batches gives on one GPU.  world must be a power of two. */
+int32_t vgpu_commit_batches_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace_t* const* mats, uint32_t n_mats, const uint32_t* coset_shifts,
+                                    uint32_t root[8]);
+/* The same phases with `world` prover contexts of THIS process standing in for the ranks (a box with one GPU): the exchanges
+ * are device-to-device copies.  mats[r * n_mats + i] = matrix i as uploaded through provers[r]. */
+int32_t vgpu_commit_batches_sharded_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* mats, uint32_t n_mats,
+                                          const uint32_t* coset_shifts, uint32_t root[8]);
+
 /* ---- trace generation on the device: Chip::generate_trace (machine/src/chip.rs:22) of the big
  * BasicMachine chips as kernels, fed by the VM's operation logs instead of host-built RowMajorMatrix traces.
  * The logs are what the reference's chips hold after Machine::run: Cpu::operations + pc/fp/instruction per cycle

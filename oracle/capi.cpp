@@ -64,6 +64,13 @@ void oracle_hash_elems(const uint32_t* e, uint64_t n, uint32_t* out8) {
     Digest d = hash_elems(v);
     for (int i = 0; i < 8; i++) out8[i] = d[i].v;
 }
+// C(a, b) of the MMCS (CompressionFunctionFromHasher / TruncatedPermutation, by the current hash selection)
+void oracle_compress(const uint32_t* a8, const uint32_t* b8, uint32_t* out8) {
+    Digest a, b;
+    for (int i = 0; i < 8; i++) { a[i] = Fp(a8[i]); b[i] = Fp(b8[i]); }
+    Digest d = compress(a, b);
+    for (int i = 0; i < 8; i++) out8[i] = d[i].v;
+}
 void oracle_poseidon_permute(const uint32_t* rc480, uint32_t* state16) {
     Poseidon16 p(rc480);
     Fp st[16];

@@ -10,31 +10,39 @@
 #pragma once
 #include <algorithm>
 #include <map>
+#include <omp.h>
 #include "hash.hpp"
 
 namespace oracle {
 
 // ---------------------------------------------------------------- DFT (App. B3)
 // In-place iterative radix-2 on one column (natural in, natural out).
-inline void dft_inplace(std::vector<Fp>& a, bool inverse) {
+inline void dft_inplace(std::vector<Fp>& a, bool inverse, bool parallel = false) {
     size_t n = a.size();
     unsigned k = log2_strict(n);
+    parallel = parallel && n >= (size_t(1) << 14);  // threads INSIDE one transform: for matrices with fewer columns than cores
+    #pragma omp parallel for if (parallel) schedule(static)
     for (size_t i = 0; i < n; i++) { size_t j = reverse_bits_len(i, k); if (i < j) std::swap(a[i], a[j]); }
     for (unsigned s = 1; s <= k; s++) {
-        size_t m = size_t(1) << s;
+        size_t m = size_t(1) << s, half = m / 2;
         Fp wm = two_adic_generator(s);
         if (inverse) wm = wm.inv();
-        std::vector<Fp> tw(m / 2);
+        std::vector<Fp> tw(half);
         tw[0] = Fp::one();
-        for (size_t j = 1; j < m / 2; j++) tw[j] = tw[j - 1] * wm;
-        for (size_t base = 0; base < n; base += m)
-            for (size_t j = 0; j < m / 2; j++) {
-                Fp t = tw[j] * a[base + j + m / 2], u = a[base + j];
-                a[base + j] = u + t;
-                a[base + j + m / 2] = u - t;
-            }
+        for (size_t j = 1; j < half; j++) tw[j] = tw[j - 1] * wm;
+        #pragma omp parallel for if (parallel) schedule(static)
+        for (size_t t = 0; t < n / 2; t++) {  // butterfly t: block t / half, position t % half
+            size_t j = t & (half - 1), lo = ((t >> (s - 1)) << s) + j, hi = lo + half;
+            Fp x = tw[j] * a[hi], u = a[lo];
+            a[lo] = u + x;
+            a[hi] = u - x;
+        }
     }
-    if (inverse) { Fp ninv = Fp((uint32_t)(n % P)).inv(); for (auto& x : a) x *= ninv; }
+    if (inverse) {
+        Fp ninv = Fp((uint32_t)(n % P)).inv();
+        #pragma omp parallel for if (parallel) schedule(static)
+        for (size_t i = 0; i < n; i++) a[i] *= ninv;
+    }
 }
 
 // O(n^2) definition, used only by tests to pin dft_inplace.
@@ -55,16 +63,22 @@ inline std::vector<Fp> naive_dft(const std::vector<Fp>& a) {
 inline Matrix coset_lde_batch(const Matrix& m, unsigned added_bits, Fp shift) {
     size_t n = m.height, N = n << added_bits;
     Matrix out(N, m.width);
-    #pragma omp parallel for schedule(dynamic)
-    for (size_t c = 0; c < m.width; c++) {
+    auto one_column = [&](size_t c, bool inner_parallel) {
         std::vector<Fp> col(n);
         for (size_t r = 0; r < n; r++) col[r] = m.at(r, c);
-        dft_inplace(col, true);
+        dft_inplace(col, true, inner_parallel);
         col.resize(N);
         Fp pw = Fp::one();
         for (size_t i = 0; i < n; i++) { col[i] *= pw; pw *= shift; }
-        dft_inplace(col, false);
+        dft_inplace(col, false, inner_parallel);
         for (size_t r = 0; r < N; r++) out.at(r, c) = col[r];
+    };
+    // wide matrices: a thread per column; tall narrow ones (the memory chip: 14 columns of 2^22 rows): threads inside each transform
+    if (m.width * 4 >= (size_t)omp_get_max_threads() || n < (size_t(1) << 14)) {
+        #pragma omp parallel for schedule(dynamic)
+        for (size_t c = 0; c < m.width; c++) one_column(c, false);
+    } else {
+        for (size_t c = 0; c < m.width; c++) one_column(c, true);
     }
     return out;
 }
@@ -72,6 +86,7 @@ inline Matrix coset_lde_batch(const Matrix& m, unsigned added_bits, Fp shift) {
 inline Matrix bit_reverse_rows(const Matrix& m) {
     Matrix out(m.height, m.width);
     unsigned k = log2_strict(m.height);
+    #pragma omp parallel for schedule(static)
     for (size_t r = 0; r < m.height; r++) {
         size_t j = reverse_bits_len(r, k);
         std::copy(m.row(r), m.row(r) + m.width, &out.v[j * m.width]);
@@ -222,18 +237,35 @@ inline std::vector<Ext5> interpolate_coset(const Matrix& lde_bitrev, size_t n, F
     unsigned k = log2_strict(n);
     Fp g = two_adic_generator(k);
     std::vector<Ext5> w(n);  // w_i = g^i / (z - shift g^i), natural i
-    Fp gi = Fp::one();
-    for (size_t i = 0; i < n; i++) { w[i] = (z - shift * gi).inv() * gi; gi *= g; }
+    #pragma omp parallel
+    {
+        // each thread walks a contiguous range of i with its own running power of g (the inversions dominate)
+        #pragma omp for schedule(static)
+        for (size_t blk = 0; blk < (n + 4095) / 4096; blk++) {
+            size_t i0 = blk * 4096, i1 = std::min(n, i0 + 4096);
+            Fp gi = g.pow(i0);
+            for (size_t i = i0; i < i1; i++) { w[i] = (z - shift * gi).inv() * gi; gi *= g; }
+        }
+    }
     Ext5 zerofier = z.exp_power_of_2(k) - shift.exp_power_of_2(k);
     Fp denom = Fp((uint32_t)(n % P)) * shift.pow(n - 1);
     Ext5 scale = zerofier * denom.inv();
-    std::vector<Ext5> ys(lde_bitrev.width);
-    #pragma omp parallel for
-    for (size_t c = 0; c < lde_bitrev.width; c++) {
-        Ext5 acc;
-        for (size_t i = 0; i < n; i++) acc += w[i] * lde_bitrev.at(reverse_bits_len(i, k), c);  // first n bit-reversed rows = shift*H_n
-        ys[c] = acc * scale;
+    // first n bit-reversed rows = shift*H_n.  Rows are split over the threads (a 14-column matrix must not leave 242 of 256
+    // cores idle); exact field arithmetic makes the order of the partial sums irrelevant.
+    const size_t W = lde_bitrev.width;
+    std::vector<Ext5> ys(W);
+    #pragma omp parallel
+    {
+        std::vector<Ext5> part(W);
+        #pragma omp for schedule(static) nowait
+        for (size_t i = 0; i < n; i++) {
+            const Fp* row = lde_bitrev.row(reverse_bits_len(i, k));
+            for (size_t c = 0; c < W; c++) part[c] += w[i] * row[c];
+        }
+        #pragma omp critical
+        for (size_t c = 0; c < W; c++) ys[c] += part[c];
     }
+    for (size_t c = 0; c < W; c++) ys[c] = ys[c] * scale;
     return ys;
 }
 

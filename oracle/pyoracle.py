@@ -14,11 +14,35 @@ c_u32p = ctypes.POINTER(ctypes.c_uint32)
 _lib = None
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a container that shows 256 CPUs
+    but is throttled to a few would otherwise run 256 spinning OpenMP threads on them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, quota // int(g.read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_PATH):
             raise ImportError("oracle/liboracle.so is not built: run `make -C oracle`")
+        # before libgomp initialises: no more threads than usable cores, and sleeping (not spinning) waits
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = ctypes.CDLL(_PATH)
         L.oracle_two_adic_generator.restype = ctypes.c_uint32
         L.oracle_fp_mul.restype = ctypes.c_uint32
@@ -58,6 +82,14 @@ def hash_elems(e):
     a, ap = _u32(e)
     out = np.zeros(8, dtype=np.uint32)
     lib().oracle_hash_elems(ap, ctypes.c_uint64(a.size), out.ctypes.data_as(c_u32p))
+    return out
+
+
+def compress(a, b):
+    x, xp = _u32(a)
+    y, yp = _u32(b)
+    out = np.zeros(8, dtype=np.uint32)
+    lib().oracle_compress(xp, yp, out.ctypes.data_as(c_u32p))
     return out
 
 

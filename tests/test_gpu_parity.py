@@ -748,3 +748,40 @@ def test_poseidon_mmcs_proof_bytes(machine, rc, poseidon_oracle, make):
     assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc) is None
     po.set_mmcs_hash(0)  # the Keccak verifier must not accept a Poseidon-committed proof
     assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc) is not None
+
+
+# ---- §8(f)-4: one commitment round of one proof sharded over W ranks, and RCCL inside the library --------------------------
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("hash_kind", [va.HASH_KECCAK256, va.HASH_POSEIDON16])
+def test_sharded_commit_gives_the_single_gpu_root(machine, rc, world, hash_kind):
+    """Column-sharded LDE -> all-to-all into row ranges -> per-rank subtrees -> gathered roots -> top: `world` prover contexts on this
+    one GPU stand in for the ranks (the exchanges are device-to-device copies; over RCCL the same phases run in
+    vgpu_commit_batches_sharded).  Mixed heights, matrices shorter than the rank count, column counts that do not divide."""
+    provers = [va.Prover(machine, rc, hash_kind=hash_kind) for _ in range(world)]
+    rng = np.random.default_rng(world)
+    mats = [rand_matrix(rng, 1 << 10, 7), rand_matrix(rng, 1 << 12, 3), rand_matrix(rng, 1 << 10, 1), rand_matrix(rng, 64, 19), rand_matrix(rng, 2, 5),
+            rand_matrix(rng, 1, 4), rand_matrix(rng, 1, 2)]
+    want = provers[0].commit_batches([provers[0].upload(m) for m in mats]).root
+    assert first_mismatch(va.commit_batches_sharded_local(provers, mats), want) is None
+    shifts = [int(x) for x in rng.integers(1, P, len(mats))]
+    want = provers[0].commit_batches([provers[0].upload(m) for m in mats], coset_shifts=shifts).root
+    assert first_mismatch(va.commit_batches_sharded_local(provers, mats, coset_shifts=shifts), want) is None
+
+
+def test_sharded_commit_of_the_basic_machine_main_round(machine, rc):
+    w = va.Workload.fib(582)
+    mt = w.main_traces()
+    provers = [va.Prover(machine, rc) for _ in range(4)]
+    want = provers[0].commit_batches([provers[0].upload(m) for m in mt]).root
+    assert first_mismatch(va.commit_batches_sharded_local(provers, mt), want) is None
+
+
+def test_rccl_communicator_of_the_library_world_of_one(prover, fib25):
+    """RCCL is loaded and driven by the library itself (vgpu_comm_*): a world of one rank on this box's single GPU exercises the
+    load, the communicator and both collectives' call paths (two ranks cannot share one device under RCCL)."""
+    comm = va.Comm(prover, va.Comm.unique_id(), 0, 1)
+    roots = np.arange(24, dtype=np.uint32)
+    assert np.array_equal(comm.allgather_roots(roots), roots.reshape(1, 24))
+    mt = fib25.main_traces()
+    dm = [prover.upload(m) for m in mt]
+    assert first_mismatch(comm.commit_batches_sharded(dm), prover.commit_batches(dm).root) is None

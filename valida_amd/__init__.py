@@ -436,6 +436,60 @@ def proof_cbor(words, flags=0):
     return bytes(buf)
 
 
+class Comm:
+    """RCCL communicator owned by the library (one process per GPU): the path's one collective without Python in the loop."""
+
+    def __init__(self, prover, unique_id, rank, world):
+        self._prover, self.rank, self.world = prover, rank, world
+        self._h = ctypes.c_void_p()
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().vgpu_comm_init(prover._h, buf, ctypes.c_uint32(rank), ctypes.c_uint32(world), ctypes.byref(self._h)))
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_uint8 * 128)()
+        _check(lib().vgpu_comm_unique_id(buf))
+        return bytes(buf)
+
+    def commit_batches_sharded(self, traces, coset_shifts=None):
+        """This rank's share of a sharded pcs.commit_batches over RCCL; returns the (common) root."""
+        arr = (ctypes.c_void_p * len(traces))(*[t._h for t in traces])
+        root = np.zeros(8, dtype=np.uint32)
+        sh = None
+        if coset_shifts is not None:
+            shv, sh = _u32(coset_shifts)
+        _check(lib().vgpu_commit_batches_sharded(self._prover._h, self._h, arr, ctypes.c_uint32(len(traces)), sh, root.ctypes.data_as(c_u32p)))
+        return root
+
+    def allgather_roots(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1)
+        out = np.zeros(w.size * self.world, dtype=np.uint32)
+        _check(lib().vgpu_comm_allgather_roots(self._h, w.ctypes.data_as(c_u32p), ctypes.c_uint32(w.size), out.ctypes.data_as(c_u32p)))
+        return out.reshape(self.world, w.size)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().vgpu_comm_destroy(self._h)
+            except TypeError:  # interpreter shutdown
+                pass
+            self._h = None
+
+
+def commit_batches_sharded_local(provers, matrices, coset_shifts=None):
+    """One commitment round sharded over len(provers) prover contexts of this process (vgpu_commit_batches_sharded_local):
+    returns the root, which equals provers[0].commit_batches(..).root."""
+    keep = [[p.upload(m) for m in matrices] for p in provers]
+    arr = (ctypes.c_void_p * (len(provers) * len(matrices)))(*[t._h for row in keep for t in row])
+    parr = (ctypes.c_void_p * len(provers))(*[p._h for p in provers])
+    root = np.zeros(8, dtype=np.uint32)
+    sh = None
+    if coset_shifts is not None:
+        shv, sh = _u32(coset_shifts)
+    _check(lib().vgpu_commit_batches_sharded_local(parr, ctypes.c_uint32(len(provers)), arr, ctypes.c_uint32(len(matrices)), sh, root.ctypes.data_as(c_u32p)))
+    return root
+
+
 class Ticket:
     """An outstanding asynchronous proof (vgpu_prove_async); keeps its inputs alive until waited for."""
 

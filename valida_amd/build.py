@@ -64,7 +64,7 @@ def build_vgpu(force=False):
         return LIB
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(_compile, SOURCES))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]  # librccl.so is dlopen'ed on first use (host/comm.hpp)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)

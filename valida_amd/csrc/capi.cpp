@@ -6,6 +6,8 @@
 #include <memory>
 #include <string>
 #include "host/cbor.hpp"
+#include "host/comm.hpp"
+#include "host/sharded.hpp"
 #include "host/prover.hpp"
 #include "workload/basic_vm.hpp"
 
@@ -34,6 +36,7 @@ struct vgpu_ticket { std::future<std::pair<vgpu_proof_t*, std::pair<int32_t, std
 struct vgpu_proof { std::vector<uint32_t> words; PhaseTimes tm; ProveDebugOut dbg; };
 struct vgpu_oplog { std::shared_ptr<Prover> owner; std::unique_ptr<DeviceOplog> log; };
 struct vgpu_opening { std::vector<uint32_t> values, proof; };
+struct vgpu_comm { std::shared_ptr<Prover> owner; std::unique_ptr<Comm> comm; };  // owner first: the communicator dies before its context
 static_assert(sizeof(vgpu_cpu_op_t) == sizeof(vk::TgCpuOp) && sizeof(vgpu_mem_op_t) == sizeof(vk::TgMemOp) && sizeof(vgpu_alu_op_t) == sizeof(vk::TgAluOp),
               "C ABI log records and their device images must match");
 static_assert((int)VGPU_CPU_LOADFP == (int)vk::TG_CPU_LOADFP, "cpu op kinds");
@@ -645,6 +648,78 @@ static int64_t copy_dbg(const std::vector<std::vector<uint32_t>>& v, uint32_t ch
 int64_t vgpu_proof_debug_perm_trace(const vgpu_proof_t* pr, uint32_t chip, uint32_t* out, uint64_t cap) { return copy_dbg(pr->dbg.perm_traces, chip, out, cap); }
 int64_t vgpu_proof_debug_quotient(const vgpu_proof_t* pr, uint32_t chip, uint32_t* out, uint64_t cap) { return copy_dbg(pr->dbg.quotient_chunks, chip, out, cap); }
 void vgpu_proof_free(vgpu_proof_t* pr) { delete pr; }
+
+// ---- RCCL inside the library
+int32_t vgpu_comm_unique_id(uint8_t id[VGPU_COMM_ID_BYTES]) {
+    VG_TRY({
+        if (!id) throw std::invalid_argument("null argument");
+        static_assert(sizeof(ncclUniqueId) == VGPU_COMM_ID_BYTES, "RCCL unique id size");
+        ncclUniqueId u;
+        VG_NCCL_CHECK(RcclApi::get().GetUniqueId(&u));
+        memcpy(id, &u, sizeof u);
+    })
+}
+int32_t vgpu_comm_init(vgpu_prover_t* p, const uint8_t id[VGPU_COMM_ID_BYTES], uint32_t rank, uint32_t world, vgpu_comm_t** out) {
+    VG_TRY({
+        if (!p || !id || !out) throw std::invalid_argument("null argument");
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof u);
+        std::unique_ptr<vgpu_comm> c(new vgpu_comm());
+        c->owner = p->p;
+        c->comm.reset(new Comm(&p->p->ctx(), u, (int)rank, (int)world));
+        *out = c.release();
+    })
+}
+int32_t vgpu_comm_allgather_roots(vgpu_comm_t* c, const uint32_t* words, uint32_t n_words, uint32_t* out) {
+    VG_TRY({
+        if (!c || !words || !out || !n_words) throw std::invalid_argument("null argument");
+        c->comm->all_gather_words(words, n_words, out);
+    })
+}
+void vgpu_comm_destroy(vgpu_comm_t* c) { delete c; }
+
+// ---- sharded commit
+int32_t vgpu_commit_batches_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace_t* const* mats, uint32_t n_mats, const uint32_t* coset_shifts,
+                                    uint32_t root[8]) {
+    VG_TRY({
+        if (!p || !comm || !mats || !n_mats || !root) throw std::invalid_argument("null argument");
+        if (comm->owner != p->p) throw std::invalid_argument("communicator of another prover context");
+        DeviceCtx& c = p->p->ctx();
+        c.activate();
+        std::vector<DMat> nat;
+        for (uint32_t i = 0; i < n_mats; i++) { if (!mats[i] || mats[i]->owner != p->p) throw std::invalid_argument("null trace or trace of another prover"); nat.push_back(ingest(c, *mats[i]->t)); }
+        std::vector<const DMat*> np;
+        for (auto& m : nat) np.push_back(&m);
+        std::vector<Fp> shifts;
+        if (coset_shifts) for (uint32_t i = 0; i < n_mats; i++) shifts.push_back(Fp::from_canonical(coset_shifts[i]));
+        commit_sharded_rccl(*comm->comm, np, coset_shifts ? &shifts : nullptr, p->p->fri(), root);
+    })
+}
+int32_t vgpu_commit_batches_sharded_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* mats, uint32_t n_mats,
+                                          const uint32_t* coset_shifts, uint32_t root[8]) {
+    VG_TRY({
+        if (!provers || !world || !mats || !n_mats || !root) throw std::invalid_argument("null argument");
+        std::vector<DeviceCtx*> ctxs;
+        std::vector<std::vector<DMat>> nat(world);
+        std::vector<std::vector<const DMat*>> np(world);
+        for (uint32_t r = 0; r < world; r++) {
+            if (!provers[r]) throw std::invalid_argument("null prover");
+            DeviceCtx& c = provers[r]->p->ctx();
+            c.activate();
+            ctxs.push_back(&c);
+            for (uint32_t i = 0; i < n_mats; i++) {
+                const vgpu_trace_t* t = mats[(size_t)r * n_mats + i];
+                if (!t || t->owner != provers[r]->p) throw std::invalid_argument("mats[r * n_mats + i] must be uploaded through provers[r]");
+                nat[r].push_back(ingest(c, *t->t));
+            }
+            for (auto& m : nat[r]) np[r].push_back(&m);
+            c.sync();
+        }
+        std::vector<Fp> shifts;
+        if (coset_shifts) for (uint32_t i = 0; i < n_mats; i++) shifts.push_back(Fp::from_canonical(coset_shifts[i]));
+        commit_sharded_local(ctxs, np, coset_shifts ? &shifts : nullptr, provers[0]->p->fri(), root);
+    })
+}
 
 // ---- workloads
 int32_t vgpu_workload_fib(uint32_t n, vgpu_workload_t** out) {

@@ -1,0 +1,111 @@
+// RCCL inside the library: the path's one collective (an all-gather of each segment's Merkle roots over xGMI)
+// and the exchanges of the sharded commit (§8(f)-4) issued by the library itself, so that a non-Python host — the reference's
+// Rust — owns them.  librccl.so is loaded on first use (dlopen): single-GPU users never pay for it and libvgpu.so carries no
+// link-time dependency on it.  One communicator per prover context, one process per GPU (RCCL's own model); collectives are
+// enqueued on the context's stream.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include "runtime.hpp"
+
+namespace vhost {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    static RcclApi& get() {
+        static RcclApi api = load();
+        return api;
+    }
+    static RcclApi load() {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) throw std::runtime_error(std::string("hip: cannot load librccl.so: ") + dlerror());
+        auto sym = [&](const char* n) { void* p = dlsym(a.lib, n); if (!p) throw std::runtime_error(std::string("hip: librccl.so lacks ") + n); return p; };
+        a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+        a.Send = (decltype(a.Send))sym("ncclSend");
+        a.Recv = (decltype(a.Recv))sym("ncclRecv");
+        a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+        a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+        return a;
+    }
+};
+
+#define VG_NCCL_CHECK(expr)                                                                                                  \
+    do {                                                                                                                     \
+        ncclResult_t _r = (expr);                                                                                            \
+        if (_r != ncclSuccess) throw std::runtime_error(std::string("hip: rccl: " #expr ": ") + RcclApi::get().GetErrorString(_r)); \
+    } while (0)
+
+struct Comm {
+    DeviceCtx* ctx;
+    ncclComm_t comm = nullptr;
+    int rank, world;
+    // The roots all-gather has its own stream and buffers: it is issued by the host thread that collects finished proofs while
+    // other proofs of this context may be in flight on the context's streams (and pool) — it must neither wait for them nor
+    // touch the pool.
+    hipStream_t coll_stream = nullptr;
+    uint32_t* coll_buf = nullptr;       // device: [send: COLL_WORDS][recv: COLL_WORDS * world]
+    uint32_t* coll_host = nullptr;      // pinned staging of the same shape
+    static constexpr size_t COLL_WORDS = 256;
+    Comm(DeviceCtx* c, const ncclUniqueId& id, int rank_, int world_) : ctx(c), rank(rank_), world(world_) {
+        if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("comm: bad rank / world");
+        VG_HIP_CHECK(hipSetDevice(c->device));
+        VG_NCCL_CHECK(RcclApi::get().CommInitRank(&comm, world, id, rank));
+        VG_HIP_CHECK(hipStreamCreateWithFlags(&coll_stream, hipStreamNonBlocking));
+        VG_HIP_CHECK(hipMalloc((void**)&coll_buf, COLL_WORDS * (size_t)(world + 1) * 4));
+        VG_HIP_CHECK(hipHostMalloc((void**)&coll_host, COLL_WORDS * (size_t)(world + 1) * 4));
+    }
+    ~Comm() {
+        (void)hipSetDevice(ctx->device);
+        if (coll_stream) { (void)hipStreamSynchronize(coll_stream); (void)hipStreamDestroy(coll_stream); }
+        if (coll_buf) (void)hipFree(coll_buf);
+        if (coll_host) (void)hipHostFree(coll_host);
+        if (comm) (void)RcclApi::get().CommDestroy(comm);
+    }
+    Comm(const Comm&) = delete;
+    // every rank's `n_words` words to every rank: out[r * n_words + k] = rank r's word k.  Host buffers; staged through HBM.
+    void all_gather_words(const uint32_t* words, size_t n_words, uint32_t* out) {
+        if (n_words > COLL_WORDS) throw std::invalid_argument("comm: at most 256 words per rank in one roots all-gather");
+        VG_HIP_CHECK(hipSetDevice(ctx->device));
+        memcpy(coll_host, words, n_words * 4);
+        uint32_t* recv = coll_buf + COLL_WORDS;
+        VG_HIP_CHECK(hipMemcpyAsync(coll_buf, coll_host, n_words * 4, hipMemcpyHostToDevice, coll_stream));
+        VG_NCCL_CHECK(RcclApi::get().AllGather(coll_buf, recv, n_words, ncclUint32, comm, coll_stream));
+        VG_HIP_CHECK(hipMemcpyAsync(coll_host + COLL_WORDS, recv, n_words * (size_t)world * 4, hipMemcpyDeviceToHost, coll_stream));
+        VG_HIP_CHECK(hipStreamSynchronize(coll_stream));
+        memcpy(out, coll_host + COLL_WORDS, n_words * (size_t)world * 4);
+    }
+    // device-to-device exchange: block `send[s]` (count words) goes to rank s, `recv[s]` arrives from rank s (the all-to-all of
+    // the sharded commit: column shards -> row-range shards)
+    void all_to_all_words(const std::vector<const uint32_t*>& send, const std::vector<size_t>& send_words, const std::vector<uint32_t*>& recv,
+                          const std::vector<size_t>& recv_words) {
+        ctx->activate();
+        auto& api = RcclApi::get();
+        VG_NCCL_CHECK(api.GroupStart());
+        for (int s = 0; s < world; s++) {
+            if (s == rank) continue;
+            if (send_words[s]) VG_NCCL_CHECK(api.Send(send[s], send_words[s], ncclUint32, s, comm, ctx->stream));
+            if (recv_words[s]) VG_NCCL_CHECK(api.Recv(recv[s], recv_words[s], ncclUint32, s, comm, ctx->stream));
+        }
+        VG_NCCL_CHECK(api.GroupEnd());
+        if (send_words[rank]) VG_HIP_CHECK(hipMemcpyAsync(recv[rank], send[rank], send_words[rank] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+};
+
+}  // namespace vhost

@@ -19,6 +19,13 @@ struct FriParams {
     int hash_kind = 0;           // MMCS hash: 0 Keccak-256 (reference), 1 Poseidon-16 sponge / truncated permutation (north-star variant)
 };
 
+// A committed matrix given by one device pointer per column (height words each): what the sharded commit hashes — its columns
+// arrive from different ranks and are used where they landed.
+struct ColMat {
+    uint64_t height = 0;
+    std::vector<const uint32_t*> cols;
+};
+
 // One Merkle tree over column-major device matrices of mixed heights (FieldMerkleTreeMmcs, App. B5).
 struct DeviceTree {
     DeviceCtx* ctx = nullptr;
@@ -30,26 +37,36 @@ struct DeviceTree {
     // mats: views in commit order.  Enqueues all kernels; root is read back (sync) at the end.
     // fetch_root = false leaves the root on the device only (layers.back()): the FRI commit phase consumes it there.
     void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats, bool fetch_root = true) {
+        std::vector<ColMat> cms(mats.size());
+        for (size_t i = 0; i < mats.size(); i++) {
+            cms[i].height = mats[i].height;
+            for (uint64_t col = 0; col < mats[i].width; col++) cms[i].cols.push_back(mats[i].data + col * mats[i].stride);
+        }
+        build_impl(c, cms, mats.size() == 1 ? &mats[0] : nullptr, fetch_root);
+    }
+    void build_cols(DeviceCtx* c, const std::vector<ColMat>& mats) { build_impl(c, mats, nullptr, true); }
+
+  private:
+    // single_view: the tree is over ONE strided matrix (every FRI layer tree): no pointer table, columns are base + k * stride
+    void build_impl(DeviceCtx* c, const std::vector<ColMat>& cms, const vk::DMatView* single_view, bool fetch_root) {
         ctx = c;
-        std::vector<size_t> order(mats.size());
+        std::vector<size_t> order(cms.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return mats[a].height > mats[b].height; });
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cms[a].height > cms[b].height; });
         // column-pointer lists per height group, uploaded in one transfer
         struct Group { uint64_t height; size_t first, count; };
         std::vector<Group> groups;
         std::vector<uint64_t> ptrs;
         for (size_t pos = 0; pos < order.size();) {
-            uint64_t h = mats[order[pos]].height;
+            uint64_t h = cms[order[pos]].height;
             Group g{h, ptrs.size(), 0};
-            while (pos < order.size() && mats[order[pos]].height == h) {
-                const vk::DMatView& m = mats[order[pos++]];
-                for (uint64_t col = 0; col < m.width; col++) ptrs.push_back((uint64_t)(m.data + col * m.stride));
-            }
+            while (pos < order.size() && cms[order[pos]].height == h)
+                for (const uint32_t* col : cms[order[pos++]].cols) ptrs.push_back((uint64_t)col);
             g.count = ptrs.size() - g.first;
             groups.push_back(g);
         }
-        // a single matrix (every FRI layer tree) needs no pointer table: columns are base + k * stride
-        const bool single = mats.size() == 1;
+        const bool single = single_view != nullptr;
+
         DBuf ptr_buf;
         if (!single) {
             ptr_buf = DBuf(c, ptrs.size() * 2);
@@ -65,9 +82,9 @@ struct DeviceTree {
         const bool pos = c->hash_kind == 1;
         const uint32_t* tab = c->poseidon_tab;
         if (pos) {
-            if (single) vk::launch_poseidon_leaves_strided(c->stream, tab, mats[0].data, mats[0].stride, (int)mats[0].width, maxh, layers[0].data);
+            if (single) vk::launch_poseidon_leaves_strided(c->stream, tab, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
             else vk::launch_poseidon_leaves(c->stream, tab, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
-        } else if (single) vk::launch_keccak_leaves_strided(c->stream, mats[0].data, mats[0].stride, (int)mats[0].width, maxh, layers[0].data);
+        } else if (single) vk::launch_keccak_leaves_strided(c->stream, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
         else vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
         vk::KeccakTopArgs top{};
@@ -95,6 +112,7 @@ struct DeviceTree {
         if (fetch_root) c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished
         else if (!single) throw std::logic_error("mmcs: a deferred root needs a single-matrix tree (no pointer table to keep alive)");
     }
+
 };
 
 // ProverData of one commitment round: the committed (bit-reversed) LDEs + their tree.
