@@ -131,6 +131,28 @@ def test_air_capture_ffi_roundtrip():
     L.vgpu_air_free(air)
 
 
+def test_air_of_degree_above_three_is_refused_when_pushed():
+    """log_quotient_degree = 1 is what the device quotient implements: a foreign AIR of higher degree is refused at
+    vgpu_machine_push_air with a message that says so (not at prover creation, not silently)."""
+    L = va.lib()
+    u = ctypes.c_uint32
+    air = ctypes.c_void_p()
+    assert L.vgpu_air_new(b"pow5", u(2), u(0), ctypes.byref(air)) == 0
+    x = L.vgpu_air_variable(air, u(0), u(0), u(0))
+    y = L.vgpu_air_variable(air, u(0), u(1), u(0))
+    x2 = L.vgpu_air_mul(air, u(x), u(x))
+    x5 = L.vgpu_air_mul(air, u(L.vgpu_air_mul(air, u(x2), u(x2))), u(x))
+    L.vgpu_air_assert_zero(air, u(L.vgpu_air_sub(air, u(y), u(x5))))  # y - x^5: degree 5 -> log_quotient_degree 2
+    m = ctypes.c_void_p()
+    assert L.vgpu_machine_new(ctypes.byref(m)) == 0
+    assert L.vgpu_machine_push_air(m, air) == -4  # VGPU_ERR_UNSUPPORTED
+    msg = L.vgpu_last_error().decode()
+    assert "pow5" in msg and "log_quotient_degree 2" in msg and "degree 5" in msg
+    assert L.vgpu_machine_num_chips(m) == 0
+    L.vgpu_machine_free(m)
+    L.vgpu_air_free(air)
+
+
 def test_status_codes_and_error_messages():
     L = va.lib()
     assert L.vgpu_machine_chip_info(va.Machine.basic()._h, ctypes.c_uint32(99), (ctypes.c_uint32 * 8)()) == -1

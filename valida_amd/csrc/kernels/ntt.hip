@@ -199,6 +199,16 @@ __global__ void k_intt_contig(DMatView m, int k, int k_lo, DeviceTables tb, uint
     }
 }
 
+// Tile order of the strided passes.  A tile's rows are T consecutive words (64 bytes at T = 16) while HBM is fetched in 128-byte
+// lines (tools/microbench.hip k_copy_segments<16>: FETCH_SIZE shows 2x the bytes used), so tiles 2q and 2q+1 share every line
+// they read.  Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b mod 8, each with its own L2): in dispatch
+// order the two tiles would sit on different XCDs and both fetch the line.  This map gives blocks x and x + 8 — same XCD,
+// adjacent in that XCD's dispatch order — the tiles 2q and 2q + 1, so the second one finds the line in its L2.
+__device__ __forceinline__ unsigned strided_tile_of_block(unsigned x, unsigned n_tiles) {
+    if (n_tiles & 15u) return x;
+    return (x & ~15u) | ((x & 7u) << 1) | ((x >> 3) & 1u);
+}
+
 // ---- inverse, strided pass: grid = (N_lo / T, columns) -----------------------------------------------
 // Tile = all N_hi values of h for T consecutive r; DIT over h; scale by 1/N.
 __global__ void k_intt_strided(DMatView m, int k, int k_lo, int logT, DeviceTables tb, uint32_t n_inv_mont) {
@@ -206,7 +216,7 @@ __global__ void k_intt_strided(DMatView m, int k, int k_lo, int logT, DeviceTabl
     const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
     const uint64_t n_lo = 1ull << k_lo;
     uint32_t* tw = lds + n_hi * LD;
-    uint32_t* col = m.col(blockIdx.y) + (uint64_t)blockIdx.x * T;
+    uint32_t* col = m.col(blockIdx.y) + (uint64_t)strided_tile_of_block(blockIdx.x, gridDim.x) * T;
     const int total = n_hi << logT;
     {
         int e = threadIdx.x;
@@ -236,7 +246,7 @@ struct CosetPowers { uint32_t lo[64], hi[256], hp[128], step; };
 __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, int logT, DeviceTables tb, CosetPowers cp) {
     extern __shared__ uint32_t lds[];
     const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
-    const uint64_t n_lo = 1ull << k_lo, r0 = (uint64_t)blockIdx.x * T;
+    const uint64_t n_lo = 1ull << k_lo, r0 = (uint64_t)strided_tile_of_block(blockIdx.x, gridDim.x) * T;
     uint32_t* tw = lds + n_hi * LD;
     const uint32_t* in = src.col(blockIdx.y) + r0;
     uint32_t* out = dst.col(blockIdx.y) + dst_row0 + r0;

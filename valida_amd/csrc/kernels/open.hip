@@ -204,9 +204,25 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
         const uint64_t stride = ((uint64_t)md[3] << 32) | md[2];
         const uint32_t width = md[4], npts = md[5];
         md += 6;
-        // reduced row sum_c alpha^c * M[j][c], lazily: 4 columns per Montgomery reduction and limb
+        // reduced row sum_c alpha^c * M[j][c], lazily: 4 columns per Montgomery reduction and limb.  The kernel is a stream over
+        // every committed LDE (2 GB per proof) and lives on memory-level parallelism: SIXTEEN independent column loads are issued
+        // before the first is consumed (the alpha powers are wave-uniform scalar loads).
         Ext5 rr = Ext5::zero();
         uint32_t c = 0;
+        for (; c + 16 <= width; c += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = colp[(uint64_t)(c + u) * stride + j];
+#pragma unroll
+            for (int g = 0; g < 16; g += 4) {
+                const uint32_t* a0 = apow + 5 * (c + g);
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    uint64_t t = (uint64_t)a0[k] * v[g] + (uint64_t)a0[5 + k] * v[g + 1] + (uint64_t)a0[10 + k] * v[g + 2] + (uint64_t)a0[15 + k] * v[g + 3];
+                    rr.c[k] += Fp::raw(vg::monty_reduce_wide(t));
+                }
+            }
+        }
         for (; c + 4 <= width; c += 4) {
             const uint32_t v0 = colp[(uint64_t)c * stride + j], v1 = colp[(uint64_t)(c + 1) * stride + j];
             const uint32_t v2 = colp[(uint64_t)(c + 2) * stride + j], v3 = colp[(uint64_t)(c + 3) * stride + j];
