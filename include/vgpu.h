@@ -195,6 +195,16 @@ uint64_t vgpu_opening_proof_len(const vgpu_opening_t* o);
 const uint32_t* vgpu_opening_proof(const vgpu_opening_t* o);
 void vgpu_opening_free(vgpu_opening_t* o);
 
+/* pcs.verify_multi_batches (basic/src/lib.rs:825-837).  Host-only (no device is touched; only log_blowup, num_queries, pow_bits,
+ * hash_kind, observe_final_poly and poseidon_rc of `cfg` are read).  commits: n_rounds x 8 words; n_mats[r] matrices per round;
+ * heights / widths / n_points: one entry per (round, matrix), rounds concatenated, heights = TRACE heights (Dimensions);
+ * points / values: as vgpu_open_multi_batches takes / returns them; proof: vgpu_opening_proof words.  The transcript `ch`
+ * must be in the state the prover's was in when it called open_multi_batches.  Returns VGPU_OK if the opening is accepted,
+ * VGPU_ERR_INVALID_ARG with the reason in vgpu_last_error() if it is rejected. */
+int32_t vgpu_verify_multi_batches(const vgpu_config_t* cfg, const uint32_t* commits, uint32_t n_rounds, const uint32_t* n_mats, const uint64_t* heights,
+                                  const uint32_t* widths, const uint32_t* n_points, const uint32_t* points, const uint32_t* values, uint64_t n_value_words,
+                                  const uint32_t* proof, uint64_t n_proof_words, vgpu_challenger_t* ch);
+
 /* FRI fold_even_odd of an Ext5 vector (n x 5 words, bit-reversed domain order) — App. B10 */
 int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uint32_t beta[5], uint32_t* out);
 

@@ -710,9 +710,13 @@ def test_open_multi_batches_generic_shapes_match_oracle(machine, rc):
     got = np.concatenate([v.ravel() for rnd in opened for mat in rnd for v in mat])
     assert first_mismatch(got, values) is None
     assert first_mismatch(words, proof) is None
-    # the host transcript was advanced exactly as the oracle's: the next samples agree
-    ref = po.challenger_probe  # oracle transcript replay is not exposed after pcs_open; the equal proof words (PoW witness,
-    assert ref is not None     # query indices) already pin every value the transcript produced inside the call
+    # pcs.verify_multi_batches of the product (host side) accepts what the device produced, from the same transcript prefix
+    ch2 = va.Challenger(rc)
+    ch2.observe(obs)
+    heights, widths = [[m.shape[0] for m in rnd] for rnd in rounds], [[m.shape[1] for m in rnd] for rnd in rounds]
+    assert va.verify_multi_batches([pd.root for pd in pds], heights, widths, points, opened, words, ch2, rc, num_queries=9, pow_bits=3) is None
+    # and both transcripts were advanced identically by open / verify: their next samples agree
+    assert np.array_equal(ch.sample(7), ch2.sample(7))
 
 
 # ---- Poseidon-16 MMCS (vgpu_config.hash_kind = VGPU_HASH_POSEIDON16): BASELINE.json's north-star Merkle variant ---------------

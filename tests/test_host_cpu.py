@@ -261,3 +261,47 @@ def test_committed_bench_line_follows_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "proofs/s" and "sample" in c
     assert d["value"] / c["value"] > 20  # north star: >= 20x the CPU baseline
+
+
+@pytest.mark.parametrize("hash_kind", [va.HASH_KECCAK256, va.HASH_POSEIDON16])
+def test_host_verify_multi_batches_accepts_oracle_openings_and_rejects_tampering(rc, hash_kind):
+    """The product's host verifier (vgpu_verify_multi_batches: own Keccak, own MMCS / FRI checks) against openings produced by the
+    oracle's pcs.commit_batches + open_multi_batches — two independent implementations of prover and verifier meeting."""
+    rng = np.random.default_rng(21)
+    P = va.P
+    rounds = [[rng.integers(0, P, (32, 40), dtype=np.uint32), rng.integers(0, P, (32, 3), dtype=np.uint32)],
+              [rng.integers(0, P, (64, 2), dtype=np.uint32), rng.integers(0, P, (4, 9), dtype=np.uint32), rng.integers(0, P, (1, 4), dtype=np.uint32)]]
+    ext = lambda: [int(x) for x in rng.integers(1, P, 5)]
+    a, b, c = ext(), ext(), ext()
+    points = [[[a], [a, b]], [[c, a], [b], [a, b, c]]]
+    obs = [int(x) for x in rng.integers(0, P, 5)]
+    po.set_mmcs_hash(1 if hash_kind == va.HASH_POSEIDON16 else 0, rc)
+    try:
+        roots, values, proof = po.pcs_open(rounds, points, rc, observed=obs, num_queries=6, pow_bits=4)
+    finally:
+        po.set_mmcs_hash(0)
+    heights = [[m.shape[0] for m in rnd] for rnd in rounds]
+    widths = [[m.shape[1] for m in rnd] for rnd in rounds]
+
+    def verify(values, proof, roots=roots):
+        ch = va.Challenger(rc)
+        ch.observe(obs)
+        return va.verify_multi_batches(list(roots), heights, widths, points, values, proof, ch, rc, num_queries=6, pow_bits=4, hash_kind=hash_kind)
+
+    assert verify(values, proof) is None
+    other = va.HASH_POSEIDON16 if hash_kind == va.HASH_KECCAK256 else va.HASH_KECCAK256
+    ch = va.Challenger(rc)
+    ch.observe(obs)
+    assert va.verify_multi_batches(list(roots), heights, widths, points, values, proof, ch, rc, num_queries=6, pow_bits=4, hash_kind=other) is not None
+    for pos in list(range(0, values.size, 37)) + [values.size - 1]:   # every opened value is bound
+        bad = values.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        assert verify(bad, proof) is not None, pos
+    for pos in list(range(0, proof.size, 41)) + [proof.size - 1]:     # and the proof itself
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        assert verify(values, bad) is not None, pos
+    bad_roots = roots.copy()
+    bad_roots[1, 3] = (int(bad_roots[1, 3]) + 1) % P
+    assert verify(values, proof, bad_roots) is not None
+    assert verify(values, proof[:-1]) is not None and verify(values[:-5], proof) is not None

@@ -476,6 +476,31 @@ class Comm:
             self._h = None
 
 
+def verify_multi_batches(commits, heights, widths, points, values, proof_words, challenger, rc, log_blowup=1, num_queries=40, pow_bits=8,
+                         hash_kind=HASH_KECCAK256, observe_final_poly=False):
+    """pcs.verify_multi_batches on the host (vgpu_verify_multi_batches): commits[r] = 8 words; heights[r][i], widths[r][i] =
+    Dimensions of matrix i of round r; points[r][i] = list of Ext5; values = flat words as open_multi_batches returned them (or the
+    nested (width, 5) arrays).  Returns None if accepted, else the rejection message."""
+    cfg = VgpuConfig()
+    cfg.log_blowup, cfg.num_queries, cfg.pow_bits, cfg.hash_kind, cfg.observe_final_poly = log_blowup, num_queries, pow_bits, int(hash_kind), int(observe_final_poly)
+    r = np.ascontiguousarray(rc, dtype=np.uint32)
+    ctypes.memmove(cfg.poseidon_rc, r.ctypes.data, 480 * 4)
+    c, cp = _u32(np.concatenate([np.asarray(x, dtype=np.uint32) for x in commits]))
+    nm = np.array([len(h) for h in heights], dtype=np.uint32)
+    hs = np.array([h for rnd in heights for h in rnd], dtype=np.uint64)
+    ws = np.array([w for rnd in widths for w in rnd], dtype=np.uint32)
+    npts = np.array([len(p) for rnd in points for p in rnd], dtype=np.uint32)
+    pts = np.array([w for rnd in points for p in rnd for z in p for w in z], dtype=np.uint32)
+    if isinstance(values, (list, tuple)):
+        values = np.concatenate([v.ravel() for rnd in values for mat in rnd for v in mat])
+    v, vp = _u32(values)
+    pw, pwp = _u32(proof_words)
+    code = lib().vgpu_verify_multi_batches(ctypes.byref(cfg), cp, ctypes.c_uint32(len(commits)), nm.ctypes.data_as(c_u32p), hs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                           ws.ctypes.data_as(c_u32p), npts.ctypes.data_as(c_u32p), pts.ctypes.data_as(c_u32p), vp, ctypes.c_uint64(v.size), pwp,
+                                           ctypes.c_uint64(pw.size), challenger._h)
+    return None if code == 0 else lib().vgpu_last_error().decode()
+
+
 def commit_batches_sharded_local(provers, matrices, coset_shifts=None):
     """One commitment round sharded over len(provers) prover contexts of this process (vgpu_commit_batches_sharded_local):
     returns the root, which equals provers[0].commit_batches(..).root."""

@@ -8,6 +8,7 @@
 #include "host/cbor.hpp"
 #include "host/comm.hpp"
 #include "host/sharded.hpp"
+#include "host/verifier.hpp"
 #include "host/prover.hpp"
 #include "workload/basic_vm.hpp"
 
@@ -496,6 +497,39 @@ int32_t vgpu_open_multi_batches(vgpu_prover_t* p, const vgpu_pdata_t* const* rou
         for (auto& round : o.opened) for (auto& mat : round) for (auto& pt : mat) for (auto& e : pt) for (int q = 0; q < 5; q++) res->values.push_back(e.c[q].canonical());
         res->proof = std::move(o.proof_words);
         *out = res.release();
+    })
+}
+int32_t vgpu_verify_multi_batches(const vgpu_config_t* cfg, const uint32_t* commits, uint32_t n_rounds, const uint32_t* n_mats, const uint64_t* heights,
+                                  const uint32_t* widths, const uint32_t* n_points, const uint32_t* points, const uint32_t* values, uint64_t n_value_words,
+                                  const uint32_t* proof, uint64_t n_proof_words, vgpu_challenger_t* ch) {
+    VG_TRY({
+        if (!cfg || !commits || !n_rounds || !n_mats || !heights || !widths || !n_points || !points || !values || !proof || !ch) throw std::invalid_argument("null argument");
+        Poseidon16 perm(cfg->poseidon_rc);
+        HostMmcs mmcs{(int)cfg->hash_kind, &perm};
+        std::vector<VerifyRoundIn> rounds(n_rounds);
+        size_t k = 0, pw = 0, vw = 0;
+        for (uint32_t r = 0; r < n_rounds; r++) {
+            memcpy(rounds[r].commit.data(), commits + 8 * r, 32);
+            for (uint32_t i = 0; i < n_mats[r]; i++, k++) {
+                rounds[r].heights.push_back(heights[k]);
+                rounds[r].widths.push_back(widths[k]);
+                std::vector<Ext5> pts;
+                std::vector<std::vector<Ext5>> vals;
+                for (uint32_t q = 0; q < n_points[k]; q++, pw += 5) pts.push_back(ext_of(points + pw));
+                for (uint32_t q = 0; q < n_points[k]; q++) {
+                    std::vector<Ext5> ys;
+                    for (uint32_t c = 0; c < widths[k]; c++, vw += 5) {
+                        if (vw + 5 > n_value_words) throw std::invalid_argument("verify: too few opened values");
+                        ys.push_back(ext_of(values + vw));
+                    }
+                    vals.push_back(std::move(ys));
+                }
+                rounds[r].points.push_back(std::move(pts));
+                rounds[r].values.push_back(std::move(vals));
+            }
+        }
+        if (vw != n_value_words) throw std::invalid_argument("verify: too many opened values");
+        verify_multi_batches(rounds, proof, (size_t)n_proof_words, *ch->ch, cfg->log_blowup, cfg->num_queries, cfg->pow_bits, cfg->observe_final_poly != 0, mmcs);
     })
 }
 uint64_t vgpu_opening_values_len(const vgpu_opening_t* o) { return o->values.size(); }
