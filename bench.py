@@ -160,6 +160,9 @@ def main():
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the latency / PCIe-inclusive / operation-log legs (profiling runs: the process then consists of the warmup and the timed region only)")
+    ap.add_argument("--mmcs", choices=["keccak", "poseidon"], default="keccak",
+                    help="Merkle hash: keccak = the reference's configuration (headline); poseidon = BASELINE.json's north-star variant "
+                         "(PaddingFreeSponge / TruncatedPermutation over Poseidon-16), a separate leg with its own roofline")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="SURVEY.md §8 config: c2 = Fibonacci (headline), c3 = Fibonacci 2^22 rows with 4x blowup, c4 = ALU/range-heavy loop")
     args = ap.parse_args()
@@ -199,7 +202,8 @@ def main():
     machine = va.Machine.basic()
     if args.workload == "c3":
         args.log_rows = 22
-    provers = [va.Prover(machine, rc, log_blowup=2 if args.workload == "c3" else 1, device=local_rank) for _ in range(max(1, args.inflight))]
+    hash_kind = va.HASH_POSEIDON16 if args.mmcs == "poseidon" else va.HASH_KECCAK256
+    provers = [va.Prover(machine, rc, log_blowup=2 if args.workload == "c3" else 1, device=local_rank, hash_kind=hash_kind) for _ in range(max(1, args.inflight))]
     prover = provers[0]
 
     # one independent segment per rank: distinct loop bounds with the same padded shape
@@ -362,6 +366,10 @@ def main():
             launches_, ms_, _, valu_ = stat
             if not valu_ or not ms_:
                 return None
+            if name.startswith("k_poseidon"):  # Poseidon-16 kernels: Montgomery products, i.e. half-rate multiply instructions
+                rate = valu_ / (ms_ * 1e-3)
+                return {"achieved": rate, "unit": "wave64 VALU instr/s (modelled: 16 x 16 lazily accumulated products per round, 30 rounds)", "peak": mb["half_rate"],
+                        "frac": rate / mb["half_rate"], "peak_is": "issue rate of v_mul_lo/hi_u32 / v_mad_u64_u32 over the chip (tools/microbench.hip)"}
             perms = valu_ * 64.0 / KECCAK_VALU_PER_PERM
             rate = perms / (ms_ * 1e-3)
             cycles_per_perm = 24 * (KECCAK_FULL_RATE_PER_ROUND * simds * mb["clock_hz"] / mb["full_rate"] + KECCAK_HALF_RATE_PER_ROUND * simds * mb["clock_hz"] / mb["half_rate"])
@@ -397,7 +405,7 @@ def main():
                     "device-resident trace from scratch (nothing is cached between proofs); ranks differ by their loop bound" % data,
             "config": {
                 "workload": wl_name + ", 14 chips, one proof per GPU",
-                "field": "BabyBear / Ext5", "mmcs": "Keccak-256", "fri_blowup": 1 << prover.log_blowup,
+                "field": "BabyBear / Ext5", "mmcs": "Keccak-256" if args.mmcs == "keccak" else "Poseidon-16 (PaddingFreeSponge<16,8,8> / TruncatedPermutation<2,8,16>; north-star variant, not the reference's)", "fri_blowup": 1 << prover.log_blowup,
                 "log_blowup": prover.log_blowup, "num_queries": prover.num_queries, "pow_bits": prover.pow_bits,
                 "parallelism": ("segments: one independent proof per GPU + all-gather of 3 roots per proof via " + comm_note) if world > 1 else "single GPU",
                 "proofs_in_flight_per_gpu": len(provers),
@@ -444,6 +452,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             headline = min(args.log_rows, 20)
+            if args.mmcs == "poseidon":
+                from oracle import pyoracle as po
+                po.set_mmcs_hash(1, rc)
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_rows if args.cpu_log_rows else headline, rc, args.log_rows)
         print(json.dumps(out))
     if world > 1:

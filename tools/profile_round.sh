@@ -20,11 +20,14 @@ rocprofv3 --kernel-trace --stats -d "$OUT/stats1" -o run -- $B --no-extra-legs -
 # 2) counters, separate passes, one proof in flight, few steps
 P="$B --inflight 1 --steps 2 --warmup 1"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d "$OUT/pmc_valu" -o run -- $P > "$OUT/pmc_valu.json" 2> "$OUT/pmc_valu.err"
+# VALU issue utilisation per SIMD: busy cycles of the CUs and of the whole GPU next to the VALU-active wave cycles
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_busy" -o run -- $P > "$OUT/pmc_busy.json" 2> "$OUT/pmc_busy.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o run -- $P > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o run -- $P > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
 # full default bench line (with the CPU baseline leg) and the other single-GPU configs
 python $ROOT/bench.py > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"
 for w in c3 c4; do $B --workload $w --steps 6 --warmup 2 > "$OUT/bench_$w.json" 2> /dev/null; done
+$B --mmcs poseidon --steps 4 --warmup 1 > "$OUT/bench_poseidon.json" 2> "$OUT/bench_poseidon.err"
 # summarise here: the databases are too big to be copied back, the summaries are not
-cd "$ROOT" && python tools/summarize_prof.py "$TAG" "$OUT/summary" && rm -rf "$OUT"/stats1 "$OUT"/stats2 "$OUT"/pmc_valu "$OUT"/pmc_fetch "$OUT"/pmc_write
+cd "$ROOT" && python tools/summarize_prof.py "$TAG" "$OUT/summary" && rm -rf "$OUT"/stats1 "$OUT"/stats2 "$OUT"/pmc_valu "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_busy
 ls "$OUT/summary"

@@ -39,6 +39,50 @@ def kernel_stats(db_path, out_csv, header):
     return {short(n): (c, t, a) for n, c, t, a, p in rows}
 
 
+def timeline(db_path, out_txt, header):
+    """One proof alone on the GPU: where the wall time of each phase goes — busy (union of kernel intervals), idle gaps between
+    kernels, and the launches, per kernel class, of the LAST proof in the trace (delimited by k_ingest launches)."""
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    if not rows:
+        return
+    starts = [i for i, r in enumerate(rows) if "k_ingest" in r[0] and (i == 0 or "k_ingest" not in rows[i - 1][0])]
+    if len(starts) < 2:
+        return
+    a, b = starts[-2], starts[-1]  # a complete proof
+    seg = rows[a:b]
+    t0, t1 = seg[0][1], max(r[2] for r in seg)
+    busy, cur_s, cur_e = 0, seg[0][1], seg[0][2]
+    for _, s_, e_ in seg[1:]:
+        if s_ > cur_e:
+            busy += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    busy += cur_e - cur_s
+    per = {}
+    for n, s_, e_ in seg:
+        k = per.setdefault(short(n), [0, 0])
+        k[0] += 1
+        k[1] += e_ - s_
+    with open(out_txt, "w") as f:
+        f.write("# %s\n# one complete proof (kernels between two consecutive k_ingest groups), times in microseconds\n" % header)
+        f.write("span_us %.1f  busy_us %.1f  idle_gaps_us %.1f  launches %d\n" % ((t1 - t0) / 1e3, busy / 1e3, (t1 - t0 - busy) / 1e3, len(seg)))
+        # gaps by size
+        gaps = []
+        prev_end = seg[0][2]
+        for _, s_, e_ in seg[1:]:
+            if s_ > prev_end:
+                gaps.append(s_ - prev_end)
+            prev_end = max(prev_end, e_)
+        for lo, hi in ((0, 2e3), (2e3, 5e3), (5e3, 20e3), (20e3, 1e12)):
+            g = [x for x in gaps if lo <= x < hi]
+            f.write("gaps %5.0f-%-8s us: %4d  total %.1f us\n" % (lo / 1e3, "%.0f" % (hi / 1e3) if hi < 1e11 else "inf", len(g), sum(g) / 1e3))
+        f.write("kernel launches total_us avg_us\n")
+        for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            f.write("%-28s %5d %10.1f %8.1f\n" % (k, n, t / 1e3, t / 1e3 / n))
+
+
 def counters(db_path):
     db = sqlite3.connect(db_path)
     out = {}
@@ -64,7 +108,13 @@ def main():
         p = db_of(os.path.join(src, leg))
         if p:
             kernel_stats(p, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, "inflight1" if leg == "stats1" else "default")), "rocprofv3 --kernel-trace --stats -- " + cmd + "   (MI355X)")
-    for f in ("bench_default.json", "bench_inflight1.json", "bench_full.json", "bench_c3.json", "bench_c4.json", "stats1.json", "stats2.json"):
+    p = db_of(os.path.join(src, "stats1"))
+    if p:
+        try:
+            timeline(p, os.path.join(dst, "%s_timeline_inflight1.txt" % tag), "rocprofv3 --kernel-trace -- python bench.py --no-cpu-baseline --no-extra-legs --inflight 1 --steps 10 --warmup 1   (MI355X)")
+        except sqlite3.Error as e:
+            print("timeline failed:", e)
+    for f in ("bench_default.json", "bench_inflight1.json", "bench_full.json", "bench_c3.json", "bench_c4.json", "bench_poseidon.json", "stats1.json", "stats2.json"):
         p = os.path.join(src, f)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, f)))
@@ -86,6 +136,25 @@ def main():
                 e["frac_wave_cycles_wait_any"] = v["SQ_WAIT_ANY"][1] / wc
                 e["frac_wave_cycles_wait_inst_any"] = v["SQ_WAIT_INST_ANY"][1] / wc
                 e["frac_wave_cycles_active_inst_any"] = v["SQ_ACTIVE_INST_ANY"][1] / wc
+    p = db_of(os.path.join(src, "pmc_busy"))
+    if p:
+        c, _ = counters(p)
+        for k, v in c.items():
+            try:
+                n = v["GRBM_GUI_ACTIVE"][0]
+                # Calibrated on tools/microbench.hip's rate kernels (profiles/r02_counter_calibration.txt, second table):
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs (value / 8 = GPU cycles of the launch); SQ_ACTIVE_INST_VALU equals
+                # SQ_INSTS_VALU (one unit per instruction, whatever its issue rate) and SQ_BUSY_CU_CYCLES / 256 = cycles a CU was busy.
+                cycles = v["GRBM_GUI_ACTIVE"][1] / n / 8.0
+                insts = v["SQ_INSTS_VALU"][1] / n
+                e = pmc.setdefault(k, {})
+                e["gpu_cycles_per_launch"] = cycles
+                # SIMD cycles available per VALU instruction issued: 2.3-2.5 = a kernel of full-rate instructions running at the issue
+                # peak, 4.2 = one of half-rate instructions at ITS peak (profiles/r02_microbench.txt); larger = issue slots left idle
+                e["simd_cycles_per_valu_instr"] = cycles * 1024.0 / insts if insts else None
+                e["cu_busy_fraction"] = v["SQ_BUSY_CU_CYCLES"][1] / n / 256.0 / cycles if cycles else None
+            except (KeyError, ZeroDivisionError):
+                pass
     for leg, cname, key in (("pmc_fetch", "FETCH_SIZE", "hbm_read_bytes_per_launch"), ("pmc_write", "WRITE_SIZE", "hbm_write_bytes_per_launch")):
         p = db_of(os.path.join(src, leg))
         if p:
@@ -101,7 +170,9 @@ def main():
     if pmc:
         with open(os.path.join(dst, tag + "_pmc.json"), "w") as f:
             json.dump({"source": "tools/profile_round.sh passes pmc_valu / pmc_fetch / pmc_write (one proof in flight, 1 warmup + 2 timed proofs + setup)",
-                       "notes": "SQ_* cycle counters are in quad-cycles; FETCH_SIZE doubled per the gfx950 correction, *_raw = as reported",
+                       "notes": "SQ_* cycle counters are in quad-cycles; FETCH_SIZE doubled per the gfx950 correction (calibrated this round on copies of known size, "
+                                "profiles/r02_counter_calibration.txt: x2 holds for 4- and 16-byte-per-lane coalesced reads and for 128-byte row segments; 64-byte row "
+                                "segments really fetch two bytes per byte used; WRITE_SIZE is exact), *_raw = as reported",
                        "kernels": pmc}, f, indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(dst)))
 
