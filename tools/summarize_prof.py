@@ -78,6 +78,16 @@ def timeline(db_path, out_txt, header):
         for lo, hi in ((0, 2e3), (2e3, 5e3), (5e3, 20e3), (20e3, 1e12)):
             g = [x for x in gaps if lo <= x < hi]
             f.write("gaps %5.0f-%-8s us: %4d  total %.1f us\n" % (lo / 1e3, "%.0f" % (hi / 1e3) if hi < 1e11 else "inf", len(g), sum(g) / 1e3))
+        # the largest idle gaps and the kernels either side (host synchronisation points show up here)
+        big, prev_end, prev_name = [], seg[0][2], short(seg[0][0])
+        for n_, s_, e_ in seg[1:]:
+            if s_ > prev_end:
+                big.append((s_ - prev_end, prev_name, short(n_), (s_ - t0) / 1e3))
+            if e_ >= prev_end:
+                prev_end, prev_name = e_, short(n_)
+        f.write("largest gaps: gap_us  after_kernel -> before_kernel  (at_us from the start of the proof)\n")
+        for g_, a_, b_, at_ in sorted(big, reverse=True)[:40]:
+            f.write("  %8.1f  %-22s -> %-22s  (%.0f)\n" % (g_ / 1e3, a_, b_, at_))
         f.write("kernel launches total_us avg_us\n")
         for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             f.write("%-28s %5d %10.1f %8.1f\n" % (k, n, t / 1e3, t / 1e3 / n))

@@ -28,6 +28,7 @@ struct ColMat {
 
 // One Merkle tree over column-major device matrices of mixed heights (FieldMerkleTreeMmcs, App. B5).
 struct DeviceTree {
+    static constexpr uint64_t TOP_FIRST_LEN = 256;
     DeviceCtx* ctx = nullptr;
     std::vector<DBuf> layers;          // layers[i]: (max_height >> i) digests of 8 words; back() = root
     std::vector<uint64_t> layer_len;
@@ -92,11 +93,14 @@ struct DeviceTree {
             layers.emplace_back(c, (size_t)len * 8);
             layer_len.push_back(len);
             const Group* inj = (gi < groups.size() && groups[gi].height == len) ? &groups[gi] : nullptr;
-            if (len > 1024) {
+            // Layers of more than TOP_FIRST_LEN parents are their own launches (spread over the whole GPU); the rest of the tree is one
+            // single-workgroup launch.  256, not the 1024 a workgroup could take: inside one workgroup a 1024-parent layer puts four
+            // waves on each SIMD of ONE CU and costs 27 us (512 parents: 15 us), as a launch of its own across the CUs 9 + 2 us.
+            if (len > TOP_FIRST_LEN) {
                 if (pos) vk::launch_poseidon_compress(c->stream, tab, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
                 else vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
                                                 layers.back().data);
-            } else {  // the last <= 11 layers go into one launch
+            } else {  // the last <= 9 layers go into one launch
                 if (top.levels == 0) { top.prev = layers[layers.size() - 2].data; top.first_len = len; }
                 top.out[top.levels] = layers.back().data;
                 top.cols[top.levels] = inj ? pd + inj->first : nullptr;
