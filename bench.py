@@ -305,13 +305,17 @@ def main():
     # prover latency with nothing else in flight (the "prover ms" half of the metric)
     single, prof1 = None, None
     if len(provers) > 1 and not args.no_extra_legs:
-        provers[0].set_profiling(True)
+        # latency of one proof alone: no per-launch HIP events (two hipEventRecord per launch cost the host ~2 ms per proof, which a
+        # lone proof cannot hide), then two further proofs WITH events for this leg's per-kernel figures
         fence()
         t0 = time.perf_counter()
-        for _ in range(4):
+        for _ in range(6):
             provers[0].prove(*inputs[0])
         torch.cuda.synchronize()
-        single = (time.perf_counter() - t0) / 4 * 1e3
+        single = (time.perf_counter() - t0) / 6 * 1e3
+        provers[0].set_profiling(True)
+        for _ in range(2):
+            provers[0].prove(*inputs[0])
         prof1 = provers[0].profile()
         provers[0].set_profiling(False)
     pcie_ms = oplog_ms = None

@@ -71,7 +71,7 @@ struct DeviceTree {
         DBuf ptr_buf;
         if (!single) {
             ptr_buf = DBuf(c, ptrs.size() * 2);
-            c->upload(ptr_buf.data, ptrs.data(), ptrs.size() * 8);
+            c->upload_async(ptr_buf.data, ptrs.data(), ptrs.size() * 8);
         }
         const uint32_t* const* pd = (const uint32_t* const*)ptr_buf.data;
 

@@ -30,6 +30,7 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
         pos[480 + d] = acc.v;
     }
     pow_pos_ = DBuf(ctx_.get(), pos);
+    VG_HIP_CHECK(hipHostMalloc((void**)&cs_pinned_, CS_PINNED_WORDS * 4));
     ctx_->hash_kind = fri_.hash_kind;
     ctx_->poseidon_tab = pow_pos_.data;
 }
@@ -47,7 +48,7 @@ uint32_t Prover::grind(Challenger& ch) {
     const uint32_t batch = 1u << (bits + 6 > 20 ? 20 : bits + 6);
     uint32_t* best_dev = pow_pos_.data + 512;
     for (uint64_t first = 0; first < vg::P; first += batch) {
-        VG_HIP_CHECK(hipMemcpyAsync(pow_pos_.data + 496, st, 17 * 4, hipMemcpyHostToDevice, c.stream));
+        c.upload_async(pow_pos_.data + 496, st, 17 * 4);
         uint32_t count = (uint32_t)std::min<uint64_t>(batch, vg::P - first);
         vk::launch_pow_grind(c.stream, pow_pos_.data, k_pending, (uint32_t)first, count, bits, best_dev);
         uint32_t best;
@@ -60,6 +61,7 @@ uint32_t Prover::grind(Challenger& ch) {
     throw std::runtime_error("pow: no witness found");
 }
 Prover::~Prover() {
+    if (cs_pinned_) (void)hipHostFree(cs_pinned_);
     prog_dev_.clear();
     iw_dev_.clear();
 }
@@ -313,8 +315,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     }
     ingest_section.join();
     c.check_launch("ingest");
-    c.sync();
-    tm.ingest = ms_since(t0);
+    tm.ingest = ms_since(t0);  // host-side phase boundaries: the GPU work of a phase completes at the next true synchronisation (a root download)
 
     // ---------------- preprocessed + main commitments (lib.rs:189-225)
     t0 = Clock::now();
@@ -341,6 +342,8 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     std::vector<std::vector<Ext5>> bus_alphas(NC), betas(NC);
     std::vector<DMat> perm_nat(NC);
     std::vector<Ext5> cumulative_sums(NC);
+    uint32_t* cs_host = nullptr;  // 5 canonical words per chip, valid after the next stream synchronisation
+    DBuf cs_keep;
     {
         std::vector<uint32_t> pool;
         std::vector<size_t> off(NC);
@@ -377,10 +380,14 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         c.check_launch("perm trace");
         DBuf gd(&c, gl.desc), gout(&c, gl.next_dst);
         vk::launch_gather(c.stream, gd.data, gl.n(), gout.data);
-        std::vector<uint32_t> cs(gl.next_dst);
-        c.download(cs.data(), gout.data, cs.size() * 4);
-        for (size_t i = 0; i < NC; i++) cumulative_sums[i] = ext_from_canonical(&cs[5 * i]);
+        // asynchronous copy into pinned memory; it has landed once the permutation commit below has synchronised on its root
+        if (gl.next_dst > CS_PINNED_WORDS) throw std::invalid_argument("prove: too many chips");
+        cs_host = cs_pinned_;  // a pinned area of its own: the generic staging buffer is reused by the root download below
+        VG_HIP_CHECK(hipMemcpyAsync(cs_host, gout.data, gl.next_dst * 4, hipMemcpyDeviceToHost, c.stream));
+        cs_keep = std::move(gout);
     }
+    auto read_cumulative_sums = [&]() { for (size_t i = 0; i < NC; i++) cumulative_sums[i] = ext_from_canonical(cs_host + 5 * i); };
+    if (dbg && dbg->check_constraints) { c.sync(); read_cumulative_sums(); }  // the debug check needs them before the commit
     tm.perm = ms_since(t0);
     if (dbg && dbg->keep_matrices) {
         dbg->perm_traces.resize(NC);
@@ -455,6 +462,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         perm_pd = commit_batches(&c, in, nullptr, fri_);
     }
     ch.observe_digest(perm_pd->tree.root);
+    read_cumulative_sums();  // the root download synchronised the stream: the asynchronous copy has landed
     perm_nat.clear();
     main_own.clear();
     prep_nat.clear();
@@ -497,7 +505,6 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         }
         quotient_section.join();
         c.check_launch("quotient");
-        c.sync();
     }
     tm.quotient = ms_since(t0);
     if (dbg && dbg->keep_matrices) {
@@ -541,6 +548,11 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
 
     // ---------------- assemble MachineProof (flat "VPF1" words; machine/src/proof.rs:13-44, App. B12)
     std::vector<uint32_t> pw;
+    {
+        size_t chip_words = 26;
+        for (size_t i = 0; i < NC; i++) chip_words += 11 + 5 * (2 * machine_.airs[i].width + 10 * (machine_.airs[i].interactions.size() + 1) + 10);
+        pw.reserve(chip_words + opening.proof_words.size());
+    }
     pw.push_back(PROOF_MAGIC);
     pw.push_back((uint32_t)NC);
     for (int k = 0; k < 8; k++) pw.push_back(main_pd->tree.root[k]);
@@ -658,7 +670,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         open_section.join();
         c.check_launch("opened values");
         std::vector<uint32_t> out(out_words + 4);
-        c.download(out.data(), out_dev.data, out_words * 4);
+        c.download_small(out.data(), out_dev.data, out_words * 4);  // through pinned memory
         for (auto& j : jobs)
             for (uint64_t col = 0; col < j.cw; col++)
                 for (int p = 0; p < j.np; p++) res.opened[j.r][j.i][j.p0 + p][j.c0 + col] = ext_from_canonical(&out[j.out_off + (col * j.np + p) * 5]);
@@ -745,7 +757,6 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         }
         reduce_section.join();
         c.check_launch("reduce openings");
-        c.sync();
     }
     res.ms_reduce = ms_since(t0);
     if (log_max < lb + 0u) throw std::invalid_argument("open: nothing to open");
@@ -783,9 +794,17 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     c.check_launch("fri fold");
     // `cur` now holds 2^lb values that must all be equal (a constant polynomial)
     std::vector<uint32_t> fin(5ull << lb), commits(8 * n_layers + 8);
-    VG_HIP_CHECK(hipMemcpyAsync(chw.data(), ch_dev.data, chw.size() * 4, hipMemcpyDeviceToHost, c.stream));
-    if (n_layers) VG_HIP_CHECK(hipMemcpyAsync(commits.data(), commits_dev.data, 8 * n_layers * 4, hipMemcpyDeviceToHost, c.stream));
-    c.download(fin.data(), cur.data, fin.size() * 4);  // synchronises the stream: all three copies have landed
+    {   // sponge state, roots and final values: three copies into one pinned area, one synchronisation
+        const size_t n0 = chw.size(), n1 = 8 * (size_t)n_layers, n2 = fin.size();
+        uint32_t* pin = (uint32_t*)c.pinned_buffer((n0 + n1 + n2) * 4);
+        VG_HIP_CHECK(hipMemcpyAsync(pin, ch_dev.data, n0 * 4, hipMemcpyDeviceToHost, c.stream));
+        if (n1) VG_HIP_CHECK(hipMemcpyAsync(pin + n0, commits_dev.data, n1 * 4, hipMemcpyDeviceToHost, c.stream));
+        VG_HIP_CHECK(hipMemcpyAsync(pin + n0 + n1, cur.data, n2 * 4, hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        memcpy(chw.data(), pin, n0 * 4);
+        memcpy(commits.data(), pin + n0, n1 * 4);
+        memcpy(fin.data(), pin + n0 + n1, n2 * 4);
+    }
     for (int i = 0; i < 16; i++) ch.state[i] = Fp::raw(chw[i]);
     ch.in.clear();
     for (uint32_t i = 0; i < chw[32]; i++) ch.in.push_back(Fp::raw(chw[16 + i]));
@@ -810,73 +829,73 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     uint32_t pow_witness = grind(ch);
     res.ms_fri = ms_since(t0);
 
-    // ---- queries
+    // ---- queries.  The gather kernel writes every opened row, sibling value and Merkle path straight to its position in the proof
+    // words (the TwoAdicFriPcsProof tail of the "VPF1" layout, App. B12); the host only patches in the length fields and the few
+    // values it already holds (commit-phase roots, final polynomial, proof-of-work witness).  One flat descriptor array, sized up
+    // front: building it is the only host work between the last FRI kernel and the gather.
     t0 = Clock::now();
     std::vector<uint64_t> indices(fri_.num_queries);
     for (auto& ix : indices) ix = ch.sample_bits(log_max);
-    GatherList gl;
-    struct QOff { std::vector<uint32_t> sib; std::vector<std::vector<uint32_t>> layer_path; std::vector<std::vector<uint32_t>> rows; std::vector<std::vector<uint32_t>> path; };
-    std::vector<QOff> qoff(indices.size());
-    auto add_path = [&](const DeviceTree& t, uint64_t idx, std::vector<uint32_t>& out) {
-        for (unsigned l = 0; l < t.log_max_height; l++) out.push_back(gl.add(t.layers[l].data + 8 * ((idx >> l) ^ 1), 1, 8, 1));
+    const size_t NQ = indices.size(), NL = layer_trees.size();
+    size_t n_desc = 0, n_fix = 8 * NL + 16;
+    for (size_t l = 0; l < NL; l++) n_desc += 1 + layer_trees[l].log_max_height;
+    for (size_t r = 0; r < NR; r++) n_desc += rounds[r].pd->ldes.size() + rounds[r].pd->tree.log_max_height;
+    n_desc *= NQ;
+    n_fix += NQ * (2 + 2 * NL + NR * 2);
+    for (size_t r = 0; r < NR; r++) n_fix += NQ * rounds[r].pd->ldes.size();
+    std::vector<uint32_t> desc;
+    desc.reserve(6 * n_desc + 8);
+    std::vector<std::pair<uint32_t, uint32_t>> fix;  // (position in the tail, value) of the words the host writes
+    fix.reserve(n_fix);
+    uint32_t pos = 0;
+    auto host_word = [&](uint32_t v) { fix.emplace_back(pos++, v); };
+    auto gather = [&](const uint32_t* src, uint64_t stride, uint32_t count, uint32_t kind) {
+        const uint64_t pv = (uint64_t)src;
+        const uint32_t d6[6] = {(uint32_t)pv, (uint32_t)(pv >> 32), (uint32_t)stride, (uint32_t)(stride >> 32), count | (kind << 28), pos};
+        desc.insert(desc.end(), d6, d6 + 6);
+        pos += count;
     };
-    for (size_t q = 0; q < indices.size(); q++) {
-        uint64_t index = indices[q];
-        QOff& o = qoff[q];
-        o.layer_path.resize(layer_trees.size());
-        for (size_t l = 0; l < layer_trees.size(); l++) {
-            uint64_t idx_i = index >> l, sib = idx_i ^ 1, pair = idx_i >> 1;
-            uint64_t half = 1ull << (log_max - 1 - l);
-            o.sib.push_back(gl.add(layer_bufs[l].data + (5 * (sib & 1)) * half + pair, half, 5, 0));
-            add_path(layer_trees[l], pair, o.layer_path[l]);
+    auto gather_path = [&](const DeviceTree& t, uint64_t idx) {
+        host_word(t.log_max_height);
+        for (unsigned l = 0; l < t.log_max_height; l++) gather(t.layers[l].data + 8 * ((idx >> l) ^ 1), 1, 8, 1);
+    };
+    host_word((uint32_t)commit_phase_commits.size());
+    for (auto& r : commit_phase_commits) for (uint32_t w : r) host_word(w);
+    host_word((uint32_t)NQ);
+    for (size_t q = 0; q < NQ; q++) {
+        const uint64_t index = indices[q];
+        host_word((uint32_t)NL);
+        for (size_t l = 0; l < NL; l++) {
+            const uint64_t idx_i = index >> l, sib = idx_i ^ 1, pair = idx_i >> 1, half = 1ull << (log_max - 1 - l);
+            gather(layer_bufs[l].data + (5 * (sib & 1)) * half + pair, half, 5, 0);
+            gather_path(layer_trees[l], pair);
         }
-        o.rows.resize(NR); o.path.resize(NR);
+    }
+    for (int k = 0; k < 5; k++) host_word(fpw[k]);
+    host_word(pow_witness);
+    host_word((uint32_t)NQ);
+    for (size_t q = 0; q < NQ; q++) {
+        const uint64_t index = indices[q];
+        host_word((uint32_t)NR);
         for (size_t r = 0; r < NR; r++) {
             const DeviceTree& t = rounds[r].pd->tree;
-            uint64_t idx_r = index >> (log_max - t.log_max_height);
+            const uint64_t idx_r = index >> (log_max - t.log_max_height);
+            host_word((uint32_t)rounds[r].pd->ldes.size());
             for (auto& lde : rounds[r].pd->ldes) {
-                unsigned lh = vg::log2_strict_u64(lde.height);
-                uint64_t row = idx_r >> (t.log_max_height - lh);
-                o.rows[r].push_back(gl.add(lde.data + row, lde.height, (uint32_t)lde.width, 0));
+                const unsigned lh = vg::log2_strict_u64(lde.height);
+                host_word((uint32_t)lde.width);
+                gather(lde.data + (idx_r >> (t.log_max_height - lh)), lde.height, (uint32_t)lde.width, 0);
             }
-            add_path(t, idx_r, o.path[r]);
+            gather_path(t, idx_r);
         }
     }
-    DBuf gd(&c, gl.desc), gout(&c, gl.next_dst + 4);
-    vk::launch_gather(c.stream, gd.data, gl.n(), gout.data);
+    const size_t tail_words = pos;
+    DBuf gd(&c, desc), gout(&c, tail_words + 4);
+    vk::launch_gather(c.stream, gd.data, desc.size() / 6, gout.data);
     c.check_launch("query gather");
-    std::vector<uint32_t> g(gl.next_dst + 4);
-    c.download(g.data(), gout.data, (size_t)gl.next_dst * 4);
-
-    // ---- TwoAdicFriPcsProof as words (the tail of the "VPF1" layout, App. B12)
-    std::vector<uint32_t>& pw = res.proof_words;
-    pw.push_back((uint32_t)commit_phase_commits.size());
-    for (auto& r : commit_phase_commits) pw.insert(pw.end(), r.begin(), r.end());
-    pw.push_back((uint32_t)indices.size());
-    for (size_t q = 0; q < indices.size(); q++) {
-        pw.push_back((uint32_t)layer_trees.size());
-        for (size_t l = 0; l < layer_trees.size(); l++) {
-            pw.insert(pw.end(), &g[qoff[q].sib[l]], &g[qoff[q].sib[l]] + 5);
-            pw.push_back((uint32_t)qoff[q].layer_path[l].size());
-            for (uint32_t o : qoff[q].layer_path[l]) pw.insert(pw.end(), &g[o], &g[o] + 8);
-        }
-    }
-    pw.insert(pw.end(), fpw, fpw + 5);
-    pw.push_back(pow_witness);
-    pw.push_back((uint32_t)indices.size());
-    for (size_t q = 0; q < indices.size(); q++) {
-        pw.push_back((uint32_t)NR);
-        for (size_t r = 0; r < NR; r++) {
-            pw.push_back((uint32_t)rounds[r].pd->ldes.size());
-            for (size_t i = 0; i < rounds[r].pd->ldes.size(); i++) {
-                uint32_t w = (uint32_t)rounds[r].pd->ldes[i].width;
-                pw.push_back(w);
-                pw.insert(pw.end(), &g[qoff[q].rows[r][i]], &g[qoff[q].rows[r][i]] + w);
-            }
-            pw.push_back((uint32_t)qoff[q].path[r].size());
-            for (uint32_t o : qoff[q].path[r]) pw.insert(pw.end(), &g[o], &g[o] + 8);
-        }
-    }
+    res.proof_words.resize(tail_words);
+    c.download_small(res.proof_words.data(), gout.data, tail_words * 4);  // through pinned memory
+    for (auto& f : fix) res.proof_words[f.first] = f.second;
     res.ms_queries = ms_since(t0);
     return res;
 }

@@ -108,6 +108,8 @@ class Prover {
     Poseidon16 perm16_;
     std::vector<DBuf> prog_dev_, iw_dev_;  // per chip: program instructions, interaction words
     DBuf pow_pos_;                         // [480 rc][16 mds coefficients][16 state][1 best] for k_pow_grind
+    static constexpr size_t CS_PINNED_WORDS = 5 * 256;
+    uint32_t* cs_pinned_ = nullptr;        // pinned landing area of the chips' cumulative sums (asynchronous D2H inside prove)
     uint32_t grind(Challenger& ch);
     void fill_quotient_args(vk::QuotientArgs& a, int chip, vk::DMatView main_lde, vk::DMatView perm_lde, vk::DMatView prep_lde, unsigned log_n, const uint32_t* consts_dev);
 };

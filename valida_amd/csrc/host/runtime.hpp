@@ -27,6 +27,12 @@ struct DeviceCtx {
     uint32_t* table_mem = nullptr;
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // Pinned staging ring for the small host -> device uploads of a proof (constant pools, pointer tables, gather descriptors):
+    // the bytes are copied here and an ASYNCHRONOUS copy is enqueued on the main stream — no host synchronisation per upload
+    // (each one used to cost a stream round trip of tens of microseconds during which the GPU idled).
+    uint8_t* stage = nullptr;
+    static constexpr size_t STAGE_BYTES = 16u << 20;
+    size_t stage_pos = 0;
     vk::Profiler profiler;
     // MMCS hash of this context (vgpu_config.hash_kind): 0 = Keccak-256 (the reference's configuration), 1 = Poseidon-16 sponge /
     // truncated permutation; poseidon_tab = [480 round constants][16 MDS coefficients] on the device (owned by the Prover)
@@ -73,6 +79,7 @@ struct DeviceCtx {
         for (auto& kv : live_blocks) (void)hipFree(kv.first);
         if (table_mem) (void)hipFree(table_mem);
         if (pinned) (void)hipHostFree(pinned);
+        if (stage) (void)hipHostFree(stage);
         (void)hipStreamDestroy(stream);
     }
     DeviceCtx(const DeviceCtx&) = delete;
@@ -183,9 +190,24 @@ struct DeviceCtx {
         VG_HIP_CHECK(hipStreamSynchronize(stream));
         memcpy(dst, pin, bytes);
     }
+    // Host -> device without a synchronisation: valid for consumers enqueued later on the main stream (or on the aux streams after
+    // a fork).  The source may be reused at once.
+    void upload_async(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return;
+        if (bytes > STAGE_BYTES / 2) { upload(dst, src, bytes); return; }
+        if (!stage) VG_HIP_CHECK(hipHostMalloc((void**)&stage, STAGE_BYTES));
+        size_t pos = (stage_pos + 63) & ~(size_t)63;
+        if (pos + bytes > STAGE_BYTES) {  // wrap: everything staged so far must have been read by the copy engine
+            VG_HIP_CHECK(hipStreamSynchronize(stream));
+            pos = 0;
+        }
+        memcpy(stage + pos, src, bytes);
+        VG_HIP_CHECK(hipMemcpyAsync(dst, stage + pos, bytes, hipMemcpyHostToDevice, stream));
+        stage_pos = pos + bytes;
+    }
     uint32_t* upload_words(const std::vector<uint32_t>& w) {
         uint32_t* d = alloc_words(w.size());
-        upload(d, w.data(), w.size() * 4);
+        upload_async(d, w.data(), w.size() * 4);
         return d;
     }
 
