@@ -160,6 +160,8 @@ def main():
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the latency / PCIe-inclusive / operation-log legs (profiling runs: the process then consists of the warmup and the timed region only)")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="experiment: no per-launch HIP events in the timed region (then no per-kernel figures / roofline in the line)")
     ap.add_argument("--mmcs", choices=["keccak", "poseidon"], default="keccak",
                     help="Merkle hash: keccak = the reference's configuration (headline); poseidon = BASELINE.json's north-star variant "
                          "(PaddingFreeSponge / TruncatedPermutation over Poseidon-16), a separate leg with its own roofline")
@@ -333,7 +335,7 @@ def main():
         torch.cuda.synchronize()
         oplog_ms = (time.perf_counter() - t0) / (2 * len(provers)) * 1e3
     for p_ in provers:
-        p_.set_profiling(True)
+        p_.set_profiling(not args.no_kernel_events)
     fence()
     t0 = time.perf_counter()
     phase = {}
@@ -357,6 +359,10 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
+        if not prof:  # --no-kernel-events experiment: no per-kernel figures, hence no roofline: not a contract line
+            print(json.dumps({"metric": "proofs/sec (experiment without per-launch events)", "value": value, "unit": "proofs/s", "ms_per_step": ms_per_step,
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prover_ms_single_proof_in_flight": single}))
+            return
         # dominant kernel by accumulated HIP-event time
         name, (launches, ms, nbytes, valu_ops) = max(prof.items(), key=lambda kv: kv[1][1])
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

@@ -75,6 +75,7 @@ struct DeviceCtx {
         (void)hipStreamSynchronize(stream);
         for (int i = 0; i < NUM_AUX; i++) { (void)hipStreamSynchronize(aux[i]); (void)hipStreamDestroy(aux[i]); (void)hipEventDestroy(join_ev[i]); }
         (void)hipEventDestroy(fork_ev);
+        if (sync_ev) (void)hipEventDestroy(sync_ev);
         for (auto& kv : free_blocks) (void)hipFree(kv.second);
         for (auto& kv : live_blocks) (void)hipFree(kv.first);
         if (table_mem) (void)hipFree(table_mem);
@@ -169,7 +170,22 @@ struct DeviceCtx {
         }
         return pinned;
     }
-    void sync() { VG_HIP_CHECK(hipStreamSynchronize(stream)); }
+    // Wait for the main stream by POLLING an event: hipStreamSynchronize parks the thread and its wake-up costs 50-150 us — with a
+    // dozen true synchronisation points per proof (roots, opened values, final values) that was >1 ms of an idle GPU per proof.
+    // A proof's host thread has nothing else to do while it waits, and there are more host cores than proofs in flight.
+    hipEvent_t sync_ev = nullptr;
+    void sync() {
+        if (!sync_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&sync_ev, hipEventDisableTiming));
+        VG_HIP_CHECK(hipEventRecord(sync_ev, stream));
+        for (;;) {
+            hipError_t e = hipEventQuery(sync_ev);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) throw std::runtime_error(std::string("hipEventQuery: ") + hipGetErrorString(e));
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
     void check_launch(const char* what) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -177,17 +193,17 @@ struct DeviceCtx {
     // small synchronous transfers (roots, challenges, descriptors)
     void upload(void* dst, const void* src, size_t bytes) {
         VG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
-        VG_HIP_CHECK(hipStreamSynchronize(stream));
+        sync();
     }
     void download(void* dst, const void* src, size_t bytes) {
         VG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
-        VG_HIP_CHECK(hipStreamSynchronize(stream));
+        sync();
     }
     // small D2H through pinned memory (a pageable destination makes hipMemcpyAsync take the slow staged path)
     void download_small(void* dst, const void* src, size_t bytes) {
         void* pin = pinned_buffer(bytes);
         VG_HIP_CHECK(hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, stream));
-        VG_HIP_CHECK(hipStreamSynchronize(stream));
+        sync();
         memcpy(dst, pin, bytes);
     }
     // Host -> device without a synchronisation: valid for consumers enqueued later on the main stream (or on the aux streams after
