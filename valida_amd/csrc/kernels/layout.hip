@@ -7,6 +7,7 @@
 namespace vk {
 
 thread_local Profiler* g_profiler = nullptr;
+thread_local ProfScope* g_scope = nullptr;
 
 // src: row-major canonical u32 [height x width] (as handed over by the reference's RowMajorMatrix<Val>,
 // basic/src/lib.rs:223).  dst: column-major Montgomery; row r lands at position bitrev(r) if `bitrev`
@@ -99,13 +100,13 @@ void launch_ingest(hipStream_t st, const uint32_t* src_dev, DMatView dst, bool b
     unsigned blocks = (unsigned)((dst.height + 63) / 64);
     size_t lds = (size_t)64 * (dst.width | 1) * 4;
     ProfScope ps("k_ingest", st, 8.0 * dst.height * dst.width);
-    hipLaunchKernelGGL(k_ingest, dim3(blocks), dim3(256), lds, st, src_dev, dst, log_h, bitrev ? 1 : 0);
+    VK_LAUNCH(k_ingest, dim3(blocks), dim3(256), lds, st, src_dev, dst, log_h, bitrev ? 1 : 0);
 }
 void launch_bitrev_rows(hipStream_t st, DMatView src, DMatView dst) {
     int k = (int)vg::log2_strict_u64(src.height);
     ProfScope ps("k_bitrev_rows", st, 8.0 * src.height * src.width);
     unsigned bx = k < 12 ? (unsigned)(((1u << k) + 255) / 256) : (1u << (k - 12));
-    hipLaunchKernelGGL(k_bitrev_rows, dim3(bx, (unsigned)src.width), dim3(256), 0, st, src, dst, k);
+    VK_LAUNCH(k_bitrev_rows, dim3(bx, (unsigned)src.width), dim3(256), 0, st, src, dst, k);
 }
 void launch_export_rows(hipStream_t st, DMatView src, uint64_t row0, uint64_t nrows, uint32_t* dst_dev) {
     uint64_t total = nrows * src.width;
@@ -113,7 +114,7 @@ void launch_export_rows(hipStream_t st, DMatView src, uint64_t row0, uint64_t nr
     if (blocks > 65535u * 16) blocks = 65535u * 16;
     if (blocks == 0) blocks = 1;
     ProfScope ps("k_export_rows", st, 8.0 * total);
-    hipLaunchKernelGGL(k_export_rows, dim3(blocks), dim3(256), 0, st, src, row0, nrows, dst_dev);
+    VK_LAUNCH(k_export_rows, dim3(blocks), dim3(256), 0, st, src, row0, nrows, dst_dev);
 }
 
 }  // namespace vk

@@ -355,12 +355,12 @@ void launch_intt(hipStream_t st, DMatView m, const DeviceTables& tb) {
     const double pass_bytes = 8.0 * m.height * m.width;
     {
         ProfScope ps("k_intt_contig", st, pass_bytes);
-        hipLaunchKernelGGL(k_intt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, m, k, p.k_lo, tb, ninv);
+        VK_LAUNCH(k_intt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, m, k, p.k_lo, tb, ninv);
     }
     if (p.k_hi > 0) {
         dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)m.width);
         ProfScope ps("k_intt_strided", st, pass_bytes);
-        hipLaunchKernelGGL(k_intt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, m, k, p.k_lo, p.logT, tb, ninv);
+        VK_LAUNCH(k_intt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, m, k, p.k_lo, p.logT, tb, ninv);
     }
 }
 
@@ -386,13 +386,13 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
             cp.step = 0;
             for (unsigned i = 0; i < 128; i++) { cp.hp[i] = a.v; a *= sn; if (i + 1 == hstep) cp.step = a.v; }
             ProfScope ps("k_ntt_strided", st, pass_bytes);
-            hipLaunchKernelGGL(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, cp);
+            VK_LAUNCH(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, cp);
         }
         ProfScope ps("k_ntt_contig", st, pass_bytes);
-        hipLaunchKernelGGL(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0);
+        VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0);
     } else {
         ProfScope ps("k_ntt_contig", st, pass_bytes);
-        hipLaunchKernelGGL(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1);
+        VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1);
     }
 }
 

@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64) k_fri_challenge(const uint32_t* __restrict
 
 void launch_fri_challenge(hipStream_t st, const uint32_t* pos_dev, uint32_t* ch_dev, const uint32_t* digest8_dev, uint32_t* beta5_dev, uint32_t* commit8_dev) {
     ProfScope ps("k_fri_challenge", st, 0.0);
-    hipLaunchKernelGGL(k_fri_challenge, dim3(1), dim3(64), 0, st, pos_dev, ch_dev, digest8_dev, beta5_dev, commit8_dev);
+    VK_LAUNCH(k_fri_challenge, dim3(1), dim3(64), 0, st, pos_dev, ch_dev, digest8_dev, beta5_dev, commit8_dev);
 }
 
 // ---- proof-of-work grinding ---------------------------------------------------------
@@ -420,14 +420,14 @@ __global__ void __launch_bounds__(256) k_pow_grind(const uint32_t* __restrict__ 
 
 void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev) {
     ProfScope ps("k_pow_grind", st, 0.0);
-    hipLaunchKernelGGL(k_pow_grind, dim3((count + 255) / 256), dim3(256), 0, st, pos_dev, k_pending, first, count, (1u << bits) - 1u, best_dev);
+    VK_LAUNCH(k_pow_grind, dim3((count + 255) / 256), dim3(256), 0, st, pos_dev, k_pending, first, count, (1u << bits) - 1u, best_dev);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w) {
     ProfScope ps("k_bary_weights", st, 20.0 * n);
     const uint64_t threads = (n + BARY_ROWS - 1) / BARY_ROWS;
-    hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n, z5_dev, shift.v, tb, w);
+    VK_LAUNCH(k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n, z5_dev, shift.v, tb, w);
 }
 uint64_t col_dot_slots(uint64_t n) {
     uint64_t tiles = (n + DOT_TR - 1) / DOT_TR;
@@ -442,23 +442,23 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
     const int pk = np * 5;
     size_t lds = (size_t)DOT_TRP * (m.width + pk) * 4;
     ProfScope ps("k_col_dot", st, 4.0 * n * (m.width + 5.0 * np));
-    if (np == 1) hipLaunchKernelGGL(k_col_dot<1>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
-    else hipLaunchKernelGGL(k_col_dot<2>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
-    hipLaunchKernelGGL(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
+    if (np == 1) VK_LAUNCH(k_col_dot<1>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
+    else VK_LAUNCH(k_col_dot<2>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
+    VK_LAUNCH(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
 }
 void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width, bool accumulate) {
     ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + (accumulate ? 10.0 : 5.0)));
-    hipLaunchKernelGGL(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out, accumulate ? 1 : 0);
+    VK_LAUNCH(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out, accumulate ? 1 : 0);
 }
 void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
     uint64_t half = L >> 1;
     ProfScope ps("k_fri_fold", st, 20.0 * L + 20.0 * half * (add ? 2 : 1));
-    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, L, beta5_dev, add, tb, out);
+    VK_LAUNCH(k_fri_fold, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, L, beta5_dev, add, tb, out);
 }
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst) {
     if (!n_desc) return;
     ProfScope ps("k_gather", st, 0.0);
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n_desc + 7) / 8)), dim3(256), 0, st, desc_dev, n_desc, dst);
+    VK_LAUNCH(k_gather, dim3((unsigned)((n_desc + 7) / 8)), dim3(256), 0, st, desc_dev, n_desc, dst);
 }
 
 }  // namespace vk

@@ -105,13 +105,13 @@ void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint3
                        uint32_t* scratch) {
     uint64_t n = main.height;
     { ProfScope ps("k_perm_recip", st, 4.0 * n * (main.width + perm.width));
-    hipLaunchKernelGGL(k_perm_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, main, prep, iw_dev, chal_dev, perm); }
+    VK_LAUNCH(k_perm_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, main, prep, iw_dev, chal_dev, perm); }
     ProfScope ps("k_scan", st, 3.0 * 20.0 * n);
     uint32_t* phi = perm.data + (uint64_t)(5 * M) * perm.stride;
     uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb, 5), dim3(SCAN_THREADS), 0, st, phi, perm.stride, n, scratch, nb);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1, 5), dim3(SCAN_THREADS), 0, st, scratch, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb, 5), dim3(SCAN_THREADS), 0, st, phi, perm.stride, n, scratch, nb);
+    VK_LAUNCH(k_scan_block_sums, dim3((unsigned)nb, 5), dim3(SCAN_THREADS), 0, st, phi, perm.stride, n, scratch, nb);
+    VK_LAUNCH(k_scan_sums, dim3(1, 5), dim3(SCAN_THREADS), 0, st, scratch, nb);
+    VK_LAUNCH(k_scan_apply, dim3((unsigned)nb, 5), dim3(SCAN_THREADS), 0, st, phi, perm.stride, n, scratch, nb);
 }
 
 }  // namespace vk

@@ -159,16 +159,16 @@ static PoseidonTab tab_of(const uint32_t* pos_dev) { return PoseidonTab{pos_dev,
 
 void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     ProfScope ps("k_poseidon_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * p_row_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
-    hipLaunchKernelGGL(k_poseidon_leaves<PPtrCols>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, PPtrCols{cols_dev}, n_elems, n_rows, tab_of(pos_dev), digests);
+    VK_LAUNCH(k_poseidon_leaves<PPtrCols>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, PPtrCols{cols_dev}, n_elems, n_rows, tab_of(pos_dev), digests);
 }
 void launch_poseidon_leaves_strided(hipStream_t st, const uint32_t* pos_dev, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests) {
     ProfScope ps("k_poseidon_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * p_row_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
-    hipLaunchKernelGGL(k_poseidon_leaves<PStridedCols>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, PStridedCols{base, stride}, n_elems, n_rows,
+    VK_LAUNCH(k_poseidon_leaves<PStridedCols>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, PStridedCols{base, stride}, n_elems, n_rows,
                        tab_of(pos_dev), digests);
 }
 void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
     ProfScope ps("k_poseidon_compress", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * p_node_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
-    hipLaunchKernelGGL(k_poseidon_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, tab_of(pos_dev), next);
+    VK_LAUNCH(k_poseidon_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, tab_of(pos_dev), next);
 }
 void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, const KeccakTopArgs& a) {
     double bytes = 0, perms = 0;
@@ -177,7 +177,7 @@ void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, const KeccakTo
         perms += (double)(a.first_len >> l) * p_node_perms(a.n_elems[l]);
     }
     ProfScope ps("k_poseidon_top", st, bytes, perms * POSEIDON_VALU_PER_PERM / 64.0);
-    hipLaunchKernelGGL(k_poseidon_top, dim3(1), dim3(1024), 0, st, a, tab_of(pos_dev));
+    VK_LAUNCH(k_poseidon_top, dim3(1), dim3(1024), 0, st, a, tab_of(pos_dev));
 }
 
 }  // namespace vk

@@ -299,18 +299,18 @@ void launch_check_constraints(hipStream_t st, const QuotientArgs& a, unsigned lo
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     ProfScope ps("k_check_constraints", st, 4.0 * n * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width));
     switch (a.native_chip) {
-#define VG_CHECK(C) case vchips::C: hipLaunchKernelGGL((k_check_constraints<vchips::C>), grid, block, 0, st, a, first_bad_dev); break;
+#define VG_CHECK(C) case vchips::C: VK_LAUNCH((k_check_constraints<vchips::C>), grid, block, 0, st, a, first_bad_dev); break;
         VG_CHECK(CHIP_CPU) VG_CHECK(CHIP_ADD) VG_CHECK(CHIP_SUB) VG_CHECK(CHIP_MUL) VG_CHECK(CHIP_SHIFT) VG_CHECK(CHIP_LT)
         VG_CHECK(CHIP_COM) VG_CHECK(CHIP_BITWISE) VG_CHECK(CHIP_OUTPUT) VG_CHECK(CHIP_STATIC_DATA)
 #undef VG_CHECK
         case QuotientArgs::INTERPRET: {
             unsigned threads = 256;
             while (threads > 64 && (size_t)a.n_regs * threads * 4 > 64 * 1024) threads >>= 1;
-            hipLaunchKernelGGL((k_check_constraints<QuotientArgs::INTERPRET>), dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), (size_t)a.n_regs * threads * 4, st, a,
+            VK_LAUNCH((k_check_constraints<QuotientArgs::INTERPRET>), dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), (size_t)a.n_regs * threads * 4, st, a,
                                first_bad_dev);
             break;
         }
-        default: hipLaunchKernelGGL((k_check_constraints<-1>), grid, block, 0, st, a, first_bad_dev); break;
+        default: VK_LAUNCH((k_check_constraints<-1>), grid, block, 0, st, a, first_bad_dev); break;
     }
 }
 
@@ -327,25 +327,25 @@ void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& 
         // the BasicMachine chips: eval compiled ahead of time, one kernel per chip with constraints
         const dim3 grid((unsigned)((n + 255) / 256)), block(256);
         switch (a.native_chip) {
-#define VG_NATIVE(C) case vchips::C: hipLaunchKernelGGL((k_quotient<3, vchips::C>), grid, block, 0, st, a, tb); break;
+#define VG_NATIVE(C) case vchips::C: VK_LAUNCH((k_quotient<3, vchips::C>), grid, block, 0, st, a, tb); break;
             VG_NATIVE(CHIP_CPU) VG_NATIVE(CHIP_ADD) VG_NATIVE(CHIP_SUB) VG_NATIVE(CHIP_MUL) VG_NATIVE(CHIP_SHIFT) VG_NATIVE(CHIP_LT)
             VG_NATIVE(CHIP_COM) VG_NATIVE(CHIP_BITWISE) VG_NATIVE(CHIP_OUTPUT) VG_NATIVE(CHIP_STATIC_DATA)
 #undef VG_NATIVE
-            default: hipLaunchKernelGGL((k_quotient<3, -1>), grid, block, 0, st, a, tb); break;
+            default: VK_LAUNCH((k_quotient<3, -1>), grid, block, 0, st, a, tb); break;
         }
         return;
     }
     if (a.n_regs <= 64) {
         const unsigned threads = 256;
         dim3 grid((unsigned)((n + threads - 1) / threads));
-        if (a.n_regs <= 32) hipLaunchKernelGGL(k_quotient<1>, grid, dim3(threads), 0, st, a, tb);
-        else hipLaunchKernelGGL(k_quotient<2>, grid, dim3(threads), 0, st, a, tb);
+        if (a.n_regs <= 32) VK_LAUNCH(k_quotient<1>, grid, dim3(threads), 0, st, a, tb);
+        else VK_LAUNCH(k_quotient<2>, grid, dim3(threads), 0, st, a, tb);
         return;
     }
     unsigned threads = 256;
     while (threads > 64 && (size_t)a.n_regs * threads * 4 > 64 * 1024) threads >>= 1;
     size_t lds = (size_t)a.n_regs * threads * 4;
-    hipLaunchKernelGGL(k_quotient<0>, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), lds, st, a, tb);
+    VK_LAUNCH(k_quotient<0>, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), lds, st, a, tb);
 }
 
 }  // namespace vk

@@ -253,7 +253,7 @@ static unsigned blocks_for(uint64_t rows) { return (unsigned)((rows + 255) / 256
 
 void launch_tracegen_cpu(hipStream_t st, const TgCpuOp* ops, uint64_t n, const TgMemOp* mem, uint64_t n_mem, DMatView t) {
     ProfScope ps("k_tracegen_cpu", st, 48.0 * n + 16.0 * n_mem + 4.0 * t.height * t.width);
-    hipLaunchKernelGGL(k_tracegen_cpu, dim3(blocks_for(t.height)), dim3(256), 0, st, ops, n, mem, n_mem, t);
+    VK_LAUNCH(k_tracegen_cpu, dim3(blocks_for(t.height)), dim3(256), 0, st, ops, n, mem, n_mem, t);
 }
 
 // ---- stable LSD radix sort of (address, index) pairs: 4 passes x 8 bits ----------------------------------------------
@@ -340,9 +340,9 @@ static void radix_sort_pairs(hipStream_t st, uint32_t* keys2, uint32_t* vals2, u
         uint32_t* vin = vals2 + (pass & 1) * n;
         uint32_t* kout = keys2 + ((pass + 1) & 1) * n;
         uint32_t* vout = vals2 + ((pass + 1) & 1) * n;
-        hipLaunchKernelGGL(k_rs_count, dim3(n_blocks), dim3(256), 0, st, (const uint32_t*)kin, n, 8 * pass, counts, n_blocks);
-        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, counts, (uint64_t)256 * n_blocks);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(n_blocks), dim3(256), 0, st, (const uint32_t*)kin, (const uint32_t*)vin, n, 8 * pass, (const uint32_t*)counts, n_blocks, kout, vout);
+        VK_LAUNCH(k_rs_count, dim3(n_blocks), dim3(256), 0, st, (const uint32_t*)kin, n, 8 * pass, counts, n_blocks);
+        VK_LAUNCH(k_rs_scan, dim3(1), dim3(1024), 0, st, counts, (uint64_t)256 * n_blocks);
+        VK_LAUNCH(k_rs_scatter, dim3(n_blocks), dim3(256), 0, st, (const uint32_t*)kin, (const uint32_t*)vin, n, 8 * pass, (const uint32_t*)counts, n_blocks, kout, vout);
     }
 }
 
@@ -352,11 +352,11 @@ hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, c
     if (n) {
         ProfScope ps("k_tracegen_mem_sort", st, 16.0 * n + 4.0 * 8.0 * 2.0 * n);
         if (sort_tmp_bytes < tracegen_mem_sort_scratch_bytes(n)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_tg_mem_keys, dim3(blocks_for(n)), dim3(256), 0, st, mem, n, keys2, idx2);
+        VK_LAUNCH(k_tg_mem_keys, dim3(blocks_for(n)), dim3(256), 0, st, mem, n, keys2, idx2);
         radix_sort_pairs(st, keys2, idx2, n, (uint32_t*)sort_tmp);
     }
     ProfScope ps("k_tracegen_mem", st, 20.0 * n + 4.0 * t.height * t.width);
-    hipLaunchKernelGGL(k_tracegen_mem, dim3(blocks_for(t.height)), dim3(256), 0, st, mem, (const uint32_t*)idx2, n, static_cells, n_static, t);
+    VK_LAUNCH(k_tracegen_mem, dim3(blocks_for(t.height)), dim3(256), 0, st, mem, (const uint32_t*)idx2, n, static_cells, n_static, t);
     return hipSuccess;
 }
 
@@ -365,33 +365,33 @@ hipError_t launch_tracegen_range(hipStream_t st, const TgAluOp* add_ops, uint64_
     hipError_t e = hipMemsetAsync(counts, 0, 256 * 4, st);
     if (e != hipSuccess) return e;
     ProfScope ps("k_tracegen_tables", st, 16.0 * (n_add + n_sub) + 8.0 * t.height);
-    if (n_add) hipLaunchKernelGGL(k_tg_byte_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n_add + 255) / 256)), dim3(256), 0, st, add_ops, n_add, counts);
-    if (n_sub) hipLaunchKernelGGL(k_tg_byte_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n_sub + 255) / 256)), dim3(256), 0, st, sub_ops, n_sub, counts);
-    hipLaunchKernelGGL(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)256, 1, t);
+    if (n_add) VK_LAUNCH(k_tg_byte_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n_add + 255) / 256)), dim3(256), 0, st, add_ops, n_add, counts);
+    if (n_sub) VK_LAUNCH(k_tg_byte_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n_sub + 255) / 256)), dim3(256), 0, st, sub_ops, n_sub, counts);
+    VK_LAUNCH(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)256, 1, t);
     return hipSuccess;
 }
 hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t n, uint64_t padded_n, uint32_t rom_len, uint32_t* counts, DMatView t) {
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)rom_len * 4, st);
     if (e != hipSuccess) return e;
     ProfScope ps("k_tracegen_tables", st, 48.0 * n + 4.0 * t.height);
-    hipLaunchKernelGGL(k_tg_pc_histogram, dim3((unsigned)((n + 256 * PC_ITEMS - 1) / (256 * PC_ITEMS))), dim3(256), 0, st, ops, n, padded_n, rom_len, counts);
-    hipLaunchKernelGGL(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)rom_len, 0, t);
+    VK_LAUNCH(k_tg_pc_histogram, dim3((unsigned)((n + 256 * PC_ITEMS - 1) / (256 * PC_ITEMS))), dim3(256), 0, st, ops, n, padded_n, rom_len, counts);
+    VK_LAUNCH(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)rom_len, 0, t);
     return hipSuccess;
 }
 
 void launch_tracegen_idle(hipStream_t st, int mode, const uint32_t* static_cells, uint64_t n_static, DMatView t) {
     ProfScope ps("k_tracegen_tables", st, 4.0 * t.height * t.width);
-    hipLaunchKernelGGL(k_tracegen_idle, dim3(blocks_for(t.height)), dim3(256), 0, st, mode, static_cells, n_static, t);
+    VK_LAUNCH(k_tracegen_idle, dim3(blocks_for(t.height)), dim3(256), 0, st, mode, static_cells, n_static, t);
 }
 
 void launch_tracegen_alu(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t) {
     ProfScope ps("k_tracegen_alu", st, 16.0 * n + 4.0 * t.height * t.width);
     const dim3 g(blocks_for(t.height)), b(256);
     switch (chip) {
-        case CHIP_ADD: hipLaunchKernelGGL(k_tracegen_alu<CHIP_ADD>, g, b, 0, st, ops, n, t); break;
-        case CHIP_SUB: hipLaunchKernelGGL(k_tracegen_alu<CHIP_SUB>, g, b, 0, st, ops, n, t); break;
-        case CHIP_LT: hipLaunchKernelGGL(k_tracegen_alu<CHIP_LT>, g, b, 0, st, ops, n, t); break;
-        default: hipLaunchKernelGGL(k_tracegen_alu<CHIP_BITWISE>, g, b, 0, st, ops, n, t); break;
+        case CHIP_ADD: VK_LAUNCH(k_tracegen_alu<CHIP_ADD>, g, b, 0, st, ops, n, t); break;
+        case CHIP_SUB: VK_LAUNCH(k_tracegen_alu<CHIP_SUB>, g, b, 0, st, ops, n, t); break;
+        case CHIP_LT: VK_LAUNCH(k_tracegen_alu<CHIP_LT>, g, b, 0, st, ops, n, t); break;
+        default: VK_LAUNCH(k_tracegen_alu<CHIP_BITWISE>, g, b, 0, st, ops, n, t); break;
     }
 }
 
