@@ -135,6 +135,9 @@ uint64_t vgpu_prover_trim(vgpu_prover_t* p);
 /* per-kernel HIP-event timing (bench): switch on/off (resets the accumulators); the profile is text,
  * one line per kernel: "name launches total_ms total_algorithmic_bytes".  Returns the size needed. */
 void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on);
+/* restrict the timing to launches of ONE kernel name (NULL or "" = all): every timed launch carries a pair of events, which costs
+ * the host and the command processor a little; a throughput measurement times only the kernel it reports a roofline for */
+void vgpu_prover_set_profiling_filter(vgpu_prover_t* p, const char* kernel_name);
 int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap);
 
 /* H2D of a host RowMajorMatrix (the reference passes these by value, basic/src/lib.rs:223) */

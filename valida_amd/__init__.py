@@ -677,7 +677,9 @@ class Prover:
         _check(lib().vgpu_prove_async(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)), ctypes.byref(h)))
         return Ticket(h, (main, preprocessed, self, keep))
 
-    def set_profiling(self, on):
+    def set_profiling(self, on, only=None):
+        """Per-kernel HIP-event timing on / off (resets the accumulators); only = time launches of this kernel name alone."""
+        lib().vgpu_prover_set_profiling_filter(self._h, only.encode() if only else None)
         lib().vgpu_prover_set_profiling(self._h, ctypes.c_uint32(1 if on else 0))
 
     def profile(self):

@@ -15,6 +15,7 @@ struct KernelStat { uint64_t launches = 0; double ms = 0; double bytes = 0; doub
 
 struct Profiler {
     bool enabled = false;
+    std::string only;  // when not empty: only launches of this kernel name carry events (the bench's timed region times its dominant kernel alone)
     struct Rec { const char* name; hipEvent_t start, stop; double bytes, valu_ops; bool counts_as_launch; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -62,7 +63,7 @@ struct ProfScope {
     // valu_ops: algorithmic wave64 VALU instructions of the launch, for the kernels whose roofline is the integer
     // issue rate rather than HBM (the Keccak kernels); 0 = not modelled
     ProfScope(const char* name_, hipStream_t, double bytes_, double valu_ops_ = 0) : p(g_profiler), outer(g_scope), name(name_), bytes(bytes_), valu_ops(valu_ops_) {
-        if (!p || !p->enabled) p = nullptr;
+        if (!p || !p->enabled || (!p->only.empty() && p->only != name_)) p = nullptr;
         g_scope = this;
     }
     ~ProfScope() { g_scope = outer; }
