@@ -14,6 +14,7 @@
 #include <cstring>
 #include <vector>
 #include "kernels/keccak.hpp"  // -I valida_amd/csrc: the product's Keccak-f[1600]
+#include "field.hpp"           // and its Montgomery arithmetic
 
 #define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(_e)); exit(2); } } while (0)
 
@@ -96,15 +97,8 @@ __global__ void __launch_bounds__(256) k_mix_mad64_add(uint32_t* out, uint32_t s
 
 // Compiled composites (instruction mix counted from the disassembly by tools/microbench.py):
 // a Montgomery product chain (field.hpp's monty_reduce) and one Keccak-style round slice (xor3 / alignbit / chi).
-__device__ __forceinline__ uint32_t monty_mul(uint32_t a, uint32_t b) {
-    const uint32_t P = 0x78000001u;
-    uint64_t t = (uint64_t)a * b;
-    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
-    uint32_t m = lo * 0x88000001u;
-    uint32_t u = __umulhi(m, P);
-    uint32_t r = hi - u, r2 = r + P;
-    return r < r2 ? r : r2;
-}
+// the product's own Montgomery product (field.hpp)
+__device__ __forceinline__ uint32_t monty_mul(uint32_t a, uint32_t b) { return vg::monty_reduce((uint64_t)a * b); }
 __global__ void __launch_bounds__(256) k_montgomery_mul(uint32_t* out, uint32_t seed, int iters) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t r[8], b = (seed | 1u) % 0x78000001u;
@@ -286,7 +280,7 @@ int main(int argc, char** argv) {
         rate_row("v_mul_hi_u32", k_v_mul_hi_u32, UNROLL, cu, d, clock_hz);
         rate_row("v_mad_u64_u32", k_v_mad_u64_u32, UNROLL, cu, d, clock_hz);
         rate_row("mad_u64 + add_u32 mix", k_mix_mad64_add, UNROLL, cu, d, clock_hz);
-        // composite: 64 Montgomery products per iteration; per-product instruction mix from the disassembly (microbench.py)
+        // composite: 64 Montgomery products (field.hpp) per iteration; per-product instruction mix from the disassembly (microbench.py)
         rate_row("montgomery_mul (x1)", k_montgomery_mul, 64, cu, d, clock_hz);
         printf("Keccak-f[1600] of kernels/keccak.hpp, chained permutations in registers, at 1..5 waves per SIMD (SIMD-cycles per wave-round =\n"
                "what one 178-instruction round costs the SIMD; 122 full-rate + 56 half-rate instructions would cost ~530 at the rates above)\n");
