@@ -15,7 +15,7 @@ NUM_CHIPS = 14
 CHIP_NAMES = ["cpu", "program", "mem", "add", "sub", "mul", "div", "shift", "lt", "com", "bitwise", "output", "range", "static_data"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libvgpu.so")
+_LIB_PATH = os.environ.get("VGPU_LIB_PATH") or os.path.join(_HERE, "libvgpu.so")  # the override serves A/B runs of two builds in one session
 
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
 c_u64p = ctypes.POINTER(ctypes.c_uint64)

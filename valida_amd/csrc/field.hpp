@@ -34,24 +34,30 @@ VG_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
 }
 
 // Montgomery reduction of a 64-bit value t < p * 2^32: returns t / 2^32 mod p, in [0, p).
-// m = t_lo * (-p^-1) mod 2^32 makes t + m p divisible by 2^32; the sum stays below 2 p 2^32 < 2^64, so ONE 64-bit multiply-add
-// (v_mad_u64_u32) yields the quotient in its high word, in [0, 2p): 4 instructions after the product (mul_lo, mad_u64, sub, min)
-// instead of the 5 of the subtractive form (mul_lo, mul_hi, sub, add, min) — 15.0 instead of 17.1 SIMD-cycles on gfx950
-// (profiles/r02_microbench.txt: every multiply is half-rate).
+// Subtractive form: mul_lo, mul_hi, sub, add, min after the product.  The additive form (m = t_lo * (-p^-1); (t + m p) >> 32 through ONE
+// v_mad_u64_u32; conditional subtraction) is one instruction shorter and made the NTT / quotient kernels of a lone proof 10-20 %
+// faster, but with three proofs in flight — the GPU full — the bench LOST 4.5 % (48.7 vs 51.0 proofs/s, A/B in one session,
+// gpurun_out/ab1): twice as many 64-bit multiply-adds per product, and the chip gives the cycles back as clock.  Measured, reverted.
 VG_HD uint32_t monty_reduce(uint64_t t) {
-    uint32_t m = (uint32_t)t * P_INV_NEG;
-    uint32_t hi = (uint32_t)((t + (uint64_t)m * P) >> 32);  // < 2p
-    uint32_t h2 = hi - P;                                    // wraps to a huge value when hi < p: min picks the reduced one
-    return hi < h2 ? hi : h2;
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo * 0x88000001u;         // lo * p^{-1} mod 2^32
+    uint32_t u = mul_hi_u32(m, P);         // (m * p) >> 32 ; low word of m*p equals lo
+    uint32_t r = hi - u;  // in (-p, p): the wrapped value is huge when negative, so min picks the corrected one
+    uint32_t r2 = r + P;
+    return r < r2 ? r : r2;
 }
 
 // Montgomery reduction of a lazily accumulated sum of up to FOUR products of values < p
 // (t < 4 p^2 < 2^64, high word < 2p): one conditional subtraction of p * 2^32 first, then as above.
+// 7 VALU instructions for 4 multiply-adds that each cost one v_mad_u64_u32.
 VG_HD uint32_t monty_reduce_wide(uint64_t t) {
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t h2 = hi - P;
     hi = hi < h2 ? hi : h2;
-    return monty_reduce(((uint64_t)hi << 32) | lo);
+    uint32_t m = lo * 0x88000001u;
+    uint32_t u = mul_hi_u32(m, P);
+    uint32_t r = hi - u, r2 = r + P;
+    return r < r2 ? r : r2;
 }
 
 struct Fp {
