@@ -37,7 +37,8 @@ VG_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
 // Subtractive form: mul_lo, mul_hi, sub, add, min after the product.  The additive form (m = t_lo * (-p^-1); (t + m p) >> 32 through ONE
 // v_mad_u64_u32; conditional subtraction) is one instruction shorter and made the NTT / quotient kernels of a lone proof 10-20 %
 // faster, but with three proofs in flight — the GPU full — the bench LOST 4.5 % (48.7 vs 51.0 proofs/s, A/B in one session,
-// gpurun_out/ab1): twice as many 64-bit multiply-adds per product, and the chip gives the cycles back as clock.  Measured, reverted.
+// tools/gpu_ab.sh): twice as many 64-bit multiply-adds per product; not a power effect (2.31 GHz, 1.13 of 1.4 kW under the full bench); cause
+// not established.  Measured, reverted.
 VG_HD uint32_t monty_reduce(uint64_t t) {
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t m = lo * 0x88000001u;         // lo * p^{-1} mod 2^32
