@@ -172,6 +172,9 @@ def main():
     # Pin the measured configuration before the HIP runtime starts: 3 prover contexts x (main + 1 aux stream) over FOUR hardware
     # queues (the runtime's default; other counts measured worse, DESIGN.md "Measurement").
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+    # a lone rank has host cores to spare: its proof threads poll for the GPU instead of parking (libvgpu: VGPU_SPIN_WAIT); with one
+    # rank per GPU the node's ranks share the cores and park
+    os.environ.setdefault("VGPU_SPIN_WAIT", "1" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "0")
     import torch
     import valida_amd as va
 

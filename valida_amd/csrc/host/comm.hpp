@@ -27,10 +27,17 @@ struct RcclApi {
     }
     static RcclApi load() {
         RcclApi a;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // a copy the process already loaded (a host that also uses RCCL through another runtime — bench.py's torch — must not end up
+        // with two RCCL instances) before a fresh one
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (a.lib) break;
         }
+        if (!a.lib)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (a.lib) break;
+            }
         if (!a.lib) throw std::runtime_error(std::string("hip: cannot load librccl.so: ") + dlerror());
         auto sym = [&](const char* n) { void* p = dlsym(a.lib, n); if (!p) throw std::runtime_error(std::string("hip: librccl.so lacks ") + n); return p; };
         a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");

@@ -4,6 +4,7 @@
 #pragma once
 #include <new>
 #include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <map>
@@ -170,11 +171,18 @@ struct DeviceCtx {
         }
         return pinned;
     }
-    // Wait for the main stream by POLLING an event: hipStreamSynchronize parks the thread and its wake-up costs 50-150 us — with a
-    // dozen true synchronisation points per proof (roots, opened values, final values) that was >1 ms of an idle GPU per proof.
-    // A proof's host thread has nothing else to do while it waits, and there are more host cores than proofs in flight.
+    // Waiting for the main stream.  hipStreamSynchronize parks the thread, and its wake-up costs 50-150 us — with a dozen true
+    // synchronisation points per proof (roots, opened values, final values) that is ~1 ms of an idle GPU per LONE proof.  POLLING an
+    // event avoids it but burns a core per waiting proof thread, which is only right when cores are plentiful: VGPU_SPIN_WAIT=1
+    // selects it (bench.py does for a single rank; with one rank per GPU and three proof threads each, a node's ranks would fight
+    // over the host cores), the default parks.
     hipEvent_t sync_ev = nullptr;
+    static bool spin_wait() {
+        static const bool on = [] { const char* e = getenv("VGPU_SPIN_WAIT"); return e && e[0] == '1'; }();
+        return on;
+    }
     void sync() {
+        if (!spin_wait()) { VG_HIP_CHECK(hipStreamSynchronize(stream)); return; }
         if (!sync_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&sync_ev, hipEventDisableTiming));
         VG_HIP_CHECK(hipEventRecord(sync_ev, stream));
         for (;;) {
