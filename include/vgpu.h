@@ -117,6 +117,8 @@ void vgpu_challenger_sample(vgpu_challenger_t* ch, uint32_t* out, uint64_t n);  
 uint64_t vgpu_challenger_sample_bits(vgpu_challenger_t* ch, uint32_t bits);
 uint32_t vgpu_challenger_grind(vgpu_challenger_t* ch, uint32_t bits);                             /* smallest witness */
 void vgpu_poseidon16_permute(const uint32_t poseidon_rc[480], uint32_t state[16]);
+/* the same permutation through the sparse-matrix form of the 22 partial rounds that the Poseidon-MMCS kernels use (test hook) */
+int32_t vgpu_poseidon16_permute_sparse(const uint32_t poseidon_rc[480], uint32_t state[16]);
 
 /* ---- Prover (one per device) ---- */
 typedef struct vgpu_prover vgpu_prover_t;

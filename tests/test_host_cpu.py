@@ -316,3 +316,18 @@ def test_host_verify_multi_batches_accepts_oracle_openings_and_rejects_tampering
     bad_roots[1, 3] = (int(bad_roots[1, 3]) + 1) % P
     assert verify(values, proof, bad_roots) is not None
     assert verify(values, proof[:-1]) is not None and verify(values[:-5], proof) is not None
+
+
+def test_sparse_partial_round_poseidon_is_the_same_permutation():
+    """The Poseidon-MMCS kernels run the 22 partial rounds in sparse-matrix form (host/poseidon_opt.hpp); its host twin, built from
+    the same tables, against the oracle's plain permutation — for the default and two other sets of round constants."""
+    L = va.lib()
+    rng = np.random.default_rng(8)
+    for seed in (None, 17, 99):
+        r = va.poseidon_round_constants() if seed is None else va.poseidon_round_constants(seed)
+        rp = np.ascontiguousarray(r, dtype=np.uint32)
+        for _ in range(12):
+            st = rng.integers(0, va.P, 16, dtype=np.uint32)
+            got = st.copy()
+            assert L.vgpu_poseidon16_permute_sparse(rp.ctypes.data_as(va.c_u32p), got.ctypes.data_as(va.c_u32p)) == 0
+            assert np.array_equal(got, po.poseidon_permute(r, st))

@@ -9,6 +9,7 @@
 #include "host/comm.hpp"
 #include "host/sharded.hpp"
 #include "host/verifier.hpp"
+#include "host/poseidon_opt.hpp"
 #include "host/prover.hpp"
 #include "workload/basic_vm.hpp"
 
@@ -249,6 +250,19 @@ void vgpu_poseidon16_permute(const uint32_t rc[480], uint32_t state[16]) {
     for (int i = 0; i < 16; i++) st[i] = Fp::from_canonical(state[i]);
     p.permute(st);
     for (int i = 0; i < 16; i++) state[i] = st[i].canonical();
+}
+
+// test hook: the SPARSE-partial-round schedule the Poseidon MMCS kernels run (host twin, same tables); returns 0 when the tables
+// are valid and the permutation was applied, -4 when a block was singular (the kernels then use the plain rounds)
+int32_t vgpu_poseidon16_permute_sparse(const uint32_t rc[480], uint32_t state[16]) {
+    Poseidon16 p(rc);
+    PoseidonOptTables t(p);
+    if (!t.valid) return VGPU_ERR_UNSUPPORTED;
+    Fp st[16];
+    for (int i = 0; i < 16; i++) st[i] = Fp::from_canonical(state[i]);
+    t.permute(p, st);
+    for (int i = 0; i < 16; i++) state[i] = st[i].canonical();
+    return VGPU_OK;
 }
 
 // ---- prover

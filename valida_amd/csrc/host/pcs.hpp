@@ -83,8 +83,8 @@ struct DeviceTree {
         const bool pos = c->hash_kind == 1;
         const uint32_t* tab = c->poseidon_tab;
         if (pos) {
-            if (single) vk::launch_poseidon_leaves_strided(c->stream, tab, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
-            else vk::launch_poseidon_leaves(c->stream, tab, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
+            if (single) vk::launch_poseidon_leaves_strided(c->stream, tab, c->poseidon_sparse, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
+            else vk::launch_poseidon_leaves(c->stream, tab, c->poseidon_sparse, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         } else if (single) vk::launch_keccak_leaves_strided(c->stream, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
         else vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
@@ -97,7 +97,7 @@ struct DeviceTree {
             // single-workgroup launch.  256, not the 1024 a workgroup could take: inside one workgroup a 1024-parent layer puts four
             // waves on each SIMD of ONE CU and costs 27 us (512 parents: 15 us), as a launch of its own across the CUs 9 + 2 us.
             if (len > TOP_FIRST_LEN) {
-                if (pos) vk::launch_poseidon_compress(c->stream, tab, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
+                if (pos) vk::launch_poseidon_compress(c->stream, tab, c->poseidon_sparse, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
                 else vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
                                                 layers.back().data);
             } else {  // the last <= 9 layers go into one launch
@@ -110,7 +110,7 @@ struct DeviceTree {
             if (inj) gi++;
             if (len == 1) break;
         }
-        if (top.levels) { if (pos) vk::launch_poseidon_top(c->stream, tab, top); else vk::launch_keccak_top(c->stream, top); }
+        if (top.levels) { if (pos) vk::launch_poseidon_top(c->stream, tab, c->poseidon_sparse, top); else vk::launch_keccak_top(c->stream, top); }
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
         c->check_launch("mmcs build");
         if (fetch_root) c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished

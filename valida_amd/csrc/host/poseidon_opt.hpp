@@ -1,0 +1,127 @@
+// Poseidon-16's 22 partial rounds in their sparse-matrix form (the standard optimisation of the Poseidon paper, Appendix B, derived
+// here for the reference's instance: Poseidon<BabyBear, CosetMds<16>, 16, 5>, 4 + 22 + 4 rounds, basic/tests/test_prover.rs:418-422).
+// A partial round is x <- M S0(x + c) with S0 the S-box on coordinate 0 only.  Anything that fixes coordinate 0 commutes with S0:
+//   * the constants of coordinates 1..15 (a vector tau with tau[0] = 0) pass through S0 and are carried to the next round
+//     (tau' = M tau + c' with its coordinate 0 split off as the scalar t' that round adds to coordinate 0);
+//   * a matrix T = diag(1, T^) passes through S0, so with D = M T = [[d00, dv],[dw, D^]] = diag(1, D^) . [[d00, dv],[D^-1 dw, I]]
+//     the dense part diag(1, D^) moves on to the next round and the round itself multiplies by the SPARSE matrix
+//     S = [[a, u^T],[w, I]] (a = d00, u = dv, w = D^-1 dw): 31 products instead of 256.
+// The recursion runs forward and leaves one dense matrix F = M T_21 and one vector f = M tau_21 for the LAST partial round; f is
+// merged into the constants of the full round that follows.  Identical outputs by construction; the constructor checks it on
+// random states against the plain permutation and the kernels fall back to the plain form if a block D^ is singular.
+#pragma once
+#include <vector>
+#include "challenger.hpp"
+
+namespace vhost {
+
+struct PoseidonOptTables {
+    // device image (Montgomery words), offsets in words
+    static constexpr int RC_FULL = 0;                 // [8][16]: rounds 0..3, then 26..29 (26's with f merged)
+    static constexpr int T_SCALARS = RC_FULL + 128;   // [22 (+2 pad)]: t_0 .. t_21
+    static constexpr int SPARSE = T_SCALARS + 24;     // [21][32]: a, u[1..15], w[1..15], pad
+    static constexpr int F_DENSE = SPARSE + 21 * 32;  // [16][16] row-major
+    static constexpr int WORDS = F_DENSE + 256;
+    std::vector<uint32_t> words;
+    bool valid = false;
+
+    static bool invert(std::vector<std::vector<Fp>>& a, std::vector<std::vector<Fp>>& inv) {
+        const size_t n = a.size();
+        inv.assign(n, std::vector<Fp>(n, Fp::zero()));
+        for (size_t i = 0; i < n; i++) inv[i][i] = Fp::one();
+        for (size_t col = 0; col < n; col++) {
+            size_t piv = col;
+            while (piv < n && a[piv][col].is_zero()) piv++;
+            if (piv == n) return false;
+            std::swap(a[piv], a[col]); std::swap(inv[piv], inv[col]);
+            const Fp s = a[col][col].inv();
+            for (size_t j = 0; j < n; j++) { a[col][j] *= s; inv[col][j] *= s; }
+            for (size_t r = 0; r < n; r++) {
+                if (r == col || a[r][col].is_zero()) continue;
+                const Fp f = a[r][col];
+                for (size_t j = 0; j < n; j++) { a[r][j] -= f * a[col][j]; inv[r][j] -= f * inv[col][j]; }
+            }
+        }
+        return true;
+    }
+
+    explicit PoseidonOptTables(const Poseidon16& p) : words(WORDS, 0) {
+        // the MDS as a matrix: column j = image of the unit vector e_j
+        Fp M[16][16];
+        for (int j = 0; j < 16; j++) {
+            Fp e[16];
+            for (auto& x : e) x = Fp::zero();
+            e[j] = Fp::one();
+            p.mds(e);
+            for (int i = 0; i < 16; i++) M[i][j] = e[i];
+        }
+        auto mat_vec = [&](const Fp (&A)[16][16], const Fp* v, Fp* out) {
+            for (int i = 0; i < 16; i++) { Fp acc = Fp::zero(); for (int j = 0; j < 16; j++) acc += A[i][j] * v[j]; out[i] = acc; }
+        };
+        for (int r = 0; r < 4; r++) for (int i = 0; i < 16; i++) words[RC_FULL + 16 * r + i] = p.rc[r][i].v;
+        Fp T[16][16];  // T_i = diag(1, T^)
+        for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) T[i][j] = i == j ? Fp::one() : Fp::zero();
+        Fp tau[16];
+        for (int i = 0; i < 16; i++) tau[i] = i ? p.rc[4][i] : Fp::zero();
+        words[T_SCALARS] = p.rc[4][0].v;  // t_0
+        for (int i = 0; i < 22; i++) {    // partial round i = global round 4 + i
+            Fp D[16][16];
+            for (int a = 0; a < 16; a++) for (int b = 0; b < 16; b++) { Fp acc = Fp::zero(); for (int k = 0; k < 16; k++) acc += M[a][k] * T[k][b]; D[a][b] = acc; }
+            Fp mt[16];
+            mat_vec(M, tau, mt);
+            if (i == 21) {  // last partial round: dense F = M T_21, f = M tau_21 merged into round 26's constants
+                for (int a = 0; a < 16; a++) for (int b = 0; b < 16; b++) words[F_DENSE + 16 * a + b] = D[a][b].v;
+                for (int a = 0; a < 16; a++) words[RC_FULL + 16 * 4 + a] = (p.rc[26][a] + mt[a]).v;
+                for (int r = 27; r < 30; r++) for (int a = 0; a < 16; a++) words[RC_FULL + 16 * (r - 22) + a] = p.rc[r][a].v;
+                break;
+            }
+            std::vector<std::vector<Fp>> Dh(15, std::vector<Fp>(15)), Dinv;
+            for (int a = 0; a < 15; a++) for (int b = 0; b < 15; b++) Dh[a][b] = D[a + 1][b + 1];
+            auto Dh_copy = Dh;
+            if (!invert(Dh_copy, Dinv)) return;  // valid stays false: plain rounds are used
+            uint32_t* s = &words[SPARSE + 32 * i];
+            s[0] = D[0][0].v;
+            for (int b = 1; b < 16; b++) s[b] = D[0][b].v;                                     // u
+            for (int a = 0; a < 15; a++) { Fp acc = Fp::zero(); for (int k = 0; k < 15; k++) acc += Dinv[a][k] * D[k + 1][0]; s[16 + a] = acc.v; }  // w = D^-1 dw
+            for (int a = 0; a < 16; a++) for (int b = 0; b < 16; b++) T[a][b] = (a == 0 || b == 0) ? (a == b ? Fp::one() : Fp::zero()) : Dh[a - 1][b - 1];
+            // constants of the next round: M tau + c_{i+1}; its coordinate 0 is that round's scalar, the rest is carried on
+            for (int a = 0; a < 16; a++) mt[a] += p.rc[5 + i][a];
+            words[T_SCALARS + i + 1] = mt[0].v;
+            tau[0] = Fp::zero();
+            for (int a = 1; a < 16; a++) tau[a] = mt[a];
+        }
+        valid = true;
+        // self-check against the plain permutation
+        uint64_t seed = 0x9E3779B97F4A7C15ull;
+        for (int trial = 0; trial < 8 && valid; trial++) {
+            Fp x[16], y[16];
+            for (int i = 0; i < 16; i++) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; x[i] = Fp::from_canonical((uint32_t)((seed >> 33) % vg::P)); y[i] = x[i]; }
+            p.permute(x);
+            permute(p, y);
+            for (int i = 0; i < 16; i++) valid = valid && x[i] == y[i];
+        }
+    }
+
+    // the optimised schedule on the host (what the kernels do), for the self-check and the C-ABI test hook
+    void permute(const Poseidon16& p, Fp* st) const {
+        auto W = [&](int off) { return Fp::raw(words[off]); };
+        auto sbox = [](Fp x) { Fp x2 = x * x; return x2 * x2 * x; };
+        for (int r = 0; r < 4; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); p.mds(st); }
+        st[0] += W(T_SCALARS);
+        for (int i = 0; i < 21; i++) {
+            const int s = SPARSE + 32 * i;
+            const Fp x0 = sbox(st[0]);
+            Fp n0 = W(s) * x0;
+            for (int b = 1; b < 16; b++) n0 += W(s + b) * st[b];
+            for (int a = 1; a < 16; a++) st[a] += W(s + 15 + a) * x0;
+            st[0] = n0 + W(T_SCALARS + i + 1);
+        }
+        st[0] = sbox(st[0]);
+        Fp out[16];
+        for (int a = 0; a < 16; a++) { Fp acc = Fp::zero(); for (int b = 0; b < 16; b++) acc += W(F_DENSE + 16 * a + b) * st[b]; out[a] = acc; }
+        for (int a = 0; a < 16; a++) st[a] = out[a];
+        for (int r = 4; r < 8; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); p.mds(st); }
+    }
+};
+
+}  // namespace vhost

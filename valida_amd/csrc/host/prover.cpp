@@ -1,6 +1,7 @@
 // Machine::prove on one MI355X (see prover.hpp).  Phase order and transcript follow
 // basic/src/lib.rs:147-675 / SURVEY.md Appendix C; PCS conventions SURVEY.md Appendix B.
 #include "prover.hpp"
+#include "poseidon_opt.hpp"
 
 namespace vhost {
 
@@ -21,7 +22,9 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
         iw_dev_.emplace_back(ctx_.get(), a.interaction_words);
     }
     // Poseidon tables for the device PoW search: round constants + circulant CosetMds coefficients
-    std::vector<uint32_t> pos(480 + 16 + 16 + 8, 0);
+    PoseidonOptTables popt(perm16_);  // sparse form of the partial rounds for the Poseidon MMCS kernels (word 1024 on)
+    std::vector<uint32_t> pos(1024 + PoseidonOptTables::WORDS, 0);
+    memcpy(pos.data() + 1024, popt.words.data(), popt.words.size() * 4);
     for (int i = 0; i < 480; i++) pos[i] = Fp::from_canonical(poseidon_rc480[i]).v;
     Fp w16 = vg::two_adic_generator(4), g = Fp::from_canonical(vg::GENERATOR);
     for (int d = 0; d < 16; d++) {
@@ -33,6 +36,7 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
     VG_HIP_CHECK(hipHostMalloc((void**)&cs_pinned_, CS_PINNED_WORDS * 4));
     ctx_->hash_kind = fri_.hash_kind;
     ctx_->poseidon_tab = pow_pos_.data;
+    ctx_->poseidon_sparse = popt.valid;
 }
 
 // challenger.grind(bits) with the search on the device; canonical rule = smallest witness.

@@ -39,6 +39,7 @@ struct DeviceCtx {
     // truncated permutation; poseidon_tab = [480 round constants][16 MDS coefficients] on the device (owned by the Prover)
     int hash_kind = 0;
     const uint32_t* poseidon_tab = nullptr;
+    bool poseidon_sparse = false;  // poseidon_tab + 1024 holds valid sparse-partial-round tables (host/poseidon_opt.hpp)
     // Auxiliary streams for fork/join sections: independent per-chip pipelines (tiny matrices are
     // latency-bound single-block launches) overlap with the big chips' kernels on the main stream.
     // One auxiliary stream.  The device exposes a handful of hardware queues (4 by default) that streams take in creation

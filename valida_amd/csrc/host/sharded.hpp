@@ -127,7 +127,7 @@ struct ShardRank {
             top.levels++;
         }
         if (top.levels > vk::KECCAK_TOP_MAX_LEVELS) throw std::invalid_argument("sharded commit: too many ranks");
-        if (c->hash_kind == 1) vk::launch_poseidon_top(c->stream, c->poseidon_tab, top); else vk::launch_keccak_top(c->stream, top);
+        if (c->hash_kind == 1) vk::launch_poseidon_top(c->stream, c->poseidon_tab, c->poseidon_sparse, top); else vk::launch_keccak_top(c->stream, top);
         c->check_launch("sharded top");
         c->download_small(root, layers.back().data, 32);
     }

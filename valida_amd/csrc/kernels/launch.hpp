@@ -49,10 +49,10 @@ struct KeccakTopArgs {
 void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a);
 // poseidon_mmcs.hip — the same tree with PaddingFreeSponge / TruncatedPermutation over Poseidon-16 (hash kind 1).
 // pos_dev: [480 round constants][16 circulant MDS coefficients], Montgomery (the table the device challenger uses)
-void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);
-void launch_poseidon_leaves_strided(hipStream_t st, const uint32_t* pos_dev, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests);
-void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next);
-void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, const KeccakTopArgs& a);
+void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);
+void launch_poseidon_leaves_strided(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests);
+void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next);
+void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, bool sparse, const KeccakTopArgs& a);
 // perm.hip
 uint64_t perm_scratch_words(uint64_t n);
 void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,
