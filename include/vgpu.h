@@ -88,7 +88,9 @@ int32_t vgpu_air_add_interaction(vgpu_air_t* air, const vgpu_interaction_t* it);
 /* ---- Machine: ordered chips (basic/src/lib.rs:151-166) ---- */
 typedef struct vgpu_machine vgpu_machine_t;
 int32_t vgpu_machine_new(vgpu_machine_t** out);
-int32_t vgpu_machine_push_air(vgpu_machine_t* m, const vgpu_air_t* air);  /* compiles the constraint program */
+/* compiles the constraint program.  log_quotient_degree 1 (every reference chip) .. 3 (constraint degree <= 9) is implemented;
+ * beyond that VGPU_ERR_UNSUPPORTED with a message naming the AIR and its degree */
+int32_t vgpu_machine_push_air(vgpu_machine_t* m, const vgpu_air_t* air);
 int32_t vgpu_machine_basic(vgpu_machine_t** out);                         /* the 14-chip BasicMachine from the in-tree chip definitions */
 /* the same 14 chips, but captured the way a foreign host captures them: each chip's eval runs against a builder that only
  * calls vgpu_air_* / vgpu_air_add_interaction, then vgpu_machine_push_air (no native kernels: the interpreted path) */

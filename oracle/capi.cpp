@@ -244,6 +244,29 @@ void* oracle_prove_basic(const uint32_t* const* main, const uint64_t* heights, c
     res->words = serialize_proof(p);
     return res;
 }
+// Any machine made of chips::ChipIndex / test-AIR ids without preprocessed traces (the general log_quotient_degree tests)
+void* oracle_prove_machine(const uint32_t* chip_ids, uint32_t n_chips, const uint32_t* const* main, const uint64_t* heights, const uint32_t* rc480,
+                           uint32_t log_blowup, uint32_t num_queries, uint32_t pow_bits, int debug_check) {
+    std::vector<int> ids(chip_ids, chip_ids + n_chips);
+    MachineDesc md = MachineDesc::of(ids);
+    MachineInput in;
+    for (uint32_t i = 0; i < n_chips; i++) in.main_traces.push_back(to_matrix(main[i], heights[i], md.chips[i].width));
+    auto* res = new ProveResult();
+    auto t0 = std::chrono::steady_clock::now();
+    MachineProof p = prove(md, in, make_cfg(rc480, log_blowup, num_queries, pow_bits), &res->dbg, debug_check != 0);
+    res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    res->words = serialize_proof(p);
+    return res;
+}
+int oracle_verify_machine(const uint32_t* chip_ids, uint32_t n_chips, const uint32_t* proof, uint64_t n_words, const uint32_t* rc480, uint32_t log_blowup,
+                          uint32_t num_queries, uint32_t pow_bits, char* msg, uint64_t msg_cap) {
+    MachineProof p;
+    const char* err = nullptr;
+    if (!deserialize_proof(proof, n_words, p)) err = "malformed proof";
+    if (!err) err = verify(MachineDesc::of(std::vector<int>(chip_ids, chip_ids + n_chips)), {}, p, make_cfg(rc480, log_blowup, num_queries, pow_bits));
+    if (err && msg && msg_cap) { strncpy(msg, err, msg_cap - 1); msg[msg_cap - 1] = 0; }
+    return err ? 1 : 0;
+}
 uint64_t oracle_result_len(void* r) { return ((ProveResult*)r)->words.size(); }
 const uint32_t* oracle_result_words(void* r) { return ((ProveResult*)r)->words.data(); }
 double oracle_result_seconds(void* r) { return ((ProveResult*)r)->seconds; }

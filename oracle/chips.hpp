@@ -476,6 +476,23 @@ template <class B> void eval_static_data(B& b) {
     a.when_transition().when(local.is_real * next.is_real).assert_eq(next.addr, local.addr + a.one + a.one + a.one + a.one);
 }
 
+// ---------------------------------------------------------------- test AIRs of higher degree (NOT in the reference)
+// The reference's chips all have constraint degree <= 3 (log_quotient_degree 1).  machine/src/quotient.rs and verify.rs handle any
+// log_quotient_degree, so the oracle carries two synthetic single-chip AIRs to exercise that generality:
+//   POW5 (chip id 100): columns (x, y);  y - x^5 = 0 (degree 5 -> lqd 2);  when_transition: x' - x - 1 = 0
+//   POW9 (chip id 101): columns (x, y);  y - x^9 = 0 (degree 9 -> lqd 3);  when_transition: x' - x - 1 = 0;  when_first_row: x - 3 = 0
+template <class B> void eval_pow(B& b, int degree, bool pin_first) {
+    using T = typename B::Expr;
+    Air<B> a(b);
+    const T x = b.main_local()[0], y = b.main_local()[1], xn = b.main_next()[0];
+    T p = x;
+    for (int k = 1; k < degree; k++) p = p * x;
+    a.assert_eq(y, p);
+    a.when_transition().assert_eq(xn, x + a.one);
+    if (pin_first) a.when_first_row().assert_eq(x, a.k(3));
+}
+constexpr int TEST_POW5 = 100, TEST_POW9 = 101;
+
 // ---------------------------------------------------------------- the machine (basic/src/lib.rs:151-166)
 enum ChipIndex { CPU = 0, PROGRAM, MEM, ADD, SUB, MUL, DIV, SHIFT, LT, COM, BITWISE, OUTPUT, RANGE, STATIC_DATA, NUM_CHIPS };
 struct ChipShape { const char* name; size_t width, preprocessed_width; };
@@ -495,6 +512,8 @@ inline ChipShape chip_shape(int chip) {
         case OUTPUT: return {"output", num_cols<OutputCols>(), 0};
         case RANGE: return {"range", num_cols<RangeCols>(), num_cols<RangePreprocessedCols>()};
         case STATIC_DATA: return {"static_data", num_cols<StaticDataCols>(), 0};
+        case TEST_POW5: return {"pow5", 2, 0};
+        case TEST_POW9: return {"pow9", 2, 0};
     }
     return {"?", 0, 0};
 }
@@ -512,6 +531,8 @@ template <class B> void eval(int chip, B& b) {
         case BITWISE: eval_bitwise(b); break;
         case OUTPUT: eval_output(b); break;
         case STATIC_DATA: eval_static_data(b); break;
+        case TEST_POW5: eval_pow(b, 5, false); break;
+        case TEST_POW9: eval_pow(b, 9, true); break;
         default: break;
     }
 }

@@ -306,6 +306,33 @@ def prove_basic(main_traces, prep_program, prep_range, rc, log_blowup=1, num_que
     return ProveResult(h)
 
 
+TEST_POW5, TEST_POW9 = 100, 101  # the oracle's synthetic higher-degree AIRs (chips.hpp)
+
+
+def prove_machine(chip_ids, main_traces, rc, log_blowup=1, num_queries=40, pow_bits=8, debug_check=False):
+    """Proof of a machine made of the given chip ids (no preprocessed traces): the general log_quotient_degree tests."""
+    ids = np.array(chip_ids, dtype=np.uint32)
+    keep = [np.ascontiguousarray(m, dtype=np.uint32) for m in main_traces]
+    ptrs = (c_u32p * len(keep))(*[k.ctypes.data_as(c_u32p) for k in keep])
+    hs = (ctypes.c_uint64 * len(keep))(*[k.shape[0] for k in keep])
+    r, rp = _u32(rc)
+    L = lib()
+    L.oracle_prove_machine.restype = ctypes.c_void_p
+    h = L.oracle_prove_machine(ids.ctypes.data_as(c_u32p), ctypes.c_uint32(ids.size), ptrs, hs, rp, ctypes.c_uint32(log_blowup), ctypes.c_uint32(num_queries),
+                               ctypes.c_uint32(pow_bits), ctypes.c_int(1 if debug_check else 0))
+    return ProveResult(h)
+
+
+def verify_machine(chip_ids, proof_words, rc, log_blowup=1, num_queries=40, pow_bits=8):
+    ids = np.array(chip_ids, dtype=np.uint32)
+    w, wp = _u32(proof_words)
+    r, rp = _u32(rc)
+    msg = ctypes.create_string_buffer(256)
+    rcode = lib().oracle_verify_machine(ids.ctypes.data_as(c_u32p), ctypes.c_uint32(ids.size), wp, ctypes.c_uint64(w.size), rp, ctypes.c_uint32(log_blowup),
+                                        ctypes.c_uint32(num_queries), ctypes.c_uint32(pow_bits), msg, ctypes.c_uint64(256))
+    return None if rcode == 0 else msg.value.decode()
+
+
 def verify_basic(prep_program, prep_range, proof_words, rc, log_blowup=1, num_queries=40, pow_bits=8):
     """Returns None if the proof is accepted, else the rejection message."""
     pp, ppp = _u32(prep_program)

@@ -94,6 +94,19 @@ struct ChipDesc {
 };
 struct MachineDesc {
     std::vector<ChipDesc> chips;
+    // a machine of the given chips::ChipIndex / test-AIR ids (tests of the general log_quotient_degree path)
+    static MachineDesc of(const std::vector<int>& ids) {
+        MachineDesc m;
+        for (int id : ids) {
+            ChipDesc c;
+            c.id = id;
+            c.interactions = chips::all_interactions(id);
+            c.width = chips::chip_shape(id).width;
+            c.prep_width = chips::chip_shape(id).preprocessed_width;
+            m.chips.push_back(c);
+        }
+        return m;
+    }
     static MachineDesc basic() {
         MachineDesc m;
         for (int i = 0; i < chips::NUM_CHIPS; i++) {
@@ -329,9 +342,12 @@ inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, co
     std::vector<const Matrix*> prep_of(NC, nullptr);
     std::vector<int> prep_slot(NC, -1);
     for (auto& p : in.preprocessed) prep_traces.push_back(p.second);
-    MerkleTree prep_tree = pcs_commit(prep_traces, cfg.fri);
+    MerkleTree prep_tree;
+    if (!prep_traces.empty()) {  // a machine without preprocessed traces commits and observes nothing here
+        prep_tree = pcs_commit(prep_traces, cfg.fri);
+        ch.observe(prep_tree.root());
+    }
     for (size_t k = 0; k < in.preprocessed.size(); k++) { prep_of[in.preprocessed[k].first] = &in.preprocessed[k].second; prep_slot[in.preprocessed[k].first] = (int)k; }
-    ch.observe(prep_tree.root());
 
     // main (lib.rs:203-225)
     MerkleTree main_tree = pcs_commit(in.main_traces, cfg.fri);
@@ -407,7 +423,7 @@ inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, co
         proof.chip_proofs.push_back(std::move(cp));
     }
     if (dbg) {
-        dbg->preprocessed_commit = prep_tree.root();
+        if (!prep_traces.empty()) dbg->preprocessed_commit = prep_tree.root();
         dbg->perm_challenges = rnd;
         dbg->alpha = alpha;
         dbg->zeta = zeta;
@@ -465,8 +481,10 @@ inline const char* verify(const MachineDesc& machine, const std::vector<std::pai
     for (size_t i = 0; i < NC; i++) lqd[i] = log_quotient_degree(machine.chips[i]);
     std::vector<Matrix> prep_traces;
     for (auto& p : preprocessed) prep_traces.push_back(p.second);
-    MerkleTree prep_tree = pcs_commit(prep_traces, cfg.fri);  // recomputed (lib.rs:791-804)
-    ch.observe(prep_tree.root());
+    if (!prep_traces.empty()) {
+        MerkleTree prep_tree = pcs_commit(prep_traces, cfg.fri);  // recomputed (lib.rs:791-804)
+        ch.observe(prep_tree.root());
+    }
     ch.observe(proof.main_commit);
     std::vector<Ext5> rnd;
     for (int i = 0; i < 3; i++) rnd.push_back(ch.sample_ext());

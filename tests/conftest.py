@@ -69,3 +69,43 @@ def first_mismatch(a, b):
     if d.size == 0:
         return None
     return "%d/%d words differ, first at %d: %d vs %d" % (d.size, a.size, d[0], a[d[0]], b[d[0]])
+
+
+def pow_trace(n, degree, x0):
+    """Trace of the oracle's synthetic POW5 / POW9 AIRs (oracle/chips.hpp): x counts up from x0, y = x^degree."""
+    import valida_amd as va
+
+    x = (np.arange(n, dtype=np.uint64) + x0) % va.P
+    y = np.array([pow(int(v), degree, va.P) for v in x], dtype=np.uint64)
+    return np.stack([x, y], axis=1).astype(np.uint32)
+
+
+def pow_machine(specs):
+    """The same AIRs captured through the vgpu_air_* FFI: specs = [(name, degree, pin_first)], one chip each."""
+    import ctypes
+
+    import valida_amd as va
+
+    L, u = va.lib(), ctypes.c_uint32
+    m = ctypes.c_void_p()
+    assert L.vgpu_machine_new(ctypes.byref(m)) == 0
+    codes = []
+    for name, degree, pin_first in specs:
+        air = ctypes.c_void_p()
+        assert L.vgpu_air_new(name.encode(), u(2), u(0), ctypes.byref(air)) == 0
+        x = L.vgpu_air_variable(air, u(0), u(0), u(0))
+        y = L.vgpu_air_variable(air, u(0), u(1), u(0))
+        xn = L.vgpu_air_variable(air, u(0), u(0), u(1))
+        p = x
+        for _ in range(degree - 1):
+            p = L.vgpu_air_mul(air, u(p), u(x))
+        L.vgpu_air_assert_zero(air, u(L.vgpu_air_sub(air, u(y), u(p))))
+        one = L.vgpu_air_constant(air, u(1))
+        step = L.vgpu_air_sub(air, u(xn), u(L.vgpu_air_add(air, u(x), u(one))))
+        L.vgpu_air_assert_zero(air, u(L.vgpu_air_mul(air, u(L.vgpu_air_is_transition(air)), u(step))))
+        if pin_first:
+            three = L.vgpu_air_constant(air, u(3))
+            L.vgpu_air_assert_zero(air, u(L.vgpu_air_mul(air, u(L.vgpu_air_is_first_row(air)), u(L.vgpu_air_sub(air, u(x), u(three))))))
+        codes.append(L.vgpu_machine_push_air(m, air))
+        L.vgpu_air_free(air)
+    return va.Machine(m), codes

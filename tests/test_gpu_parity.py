@@ -789,3 +789,42 @@ def test_rccl_communicator_of_the_library_world_of_one(prover, fib25):
     mt = fib25.main_traces()
     dm = [prover.upload(m) for m in mt]
     assert first_mismatch(comm.commit_batches_sharded(dm), prover.commit_batches(dm).root) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specs,heights,log_blowup", [
+    ([("pow5", 5, False)], [16], 2),
+    ([("pow5", 5, False)], [1 << 12], 3),
+    ([("pow9", 9, True), ("pow5", 5, False)], [8, 32], 3),
+    ([("pow9", 9, True)], [1 << 14], 3),
+    ([("pow5", 5, False), ("pow9", 9, True), ("pow5", 5, False)], [1 << 10, 2, 1 << 13], 3),
+])
+def test_general_log_quotient_degree_proof_bytes(rc, specs, heights, log_blowup):
+    """AIRs of degree 5 / 9 (log_quotient_degree 2 / 3; machine/src/quotient.rs handles any): the quotient is evaluated on
+    2^lqd cosets, decomposed into 2^lqd chunks, committed and opened at zeta^(2^lqd) -- every proof word equals the oracle's."""
+    from conftest import pow_machine, pow_trace
+
+    mach, codes = pow_machine(specs)
+    assert codes == [0] * len(specs)
+    ids = [po.TEST_POW9 if d == 9 else po.TEST_POW5 for _, d, _ in specs]
+    traces = [pow_trace(h, d, 3) for h, (_, d, _) in zip(heights, specs)]
+    p = va.Prover(mach, rc, log_blowup=log_blowup, num_queries=11, pow_bits=4)
+    proof = p.prove([p.upload(t) for t in traces], [], check=True)
+    ref = po.prove_machine(ids, traces, rc, log_blowup=log_blowup, num_queries=11, pow_bits=4)
+    assert first_mismatch(proof.words, ref.words) is None
+    assert po.verify_machine(ids, proof.words, rc, log_blowup=log_blowup, num_queries=11, pow_bits=4) is None
+    bad = traces[0].copy()
+    bad[1, 1] ^= 1  # y != x^d on one row: the proof must not verify
+    traces[0] = bad
+    proof = p.prove([p.upload(t) for t in traces], [])
+    assert po.verify_machine(ids, proof.words, rc, log_blowup=log_blowup, num_queries=11, pow_bits=4) is not None
+
+
+@pytest.mark.gpu
+def test_quotient_degree_above_the_blowup_is_refused(rc):
+    from conftest import pow_machine
+
+    mach, _ = pow_machine([("pow5", 5, False)])
+    with pytest.raises(va.VgpuError) as e:
+        va.Prover(mach, rc, log_blowup=1)
+    assert "log_blowup" in str(e.value)

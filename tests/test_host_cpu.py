@@ -131,26 +131,33 @@ def test_air_capture_ffi_roundtrip():
     L.vgpu_air_free(air)
 
 
-def test_air_of_degree_above_three_is_refused_when_pushed():
-    """log_quotient_degree = 1 is what the device quotient implements: a foreign AIR of higher degree is refused at
+def test_air_of_degree_five_and_nine_are_accepted_with_their_quotient_degree():
+    """get_log_quotient_degree (machine/src/quotient.rs): degree 5 -> 2, degree 9 -> 3; both are within what k_quotient_general does."""
+    from conftest import pow_machine
+
+    mach, codes = pow_machine([("pow5", 5, False), ("pow9", 9, True)])
+    assert codes == [0, 0]
+    assert mach.chip_info(0)["max_degree"] == 5 and mach.chip_info(0)["log_quotient_degree"] == 2
+    assert mach.chip_info(1)["max_degree"] == 9 and mach.chip_info(1)["log_quotient_degree"] == 3 and mach.chip_info(1)["constraints"] == 3
+    from conftest import pow_trace
+
+    tr = pow_trace(8, 9, 3)
+    for i in range(8):
+        vals = mach.eval_constraints(1, tr[i], tr[(i + 1) % 8], is_first=int(i == 0), is_last=int(i == 7), is_transition=int(i != 7))
+        assert not vals.any()
+
+
+def test_air_of_degree_above_nine_is_refused_when_pushed():
+    """log_quotient_degree 1..3 is what the device quotient implements: a foreign AIR of higher degree is refused at
     vgpu_machine_push_air with a message that says so (not at prover creation, not silently)."""
+    from conftest import pow_machine
+
     L = va.lib()
-    u = ctypes.c_uint32
-    air = ctypes.c_void_p()
-    assert L.vgpu_air_new(b"pow5", u(2), u(0), ctypes.byref(air)) == 0
-    x = L.vgpu_air_variable(air, u(0), u(0), u(0))
-    y = L.vgpu_air_variable(air, u(0), u(1), u(0))
-    x2 = L.vgpu_air_mul(air, u(x), u(x))
-    x5 = L.vgpu_air_mul(air, u(L.vgpu_air_mul(air, u(x2), u(x2))), u(x))
-    L.vgpu_air_assert_zero(air, u(L.vgpu_air_sub(air, u(y), u(x5))))  # y - x^5: degree 5 -> log_quotient_degree 2
-    m = ctypes.c_void_p()
-    assert L.vgpu_machine_new(ctypes.byref(m)) == 0
-    assert L.vgpu_machine_push_air(m, air) == -4  # VGPU_ERR_UNSUPPORTED
+    mach, codes = pow_machine([("pow10", 10, False)])
+    assert codes == [-4]  # VGPU_ERR_UNSUPPORTED
     msg = L.vgpu_last_error().decode()
-    assert "pow5" in msg and "log_quotient_degree 2" in msg and "degree 5" in msg
-    assert L.vgpu_machine_num_chips(m) == 0
-    L.vgpu_machine_free(m)
-    L.vgpu_air_free(air)
+    assert "pow10" in msg and "log_quotient_degree 4" in msg and "degree 10" in msg
+    assert mach.num_chips == 0
 
 
 def test_status_codes_and_error_messages():

@@ -107,12 +107,12 @@ int32_t vgpu_machine_push_air(vgpu_machine_t* m, const vgpu_air_t* air) {
     VG_TRY({
         if (!m || !air) throw std::invalid_argument("null argument");
         AirDesc d = MachineDesc::make_air_from_dag(air->name, air->dag, air->interactions);
-        // The device quotient kernels evaluate and decompose over a quotient domain of 2n points: log_quotient_degree = 1, i.e.
-        // constraint degree <= 3 (= LOOKUP_DEGREE_BOUND, machine/src/lib.rs:36, which the permutation constraints reach anyway).
-        // Every chip of the reference satisfies it; a foreign AIR of higher degree is refused HERE, when it is pushed, not later.
-        if (d.log_quotient_degree != 1) {
+        // log_quotient_degree 1 (constraint degree <= 3 = LOOKUP_DEGREE_BOUND, machine/src/lib.rs:36) is what every chip of the
+        // reference has; captured AIRs of degree up to 9 (log_quotient_degree 2, 3) run through the general quotient kernel.  Beyond
+        // that the AIR is refused HERE, when it is pushed.
+        if (d.log_quotient_degree < 1 || d.log_quotient_degree > 3) {
             g_err = "AIR '" + air->name + "': max constraint degree " + std::to_string(d.max_constraint_degree) + " gives log_quotient_degree " +
-                    std::to_string(d.log_quotient_degree) + "; the device path implements log_quotient_degree = 1 (constraint degree <= 3) only";
+                    std::to_string(d.log_quotient_degree) + "; the device path implements log_quotient_degree 1..3 (constraint degree <= 9)";
             return VGPU_ERR_UNSUPPORTED;
         }
         m->desc.airs.push_back(std::move(d));

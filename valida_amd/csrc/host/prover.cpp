@@ -14,8 +14,10 @@ static void ext_to_canonical(const Ext5& e, uint32_t* w) { for (int k = 0; k < 5
 Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_rc480, const FriParams& fri)
     : ctx_(new DeviceCtx(device)), machine_(machine), fri_(fri), perm16_(poseidon_rc480) {
     for (auto& a : machine_.airs) {
-        if (a.log_quotient_degree != 1) throw std::runtime_error("chip " + a.name + ": only log_quotient_degree = 1 is implemented on the device");
-        if (fri_.log_blowup < a.log_quotient_degree) throw std::runtime_error("log_blowup must be >= log_quotient_degree");
+        if (a.log_quotient_degree < 1 || a.log_quotient_degree > 3) throw std::invalid_argument("chip " + a.name + ": log_quotient_degree must be 1..3");
+        if (a.log_quotient_degree != 1 && a.native_chip >= -1) throw std::invalid_argument("chip " + a.name + ": the compiled chip kernels assume log_quotient_degree = 1");
+        if (fri_.log_blowup < a.log_quotient_degree)
+            throw std::invalid_argument("chip " + a.name + ": log_blowup must be >= log_quotient_degree (the quotient domain must lie inside the committed LDE)");
         std::vector<uint32_t> pw(a.program.instrs.size() * 2 + 2, 0);
         if (!a.program.instrs.empty()) memcpy(pw.data(), a.program.instrs.data(), a.program.instrs.size() * 8);
         prog_dev_.emplace_back(ctx_.get(), pw);
@@ -244,7 +246,7 @@ DMat Prover::quotient_chunks(int chip, const DMat& main_lde, const DMat& perm_ld
     a.K = quotient_consts(air, rnd, alpha, cumulative_sum, pool);
     DBuf pool_dev(&c, pool);
     fill_quotient_args(a, chip, main_lde.view(), perm_lde.view(), prep_lde ? prep_lde->view() : vk::DMatView{nullptr, 0, 0, 0}, log_n, pool_dev.data);
-    DMat q(&c, 1ull << log_n, 10);
+    DMat q(&c, 1ull << log_n, 5ull << air.log_quotient_degree);
     a.out = q.view();
     vk::launch_quotient(c.stream, a, c.tables);
     c.check_launch("quotient");
@@ -267,10 +269,11 @@ void Prover::fill_quotient_args(vk::QuotientArgs& a, int chip, vk::DMatView main
     a.consts = consts_dev;
     a.coset_shift = s.v;
     a.coset_shift_inv = s.inv().v;
-    Fp sn = s.exp_power_of_2(log_n);
-    Fp z0 = sn - Fp::one(), z1 = -sn - Fp::one();
-    a.zh[0] = z0.v; a.zh[1] = z1.v;
-    a.zh_inv[0] = z0.inv().v; a.zh_inv[1] = z1.inv().v;
+    // ZerofierOnCoset::new(log_n, lqd, s) (App. B11): Z_H(s w_{Qn}^i) = s^n w_Q^(i mod Q) - 1
+    a.lqd = (int)air.log_quotient_degree;
+    const Fp sn = s.exp_power_of_2(log_n), wq = vg::two_adic_generator(air.log_quotient_degree);
+    Fp wp = Fp::one();
+    for (unsigned r = 0; r < (1u << air.log_quotient_degree); r++) { Fp z = sn * wp - Fp::one(); a.zh[r] = z.v; a.zh_inv[r] = z.inv().v; wp *= wq; }
     a.g_inv = vg::two_adic_generator(log_n).inv().v;
 }
 
@@ -502,7 +505,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             fill_quotient_args(a, (int)i, main_pd->ldes[i].view(), perm_pd->ldes[i].view(),
                                prep_slot[i] >= 0 ? prep_pd->ldes[prep_slot[i]].view() : vk::DMatView{nullptr, 0, 0, 0}, log_deg[i], pool_dev.data + off[i]);
             a.K = Ks[i];
-            quot[i] = DMat(&c, 1ull << log_deg[i], 10);
+            quot[i] = DMat(&c, 1ull << log_deg[i], 5ull << air.log_quotient_degree);
             a.out = quot[i].view();
             vk::launch_quotient(c.stream_for(i, 1ull << log_deg[i]), a, c.tables);
             quot_shifts[i] = s.exp_power_of_2(air.log_quotient_degree);  // lib.rs:593-596

@@ -15,10 +15,11 @@ struct QuotientArgs {
     const uint32_t* consts;      // Ext5 words: [K alpha powers][M bus alphas][max_fields betas][cumulative_sum]
     uint32_t K;                  // total number of folded constraints = n_air_asserts + M + 3
     uint32_t coset_shift, coset_shift_inv;      // s = 31 (Montgomery), s^-1
-    uint32_t zh_inv[2];          // 1/(s^n - 1), 1/(-s^n - 1)   (Z_H on the two cosets of the quotient domain)
-    uint32_t zh[2];              // s^n - 1, -s^n - 1
+    int lqd;                     // log_quotient_degree: quotient domain 2^(log_n + lqd); 1 for every reference chip
+    uint32_t zh_inv[8];          // 1 / zh[r]
+    uint32_t zh[8];              // Z_H on the 2^lqd cosets of the quotient domain: zh[r] = s^n w_Q^r - 1 for natural index = r mod 2^lqd
     uint32_t g_inv;              // g_n^{-1}  (subgroup_last)
-    DMatView out;                // n x 10, row for natural i stored at position bitrev_k(i)
+    DMatView out;                // n x (5 << lqd), row for natural i stored at position bitrev_k(i)
     // BasicMachine chip whose eval template is compiled into a native kernel (vchips::ChipId), or INTERPRET for
     // the register-program interpreter (AIRs captured at run time through vgpu_air_*)
     static constexpr int INTERPRET = -2;

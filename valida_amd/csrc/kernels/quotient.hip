@@ -19,6 +19,7 @@
 // quotient-chunk row i is produced in place (written at position m = bit-reversed order, which is what
 // the inverse NTT of the following commit consumes).
 #include <cstdlib>
+#include <stdexcept>
 #include "launch.hpp"
 #include "interactions.hpp"
 #include "../chips/basic_machine.hpp"
@@ -243,6 +244,64 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
     }
 }
 
+// ---- log_quotient_degree >= 2 (AIRs of degree 4..9 captured through vgpu_air_*; no chip of the reference needs it) -------------
+// The quotient domain s*H_{Qn}, Q = 2^lqd, is the first Qn storage rows; thread m owns storage rows Qm .. Qm+Q-1 = natural indices
+// i0 + n bitrev_lqd(r), i.e. the Q points x0 w_Q^{bitrev(r)}: every pair decompose() butterflies at any level of its recursion
+// (machine/src/quotient.rs:63-67 -> p3_uni_stark::decompose, App. B11) lives in this thread.  At each level adjacent storage
+// entries are (f(y), f(-y)): even = (a + b) / 2, odd = (a - b) / (2 y); the evens (then the odds) of a group are again in
+// bit-reversed order of the squared domain, so the same step recurses with y^2.  Chunk order = decompose(even) ++ decompose(odd).
+template <int RFKIND>
+__global__ void __launch_bounds__(256) k_quotient_general(QuotientArgs a, DeviceTables tb) {
+    extern __shared__ uint32_t regs[];
+    constexpr int QMAX = 8;
+    const int lqd = a.lqd, Q = 1 << lqd;
+    const uint64_t n = 1ull << a.log_n;
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const int kq = a.log_n + lqd;
+    const uint32_t Qmask = (uint32_t)(((uint64_t)Q << a.log_n) - 1);
+    const uint32_t i0 = vg::reverse_bits_len((uint32_t)m, (unsigned)a.log_n);
+    const Fp s = Fp::raw(a.coset_shift), g_inv = Fp::raw(a.g_inv);
+    Ext5 v[QMAX];
+#pragma unroll 1
+    for (int r = 0; r < Q; r++) {
+        const uint32_t j = (uint32_t)(Q * m) + (uint32_t)r;                                       // storage row
+        const uint32_t i = i0 + (uint32_t)(n * vg::reverse_bits_len((uint32_t)r, (unsigned)lqd));  // its natural index
+        const Fp x = s * domain_point(tb, j);
+        const Fp zh = Fp::raw(a.zh[i & (uint32_t)(Q - 1)]);
+        PointCtx p;
+        p.row = j;
+        p.next_row = vg::reverse_bits_len((i + (uint32_t)Q) & Qmask, (unsigned)kq);
+        p.is_trans = x - g_inv;
+        p.is_first = zh * (x - Fp::one()).inv();
+        p.is_last = zh * p.is_trans.inv();
+        Ext5 q = RFKIND == 0 ? run_program_lds(a, p, regs) : run_program_vgpr<(RFKIND == 0 ? 1 : RFKIND)>(a, p);
+        v[r] = (q + perm_constraints(a, p)) * Fp::raw(a.zh_inv[i & (uint32_t)(Q - 1)]);
+    }
+    // recursive even / odd decomposition, in registers
+    Fp ybase = s * domain_point(tb, (uint32_t)(Q * m));  // x0 of this thread; squared at every level
+    for (int level = 0; level < lqd; level++) {
+        const int G = Q >> level;                         // group size at this level; groups are contiguous
+        const int lg = lqd - level;
+        Ext5 t[QMAX];
+        for (int base = 0; base < Q; base += G)
+            for (int u = 0; u < G / 2; u++) {
+                // y = ybase * w_G^{bitrev_lg(2u)}; only its inverse is needed
+                const Fp w = vg::two_adic_generator((unsigned)lg).pow(vg::reverse_bits_len((uint32_t)(2 * u), (unsigned)lg));
+                const Fp yinv = (ybase * w).inv();
+                const Ext5 av = v[base + 2 * u], bv = v[base + 2 * u + 1];
+                Ext5 e = av + bv, o = (av - bv) * yinv;
+                for (int c = 0; c < 5; c++) { e.c[c] = e.c[c].halve(); o.c[c] = o.c[c].halve(); }
+                t[base + u] = e;
+                t[base + G / 2 + u] = o;
+            }
+        for (int r = 0; r < Q; r++) v[r] = t[r];
+        ybase = ybase * ybase;
+    }
+    for (int ch = 0; ch < Q; ch++)
+        for (int c = 0; c < 5; c++) a.out.data[(uint64_t)(5 * ch + c) * a.out.stride + m] = v[ch].c[c].v;
+}
+
 // ---- debug check of the witness (machine/src/check_constraints.rs via basic/src/lib.rs:270-372, debug builds) ---------
 // Every constraint evaluated on the TRACE domain itself: row r, next = r + 1 mod n, is_first / is_last / is_transition as
 // 0/1 selectors (DebugConstraintBuilder, machine/src/debug_builder.rs:7-114).  The first failing (row, constraint) is
@@ -316,8 +375,26 @@ void launch_check_constraints(hipStream_t st, const QuotientArgs& a, unsigned lo
 
 void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& tb) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_quotient_general<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     uint64_t n = 1ull << a.log_n;
+    if (a.lqd != 1) {  // higher-degree AIRs: the interpreted program over 2^lqd points per thread
+        if (a.lqd < 1 || a.lqd > 3 || a.native_chip != QuotientArgs::INTERPRET) throw std::runtime_error("quotient: log_quotient_degree must be 1..3 (and above 1 only for interpreted AIRs)");
+        ProfScope ps("k_quotient", st, 4.0 * n * ((double)(1 << a.lqd) * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 5.0 * (1 << a.lqd)));
+        unsigned threads = 256;
+        if (a.n_regs <= 64) {
+            dim3 grid((unsigned)((n + threads - 1) / threads));
+            if (a.n_regs <= 32) VK_LAUNCH(k_quotient_general<1>, grid, dim3(threads), 0, st, a, tb);
+            else VK_LAUNCH(k_quotient_general<2>, grid, dim3(threads), 0, st, a, tb);
+            return;
+        }
+        while (threads > 64 && (size_t)a.n_regs * threads * 4 > 64 * 1024) threads >>= 1;
+        VK_LAUNCH(k_quotient_general<0>, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), (size_t)a.n_regs * threads * 4, st, a, tb);
+        return;
+    }
     static const char* names[16] = {"k_quotient.cpu", "k_quotient.program", "k_quotient.mem", "k_quotient.add", "k_quotient.sub", "k_quotient.mul", "k_quotient.div",
                                     "k_quotient.shift", "k_quotient.lt", "k_quotient.com", "k_quotient.bitwise", "k_quotient.output", "k_quotient.range",
                                     "k_quotient.static_data", "k_quotient", "k_quotient"};
