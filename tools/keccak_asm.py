@@ -338,7 +338,32 @@ def _run(lines, v):
     return v
 
 
+def emit_header(path):
+    """valida_amd/csrc/kernels/keccak_f1600_gfx950.inc: the permutation as asm string macros (identity register map, program order,
+    s_nop 0 behind every v_alignbit_b32).  State word w (= 2 * lane + half) is v[8 + w] on entry and on exit."""
+    PHYS.update({r: r for r in range(8, 128)})
+    out = ["// GENERATED by tools/keccak_asm.py --emit -- do not edit (tests/test_host_cpu.py regenerates and compares).",
+           "// Keccak-f[1600] for gfx950, one permutation per lane, fixed VGPRs: state word w = 2 * lane + half in v[8 + w] (v8..v57), scratch v58..v127.",
+           "// Bind the state with the operand tuples \"+{v[8:23]}\", \"+{v[24:39]}\", \"+{v[40:55]}\", \"+{v[56:71]}\" and clobber VK_KECCAK_ASM_CLOBBERS."]
+    for name, digest in (("VK_KECCAK_F1600_ASM", False), ("VK_KECCAK_F1600_DIGEST_ASM", True)):
+        ins = []
+        for r in range(24):
+            ins += round_instrs(r, digest and r == 23)
+        lines = with_nops(ins, "each")
+        out.append("#define %s \\" % name)
+        out += ['    "%s\\n" \\' % ln for ln in lines[:-1]]
+        out.append('    "%s\\n"' % lines[-1])
+    out.append("#define VK_KECCAK_ASM_CLOBBERS " + ", ".join('"v%d"' % r for r in range(72, 128)))
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
 if __name__ == "__main__":
+    import os
+    if len(sys.argv) > 1 and sys.argv[1] == "--emit":
+        emit_header(sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "valida_amd", "csrc", "kernels",
+                                                                      "keccak_f1600_gfx950.inc"))
+        sys.exit(0)
     import random
     rnd = random.Random(1)
     st = [rnd.getrandbits(64) for _ in range(25)]

@@ -39,7 +39,7 @@ def _all_headers():
     out = []
     for base, _, files in os.walk(CSRC):
         for f in files:
-            if f.endswith((".hpp", ".h")):
+            if f.endswith((".hpp", ".h", ".inc")):
                 out.append(os.path.join(base, f))
     out.append(os.path.join(ROOT, "include", "vgpu.h"))
     return out
