@@ -144,6 +144,13 @@ void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on);
 void vgpu_prover_set_profiling_filter(vgpu_prover_t* p, const char* kernel_name);
 int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap);
 
+/* Page-locked host memory for the matrices a host hands over: vgpu_trace_upload / vgpu_oplog_upload from such a buffer is one DMA at
+ * PCIe rate; from ordinary (pageable) memory the runtime stages the copy through its own bounce buffers on the calling thread, which
+ * at 516 MB of main traces per C2 proof is slower than the proof itself (bench.py: pcie_inclusive).  A Rust host would back its
+ * RowMajorMatrix<Val> values with this allocator.  Needs a HIP device; free with vgpu_host_free. */
+int32_t vgpu_host_alloc(uint64_t bytes, void** out);
+void vgpu_host_free(void* ptr);
+
 /* H2D of a host RowMajorMatrix (the reference passes these by value, basic/src/lib.rs:223) */
 int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t height, uint64_t width, vgpu_trace_t** out);
 void vgpu_trace_free(vgpu_trace_t* t);

@@ -828,3 +828,41 @@ def test_quotient_degree_above_the_blowup_is_refused(rc):
     with pytest.raises(va.VgpuError) as e:
         va.Prover(mach, rc, log_blowup=1)
     assert "log_blowup" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_upload_from_page_locked_host_memory(prover, fib25):
+    """vgpu_host_alloc: matrices handed over in page-locked memory give the same proof; the allocation outlives views of it."""
+    import gc
+
+    ref = prover.prove([prover.upload(fib25.main_trace(c)) for c in range(va.NUM_CHIPS)], [(c, prover.upload(m)) for c, m in fib25.preprocessed()])
+    pinned = [va.pinned_copy(fib25.main_trace(c)) for c in range(va.NUM_CHIPS)]
+    view = pinned[0][1:, :]
+    first_row = pinned[0][1].copy()
+    got = prover.prove([prover.upload(m) for m in pinned], [(c, prover.upload(m)) for c, m in fib25.preprocessed()])
+    assert first_mismatch(got.words, ref.words) is None
+    del pinned
+    gc.collect()
+    assert np.array_equal(view[0], first_row)  # the view keeps the block alive
+    assert va.lib().vgpu_host_alloc(ctypes.c_uint64(0), ctypes.byref(ctypes.c_void_p())) == -1
+
+
+@pytest.mark.gpu
+def test_uploads_beside_a_running_proof(machine, rc):
+    """A host prepares the next segment while the previous proof runs on the same context: vgpu_trace_upload then copies on a stream of
+    its own (ordered behind the kernels that may still read recycled pool blocks); every proof equals the one proved from idle uploads."""
+    p = va.Prover(machine, rc)
+    ws = [va.Workload.fib(2000 + 7 * k) for k in range(4)]
+    prep = [(c, p.upload(m)) for c, m in ws[0].preprocessed()]
+    want = [p.prove([p.upload(w.main_trace(c)) for c in range(va.NUM_CHIPS)], prep).words.copy() for w in ws]
+    host = [[va.pinned_copy(w.main_trace(c)) if k % 2 else w.main_trace(c) for c in range(va.NUM_CHIPS)] for k, w in enumerate(ws)]
+    ticket, got = None, []
+    for rep in range(3):
+        for k in range(len(ws)):
+            staged = [p.upload(m) for m in host[k]]  # while the previous ticket is still running
+            if ticket is not None:
+                got.append(ticket.wait().words.copy())
+            ticket = p.prove_async(staged, prep)
+    got.append(ticket.wait().words.copy())
+    for i, g in enumerate(got):
+        assert first_mismatch(g, want[i % len(ws)]) is None, i

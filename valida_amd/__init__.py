@@ -307,6 +307,38 @@ def poseidon16_permute(rc, state):
     return s
 
 
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        self.ptr = ctypes.c_void_p()
+        _check(lib().vgpu_host_alloc(ctypes.c_uint64(max(1, nbytes)), ctypes.byref(self.ptr)))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            try:
+                lib().vgpu_host_free(self.ptr)
+            except TypeError:  # interpreter shutdown
+                pass
+            self.ptr = None
+
+
+def pinned_empty(shape, dtype=np.uint32):
+    """numpy array in page-locked host memory (vgpu_host_alloc): uploads from it are plain DMA.  The memory lives as long as the array
+    (or any view of it) does."""
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if shape else 1
+    blk = _PinnedBlock(n * dt.itemsize)
+    buf = (ctypes.c_char * max(1, n * dt.itemsize)).from_address(blk.ptr.value)
+    buf._vgpu_block = blk  # the ctypes buffer (numpy's .base) keeps the allocation alive
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+
+def pinned_copy(a):
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
 class DeviceOplog:
     def __init__(self, prover, handle, nbytes):
         self._prover, self._h, self.nbytes = prover, handle, nbytes

@@ -318,6 +318,17 @@ int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap) {
     if (out && cap > s.size()) memcpy(out, s.c_str(), s.size() + 1);
     return (int64_t)s.size() + 1;
 }
+int32_t vgpu_host_alloc(uint64_t bytes, void** out) {
+    VG_TRY({
+        if (!out || !bytes) throw std::invalid_argument("vgpu_host_alloc: null output or zero size");
+        void* ptr = nullptr;
+        hipError_t e = hipHostMalloc(&ptr, bytes, hipHostMallocPortable);
+        if (e == hipErrorOutOfMemory) throw std::bad_alloc();
+        if (e != hipSuccess) throw std::runtime_error(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        *out = ptr;
+    })
+}
+void vgpu_host_free(void* ptr) { if (ptr) (void)hipHostFree(ptr); }
 int32_t vgpu_trace_upload(vgpu_prover_t* p, const uint32_t* data, uint64_t height, uint64_t width, vgpu_trace_t** out) {
     VG_TRY({
         if (!p || !data || !out || !height || !width) throw std::invalid_argument("bad trace");

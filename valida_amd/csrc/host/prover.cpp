@@ -76,6 +76,10 @@ std::unique_ptr<DeviceTrace> Prover::upload_trace(const HostMatrix& m) {
     auto t = std::make_unique<DeviceTrace>();
     t->height = m.height; t->width = m.width;
     t->raw = DBuf(ctx_.get(), (size_t)(m.height * m.width));
+    if (ctx_->proofs_running.load() > 0) {  // the caller prepares the next segment while a proof owns this context's streams
+        ctx_->upload_beside_proof(t->raw.data, m.data, m.height * m.width * 4);
+        return t;
+    }
     VG_HIP_CHECK(hipMemcpyAsync(t->raw.data, m.data, m.height * m.width * 4, hipMemcpyHostToDevice, ctx_->stream));
     ctx_->sync();
     return t;
@@ -282,6 +286,11 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
                                     PhaseTimes* times, ProveDebugOut* dbg) {
     DeviceCtx& c = *ctx_;
     c.activate();
+    struct Running {
+        std::atomic<int>& n;
+        explicit Running(std::atomic<int>& a) : n(a) { n.fetch_add(1); }
+        ~Running() { n.fetch_sub(1); }
+    } running(c.proofs_running);
     const size_t NC = machine_.airs.size();
     if (main.size() != NC) throw std::invalid_argument("prove: need one main trace per chip");
     const Fp s = Fp::from_canonical(vg::GENERATOR);  // pcs.coset_shift()

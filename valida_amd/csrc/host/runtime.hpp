@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -54,6 +55,12 @@ struct DeviceCtx {
     // The pool is shared by the thread that drives a proof (vgpu_prove_async's worker) and by whichever host thread frees a
     // handle meanwhile (vgpu_trace_free / vgpu_oplog_free / a garbage collector): every pool operation takes this lock.
     std::mutex pool_mu;
+    // Uploads handed in by a caller thread WHILE a proof owns the main stream (a host that prepares segment i+1 during proof i):
+    // a stream of their own, created on first use, so the copy neither queues behind the proof's kernels nor shares its waits.
+    std::atomic<int> proofs_running{0};
+    std::mutex upload_mu;
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t upload_ev = nullptr;
 
     explicit DeviceCtx(int dev) : device(dev) {
         VG_HIP_CHECK(hipSetDevice(dev));
@@ -81,6 +88,7 @@ struct DeviceCtx {
         for (auto& kv : free_blocks) (void)hipFree(kv.second);
         for (auto& kv : live_blocks) (void)hipFree(kv.first);
         if (table_mem) (void)hipFree(table_mem);
+        if (upload_stream) { (void)hipStreamSynchronize(upload_stream); (void)hipStreamDestroy(upload_stream); (void)hipEventDestroy(upload_ev); }
         if (pinned) (void)hipHostFree(pinned);
         if (stage) (void)hipHostFree(stage);
         (void)hipStreamDestroy(stream);
@@ -203,6 +211,20 @@ struct DeviceCtx {
     void upload(void* dst, const void* src, size_t bytes) {
         VG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
         sync();
+    }
+    // The same from a second host thread while a proof is running on this context.  `dst` comes from the pool: a block on the free list
+    // may still be read by kernels the proving thread enqueued before it released the block, and every such kernel is ordered before an
+    // event recorded on the main stream now (releases inside a fork/join section are deferred to the join) — the copy waits for that event.
+    void upload_beside_proof(void* dst, const void* src, size_t bytes) {
+        std::lock_guard<std::mutex> lk(upload_mu);
+        if (!upload_stream) {
+            VG_HIP_CHECK(hipStreamCreateWithFlags(&upload_stream, hipStreamNonBlocking));
+            VG_HIP_CHECK(hipEventCreateWithFlags(&upload_ev, hipEventDisableTiming));
+        }
+        VG_HIP_CHECK(hipEventRecord(upload_ev, stream));
+        VG_HIP_CHECK(hipStreamWaitEvent(upload_stream, upload_ev, 0));
+        VG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, upload_stream));
+        VG_HIP_CHECK(hipStreamSynchronize(upload_stream));
     }
     void download(void* dst, const void* src, size_t bytes) {
         VG_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
