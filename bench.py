@@ -239,14 +239,37 @@ def main():
     # The path's one collective is issued by the LIBRARY (vgpu_comm_*: RCCL loaded and driven by libvgpu.so, so a non-Python host
     # owns it); the 128-byte communicator id travels through the launcher's own channel (here torch.distributed's).  Any failure
     # falls back to torch.distributed's all_gather and says so in the JSON line.
-    lib_comm, comm_note = None, "torch.distributed all_gather_into_tensor"
+    lib_comm, comm_note, comm_stuck = None, "torch.distributed all_gather_into_tensor", False
     if world > 1 and backend == "nccl" and os.environ.get("VGPU_BENCH_COMM", "library") == "library":
+        # a rendezvous that never completes must not take the scaling run with it: communicator creation and a first all-gather
+        # run on a watchdog thread; past the deadline this rank reports failure and every rank takes the torch route
+        import threading
+        box = {}
+
+        def bring_up():
+            try:
+                cm = va.Comm(prover, ids[0], rank, world)
+                probe = cm.allgather_roots(np.full(24, rank, dtype=np.uint32))
+                if [int(r[0]) for r in probe] != list(range(world)):
+                    raise RuntimeError("probe all-gather returned %s" % probe[:, 0].tolist())
+                box["comm"] = cm
+            except Exception as e:  # noqa: BLE001 - the scaling run must not die on the optional route
+                box["error"] = e
+
         try:
             ids = [va.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            lib_comm = va.Comm(prover, ids[0], rank, world)
+            th = threading.Thread(target=bring_up, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("VGPU_BENCH_COMM_TIMEOUT", "90")))
+            if th.is_alive():
+                comm_stuck = True
+                raise TimeoutError("communicator bring-up still running after the deadline")
+            if "error" in box:
+                raise box["error"]
+            lib_comm = box["comm"]
             comm_note = "vgpu_comm_allgather_roots (RCCL driven by libvgpu.so)"
-        except Exception as e:  # noqa: BLE001 - the scaling run must not die on the optional route
+        except Exception as e:  # noqa: BLE001
             lib_comm, comm_note = None, "torch.distributed all_gather_into_tensor (library communicator failed: %s)" % e
         flags = [lib_comm is not None]
         gathered = [None] * world
@@ -499,8 +522,12 @@ def main():
                 from oracle import pyoracle as po
                 po.set_mmcs_hash(1, rc)
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_rows if args.cpu_log_rows else headline, rc, args.log_rows)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        if comm_stuck:  # a thread is still inside the abandoned rendezvous: leave without waiting for it
+            dist.barrier()
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
