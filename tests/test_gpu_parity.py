@@ -49,6 +49,16 @@ def test_mixed_height_commit_root(prover):
     assert first_mismatch(pd.root, po.commit_root(mats)) is None
 
 
+def test_commit_root_across_the_lane_pair_threshold(prover):
+    """Layers of at most 32768 nodes are hashed by lane pairs (keccak_pair.hpp), larger ones one node per thread: a tree whose injections
+    land on both sides, with row widths that end exactly on / one before / one after a 34-word Keccak block."""
+    rng = np.random.default_rng(13)
+    shapes = [(1 << 16, 2), (1 << 15, 35), (1 << 14, 69), (1 << 13, 34), (1 << 12, 33), (1 << 11, 67), (1 << 10, 68), (1 << 9, 1), (1 << 14, 1)]
+    mats = [rand_matrix(rng, h, w) for h, w in shapes]
+    pd = prover.commit_batches([prover.upload(m) for m in mats])
+    assert first_mismatch(pd.root, po.commit_root(mats)) is None
+
+
 def test_single_row_batch_root(prover):
     rng = np.random.default_rng(12)
     mats = [rand_matrix(rng, 1, w) for w in (3, 40, 7)]

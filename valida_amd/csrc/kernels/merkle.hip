@@ -10,6 +10,8 @@
 // (SURVEY.md §8(d) caveat) — 25 lanes = 50 VGPRs of state per thread.
 #include "launch.hpp"
 #include "keccak.hpp"
+#include "keccak_pair.hpp"
+#include <cstdlib>
 
 namespace vk {
 
@@ -107,6 +109,91 @@ __global__ void __launch_bounds__(256) k_keccak_compress(const uint32_t* __restr
     }
 }
 
+// ---- lane-pair variants (keccak_pair.hpp) for the latency-bound layers: thread t works on node t / 2, half t & 1 ----
+// A digest is 8 words d[0..7] = (lane0.lo, lane0.hi, lane1.lo, ...): the half-h thread holds d[h], d[2 + h], d[4 + h], d[6 + h].
+template <class Cols>
+__device__ __forceinline__ void hash_row_pair(const Cols cols, int n_elems, uint64_t r, int h, uint32_t (&out)[4]) {
+    KHalf a;
+#pragma unroll
+    for (int i = 0; i < 25; i++) a.s[i] = 0;
+    int base = 0;
+    for (; base + 34 <= n_elems; base += 34) {
+#pragma unroll
+        for (int l = 0; l < 17; l++) a.s[l] ^= Fp::raw(cols[base + 2 * l + h][r]).canonical();
+        keccak_f1600_pair<false>(a, h);
+    }
+    const int rem = n_elems - base;  // 0..33: words base .. base + rem - 1, then the 0x01 pad word at position rem
+#pragma unroll
+    for (int l = 0; l < 17; l++) {
+        const int k = 2 * l + h;
+        if (k < rem) a.s[l] ^= Fp::raw(cols[base + k][r]).canonical();
+        if (k == rem) a.s[l] ^= 0x01u;
+    }
+    if (h) a.s[16] ^= 0x80000000u;  // word 33
+    keccak_f1600_pair<true>(a, h);
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = wrap_mod_p(a.s[i]);
+}
+__device__ __forceinline__ void compress2_pair(const uint32_t (&l)[4], const uint32_t (&r)[4], int h, uint32_t (&out)[4]) {
+    KHalf a;
+#pragma unroll
+    for (int i = 0; i < 25; i++) a.s[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a.s[i] = l[i]; a.s[4 + i] = r[i]; }
+    if (!h) a.s[8] = 0x01u;
+    else a.s[16] = 0x80000000u;
+    keccak_f1600_pair<true>(a, h);
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = wrap_mod_p(a.s[i]);
+}
+__device__ __forceinline__ void load_digest_half(const uint32_t* p, int h, uint32_t (&d)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = p[2 * i + h];
+}
+__device__ __forceinline__ void store_digest_half(uint32_t* p, int h, const uint32_t (&d)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) p[2 * i + h] = d[i];
+}
+// one node (parent i of `prev`, optionally with the injected row i of `cols`) by the lane pair
+__device__ __forceinline__ void node_pair(const uint32_t* prev, const uint32_t* const* cols, int n_elems, uint64_t i, int h, uint32_t* out) {
+    uint32_t l[4], r[4], d[4];
+    load_digest_half(prev + 16 * i, h, l);
+    load_digest_half(prev + 16 * i + 8, h, r);
+    compress2_pair(l, r, h, d);
+    if (n_elems > 0) {
+        uint32_t hr[4], d2[4];
+        hash_row_pair(PtrCols{cols}, n_elems, i, h, hr);
+        compress2_pair(d, hr, h, d2);
+        store_digest_half(out + 8 * i, h, d2);
+    } else {
+        store_digest_half(out + 8 * i, h, d);
+    }
+}
+template <class Cols>
+__global__ void __launch_bounds__(256) k_keccak_leaves_pair(const Cols cols, int n_elems, uint64_t n_rows, uint32_t* __restrict__ digests) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, r = t >> 1;
+    if (r >= n_rows) return;
+    uint32_t d[4];
+    hash_row_pair(cols, n_elems, r, (int)(t & 1), d);
+    store_digest_half(digests + 8 * r, (int)(t & 1), d);
+}
+__global__ void __launch_bounds__(256) k_keccak_compress_pair(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int n_elems, uint64_t n_out,
+                                                             uint32_t* __restrict__ next) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i = t >> 1;
+    if (i >= n_out) return;
+    node_pair(prev, cols, n_elems, i, (int)(t & 1), next);
+}
+__global__ void __launch_bounds__(1024) k_keccak_top_pair(KeccakTopArgs a) {
+    const uint32_t* prev = a.prev;
+    for (int l = 0; l < a.levels; l++) {
+        const uint64_t len = a.first_len >> l;
+        if ((threadIdx.x >> 1) < len) node_pair(prev, a.cols[l], a.n_elems[l], threadIdx.x >> 1, (int)(threadIdx.x & 1), a.out[l]);
+        __threadfence_block();
+        __syncthreads();
+        prev = a.out[l];
+    }
+}
+
 // Top of a tree in ONE launch: a single 1024-thread workgroup walks the last `levels` layers
 // (first_len <= 1024 parents down to the root), one barrier per layer, instead of one ~10 us launch per
 // layer — there are ~25 trees per proof (3 commitment rounds + one per FRI layer).
@@ -138,6 +225,14 @@ __global__ void __launch_bounds__(1024) k_keccak_top(KeccakTopArgs a) {
 // Algorithmic VALU work of the Keccak kernels, in wave64 instructions: permutations x (23 full rounds of 178 ops +
 // the 58-op digest-only last round) / 64 lanes.  A row of n field elements absorbs floor(n / 34) + 1 blocks.
 constexpr double KECCAK_VALU_PER_PERM = 23 * 178.0 + 58.0;
+// Below this many nodes a layer cannot fill the GPU's wave slots (256 CUs x 4 SIMDs x >= 2 waves x 64 lanes = 131072 threads): it is
+// latency-bound and the lane-pair permutation (2 threads per node, 0.67 x the instructions per thread) is the faster one.
+// VGPU_KECCAK_PAIRS=0 switches the pair kernels off (A/B, tools/gpu_ab_env.sh).
+constexpr uint64_t KECCAK_PAIR_MAX_NODES = 32768;  // 8192 .. 131072 measure the same (tools/gpu_pair_sweep.sh)
+static bool keccak_pairs_enabled() {
+    static const bool on = [] { const char* e = getenv("VGPU_KECCAK_PAIRS"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static double row_perms(int n_elems) { return (double)(n_elems / 34 + 1); }
 static double node_perms(int n_inject) { return n_inject > 0 ? 2.0 + row_perms(n_inject) : 1.0; }
 
@@ -148,22 +243,35 @@ void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
         perms += (double)(a.first_len >> l) * node_perms(a.n_elems[l]);
     }
     ProfScope ps("k_keccak_top", st, bytes, perms * KECCAK_VALU_PER_PERM / 64.0);
+    if (keccak_pairs_enabled() && a.first_len <= 512) { VK_LAUNCH(k_keccak_top_pair, dim3(1), dim3(1024), 0, st, a); return; }
     VK_LAUNCH(k_keccak_top, dim3(1), dim3(1024), 0, st, a);
 }
 
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
     ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
+    if (keccak_pairs_enabled() && n_rows <= KECCAK_PAIR_MAX_NODES) {
+        VK_LAUNCH(k_keccak_leaves_pair<PtrCols>, dim3((unsigned)((2 * n_rows + 255) / 256)), dim3(256), 0, st, PtrCols{cols_dev}, n_elems, n_rows, digests);
+        return;
+    }
     VK_LAUNCH(k_keccak_leaves<PtrCols>, dim3(blocks), dim3(256), 0, st, PtrCols{cols_dev}, n_elems, n_rows, digests);
 }
 void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
     ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
+    if (keccak_pairs_enabled() && n_rows <= KECCAK_PAIR_MAX_NODES) {
+        VK_LAUNCH(k_keccak_leaves_pair<StridedCols>, dim3((unsigned)((2 * n_rows + 255) / 256)), dim3(256), 0, st, StridedCols{base, stride}, n_elems, n_rows, digests);
+        return;
+    }
     VK_LAUNCH(k_keccak_leaves<StridedCols>, dim3(blocks), dim3(256), 0, st, StridedCols{base, stride}, n_elems, n_rows, digests);
 }
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
     unsigned blocks = (unsigned)((n_out + 255) / 256);
     ProfScope ps("k_keccak_compress", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * node_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
+    if (keccak_pairs_enabled() && n_out <= KECCAK_PAIR_MAX_NODES) {
+        VK_LAUNCH(k_keccak_compress_pair, dim3((unsigned)((2 * n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
+        return;
+    }
     VK_LAUNCH(k_keccak_compress, dim3(blocks), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
 }
 
