@@ -86,7 +86,18 @@ struct Fp {
         return r;
     }
     VG_HD Fp exp_power_of_2(unsigned k) const { Fp r = *this; for (unsigned i = 0; i < k; i++) r *= r; return r; }
-    VG_HD Fp inv() const { return pow(P - 2); }  // 0 -> 0
+    // x^(p-2), p - 2 = 7 * 2^28 + (2^27 - 1), by an addition chain: t = x^(2^27 - 1) (24 squarings, 6 products), w = t * x = x^(2^27),
+    // x^(7 * 2^28) = w^14 (3 squarings, 2 products): 37 products instead of square-and-multiply's 59.  0 -> 0.
+    VG_HD Fp inv() const {
+        const Fp x = *this;
+        const Fp x3 = x.square() * x, x7 = x3.square() * x;             // 2^2 - 1, 2^3 - 1
+        const Fp a6 = x7.exp_power_of_2(3) * x7;                         // 2^6 - 1
+        const Fp a12 = a6.exp_power_of_2(6) * a6;                        // 2^12 - 1
+        const Fp a24 = a12.exp_power_of_2(12) * a12;                     // 2^24 - 1
+        const Fp t = a24.exp_power_of_2(3) * x7;                         // 2^27 - 1
+        const Fp w = t * x, w2 = w.square(), w4 = w2.square(), w8 = w4.square();
+        return t * (w8 * w4 * w2);
+    }
     VG_HD Fp halve() const { return raw((v & 1) ? (uint32_t)(((uint64_t)v + P) >> 1) : v >> 1); }
 };
 

@@ -599,6 +599,26 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     return pw;
 }
 
+// k_reduce_openings' per-point table: g(X) = prod_{i=1..4} (X - frob^i z) = X^4 + g3 X^3 + .. + g0 over Ext5 and m(X) = (X - z) g(X), the minimal
+// polynomial of z over the base field (X^5 + m4 X^4 + .. + m0): 1/(z - x) = -g(x)/m(x) for x in the base field.  Words: [m0..m4][g0]..[g3].
+static void put_min_poly(std::vector<uint32_t>& w, const Ext5& z) {
+    Ext5 g[5] = {Ext5::one(), Ext5::zero(), Ext5::zero(), Ext5::zero(), Ext5::zero()};  // coefficients, low first; degree grows to 4
+    Ext5 conj = z;
+    for (int i = 1; i <= 4; i++) {
+        conj = conj.frobenius();
+        for (int k = i; k >= 1; k--) g[k] = g[k - 1] - conj * g[k];  // g *= (X - conj)
+        g[0] = Ext5::zero() - conj * g[0];
+    }
+    // m = (X - z) * g: m_k = g_{k-1} - z * g_k (g_5 = 0, g_{-1} = 0); every coefficient must land in the base field
+    Ext5 m[5];
+    for (int k = 0; k < 5; k++) m[k] = (k ? g[k - 1] : Ext5::zero()) - z * g[k];
+    for (int k = 0; k < 5; k++) {
+        for (int l = 1; l < 5; l++) if (!m[k].c[l].is_zero()) throw std::logic_error("open: minimal polynomial coefficient outside the base field");
+        w.push_back(m[k].c[0].v);
+    }
+    for (int k = 0; k < 4; k++) put_ext(w, g[k]);
+}
+
 // pcs.open_multi_batches (basic/src/lib.rs:611-619; Plonky3 TwoAdicFriPcs): opens every matrix of every
 // round at its points, reduces the openings per LDE height, runs the FRI commit phase, grinds, answers the queries.  `ch` is the
 // caller's transcript (the reference passes `&mut challenger`): it leaves advanced exactly as the reference leaves it.
@@ -746,7 +766,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                 pool.push_back((uint32_t)live.size());
                 pool.push_back(s1 - s0);
                 pool.push_back((uint32_t)max_w);
-                for (uint32_t q = s0; q < s1; q++) put_ext(pool, g.zs[q]);
+                for (uint32_t q = s0; q < s1; q++) put_min_poly(pool, g.zs[q]);
                 for (size_t col = 0; col < max_w; col++) put_ext(pool, apow[col]);
                 for (auto* me : live) {
                     put_ptr(pool, me->lde->data);

@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(64) k_col_dot_finish(const uint32_t* __restric
 // ---- reduced openings -----------------------------------------------------------------------------
 // Descriptor (u32 words, uniform loads) for one LDE height:
 //   [0] n_mats  [1] n_points  [2] max_width
-//   [3 .. 3 + 5*n_points)                       distinct opening points z_p (Ext5, Montgomery)
+//   [3 .. 3 + 25*n_points)                      per distinct opening point z_p: its minimal polynomial m_p over the base field, X^5 + m4 X^4 + .. + m0
+//                                               ([m0..m4], Montgomery), and g_p = m_p / (X - z_p) = X^4 + g3 X^3 + .. + g0 ([g0 (5)] .. [g3 (5)], Ext5)
 //   then alpha powers alpha^c, c < max_width      (5 words each)
 //   then per matrix: [col_ptr_lo] [col_ptr_hi] [stride_lo] [stride_hi] [width] [n_pts]
 //                    then n_pts x { [point slot] [coef: alpha^offset (5)] [Y = sum_c alpha^c y_c (5)] }
@@ -193,8 +194,8 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= L) return;
     const uint32_t n_mats = desc[0], n_points = desc[1], max_w = desc[2];
-    const uint32_t* zs = desc + 3;
-    const uint32_t* apow = zs + 5 * n_points;
+    const uint32_t* mg = desc + 3;
+    const uint32_t* apow = mg + 25 * n_points;
     const uint32_t* md = apow + 5 * max_w;
     Ext5 S[MAX_OPEN_POINTS];
 #pragma unroll
@@ -241,19 +242,38 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
             for (int p = 0; p < MAX_OPEN_POINTS; p++) if ((uint32_t)p == slot) S[p] += t;
         }
     }
-    Fp x = Fp::raw(shift) * domain_point(tb, (uint32_t)j);
-    // 1/(z_p - x) for all points with ONE Ext5 inversion (Montgomery's trick); denominators are nonzero
-    // (x lies on the coset 31*H, the z_p are out-of-domain challenges)
-    Ext5 d[MAX_OPEN_POINTS], pre[MAX_OPEN_POINTS];
-    Ext5 run = Ext5::one();
+    const Fp x = Fp::raw(shift) * domain_point(tb, (uint32_t)j);
+    // 1/(z_p - x) WITHOUT an extension-field inversion: x lies in the base field, so with m_p the minimal polynomial of z_p over it
+    // (m_p(X) = prod_i (X - frob^i z_p), coefficients in the base field) and g_p(X) = m_p(X) / (X - z_p) = prod_{i>=1} (X - frob^i z_p),
+    //     1 / (z_p - x) = -g_p(x) / m_p(x),        m_p(x) in the base field.
+    // The host ships m_p (5 words, monic) and g_p (4 Ext5, monic) per point; a row costs x^2..x^5, per point 19 multiply-adds for g_p(x) and
+    // m_p(x), and ONE base-field inversion for all points (Montgomery's trick) -- about 900 instructions where the Ext5 inversion with its
+    // prefix products cost 2100 (and this kernel spends most of its instructions per ROW, not per element: the tall matrices are narrow).
+    const Fp x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+    Ext5 gx[MAX_OPEN_POINTS];
+    Fp mx[MAX_OPEN_POINTS], pre[MAX_OPEN_POINTS];
+    Fp run = Fp::one();
 #pragma unroll
     for (int p = 0; p < MAX_OPEN_POINTS; p++)
-        if ((uint32_t)p < n_points) { d[p] = ext_from_words(zs + 5 * p) - x; pre[p] = run; run = run * d[p]; }
-    Ext5 inv_run = run.inv();
+        if ((uint32_t)p < n_points) {
+            const uint32_t* q = mg + 25 * p;
+            const uint64_t tm = (uint64_t)q[1] * x.v + (uint64_t)q[2] * x2.v + (uint64_t)q[3] * x3.v + (uint64_t)q[4] * x4.v;
+            mx[p] = Fp::raw(vg::monty_reduce_wide(tm)) + Fp::raw(q[0]) + x5;
+            const uint32_t* g = q + 5;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint64_t tg = (uint64_t)g[5 + k] * x.v + (uint64_t)g[10 + k] * x2.v + (uint64_t)g[15 + k] * x3.v;
+                gx[p].c[k] = Fp::raw(vg::monty_reduce_wide(tg)) + Fp::raw(g[k]);
+            }
+            gx[p].c[0] += x4;
+            pre[p] = run;
+            run = run * mx[p];
+        }
+    Fp inv_run = run.inv();
     Ext5 ro = Ext5::zero();
 #pragma unroll
     for (int p = MAX_OPEN_POINTS - 1; p >= 0; p--)
-        if ((uint32_t)p < n_points) { ro += S[p] * (inv_run * pre[p]); inv_run = inv_run * d[p]; }
+        if ((uint32_t)p < n_points) { ro -= (S[p] * gx[p]) * (inv_run * pre[p]); inv_run = inv_run * mx[p]; }
     const uint64_t half = L >> 1;
     if (accumulate) ro += load_ext(out + (j & 1) * 5 * half, half, j >> 1);
     store_ext(out + (j & 1) * 5 * half, half, j >> 1, ro);
