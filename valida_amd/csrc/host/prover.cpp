@@ -683,7 +683,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                 }
             }
         }
-        for (auto& w : wlist) { w.pool_off = pool.size(); put_ext(pool, w.z); }
+        for (auto& w : wlist) { w.pool_off = pool.size(); put_min_poly(pool, w.z); }
         pool.push_back(0);
         DBuf pool_dev(&c, pool);
         for (auto& w : wlist) {

@@ -78,7 +78,7 @@ void launch_tracegen_idle(hipStream_t st, int mode, const uint32_t* static_cells
 hipError_t launch_tracegen_range(hipStream_t st, const TgAluOp* add_ops, uint64_t n_add, const TgAluOp* sub_ops, uint64_t n_sub, uint32_t* counts, DMatView t);
 hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t n, uint64_t padded_n, uint32_t rom_len, uint32_t* counts, DMatView t);
 // open.hip
-void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w);
+void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* min_poly_dev, Fp shift, const DeviceTables& tb, uint32_t* w);
 uint64_t col_dot_slots(uint64_t n);
 uint64_t col_dot_max_columns(int np);  // widest matrix (view) one k_col_dot launch takes for np points; wider ones are opened in column chunks
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,

@@ -18,30 +18,39 @@ namespace vk {
 // The first n storage rows of a bit-reversed LDE are the evaluations on s*H_n in bit-reversed order:
 // row j <-> x_j = s * r_j, r_j = w_n^{bitrev(j)}.  p(z) = scale * sum_j y_j * r_j / (z - s r_j) with
 // scale = (z^n - s^n) / (n s^{n-1}) applied on the host.  w: 5 columns of height n (stride n).
-// Four consecutive rows per thread share ONE Ext5 inversion (Montgomery's trick: 9 products + 1 inverse instead of 4 inverses).
+// 1/(z - x) = -g(x)/m(x) with m the minimal polynomial of z over the base field and g = m/(X - z) (see k_reduce_openings; the host ships
+// [m0..m4][g0..g3] per point): no extension-field inversion.  Four consecutive rows per thread share ONE base-field inversion.
 constexpr int BARY_ROWS = 4;
-__global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t* __restrict__ z5, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ w) {
+__global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t* __restrict__ mg, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ w) {
     const uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * BARY_ROWS;
     if (j0 >= n) return;
-    const Ext5 z = ext_from_words(z5);
-    Fp r[BARY_ROWS];
-    Ext5 d[BARY_ROWS], pre[BARY_ROWS];
-    Ext5 run = Ext5::one();
+    const uint32_t* g = mg + 5;
+    Fp r[BARY_ROWS], mx[BARY_ROWS], pre[BARY_ROWS];
+    Ext5 gx[BARY_ROWS];
+    Fp run = Fp::one();
 #pragma unroll
     for (int q = 0; q < BARY_ROWS; q++) {
         const bool live = j0 + q < n;
         r[q] = live ? domain_point(tb, (uint32_t)(j0 + q)) : Fp::one();
-        d[q] = live ? z - Fp::raw(shift) * r[q] : Ext5::one();  // z is out of the domain: never zero
+        const Fp x = Fp::raw(shift) * r[q], x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+        const uint64_t tm = (uint64_t)mg[1] * x.v + (uint64_t)mg[2] * x2.v + (uint64_t)mg[3] * x3.v + (uint64_t)mg[4] * x4.v;
+        mx[q] = Fp::raw(vg::monty_reduce_wide(tm)) + Fp::raw(mg[0]) + x5;  // z is out of the domain: never zero
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint64_t tg = (uint64_t)g[5 + k] * x.v + (uint64_t)g[10 + k] * x2.v + (uint64_t)g[15 + k] * x3.v;
+            gx[q].c[k] = Fp::raw(vg::monty_reduce_wide(tg)) + Fp::raw(g[k]);
+        }
+        gx[q].c[0] += x4;
         pre[q] = run;
-        run = q == 0 ? d[0] : run * d[q];
+        run = run * mx[q];
     }
-    Ext5 inv = run.inv();
+    Fp inv = run.inv();
     Ext5 res[BARY_ROWS];
 #pragma unroll
     for (int q = BARY_ROWS - 1; q >= 0; q--) {
-        const Ext5 dinv = q == 0 ? inv : inv * pre[q];
-        if (q > 0) inv = inv * d[q];
-        res[q] = dinv * r[q];
+        const Fp minv = inv * pre[q];
+        inv = inv * mx[q];
+        res[q] = gx[q] * (-(minv * r[q]));
     }
     if (j0 + BARY_ROWS <= n) {  // n >= 4 is a power of two: the four rows of a limb are one aligned 16-byte store
 #pragma unroll
@@ -444,10 +453,10 @@ void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pendin
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
-void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* z5_dev, Fp shift, const DeviceTables& tb, uint32_t* w) {
+void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* min_poly_dev, Fp shift, const DeviceTables& tb, uint32_t* w) {
     ProfScope ps("k_bary_weights", st, 20.0 * n);
     const uint64_t threads = (n + BARY_ROWS - 1) / BARY_ROWS;
-    VK_LAUNCH(k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n, z5_dev, shift.v, tb, w);
+    VK_LAUNCH(k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n, min_poly_dev, shift.v, tb, w);
 }
 uint64_t col_dot_slots(uint64_t n) {
     uint64_t tiles = (n + DOT_TR - 1) / DOT_TR;
