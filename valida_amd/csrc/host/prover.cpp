@@ -688,7 +688,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         DBuf pool_dev(&c, pool);
         for (auto& w : wlist) {
             uint64_t n = 1ull << w.log_n;
-            w.buf = DBuf(&c, (size_t)(5 * n));
+            w.buf = DBuf(&c, (size_t)vk::bary_buffer_words(n));
             vk::launch_bary_weights(c.stream, n, pool_dev.data + w.pool_off, s, c.tables, w.buf.data);
         }
         DBuf out_dev(&c, out_words + 4);

@@ -80,6 +80,7 @@ hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t 
 // open.hip
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* min_poly_dev, Fp shift, const DeviceTables& tb, uint32_t* w);
 uint64_t col_dot_slots(uint64_t n);
+uint64_t bary_buffer_words(uint64_t n);  // words of a weight vector launch_bary_weights fills (launch_col_dot takes such buffers)
 uint64_t col_dot_max_columns(int np);  // widest matrix (view) one k_col_dot launch takes for np points; wider ones are opened in column chunks
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
                     const uint32_t* scale5_dev, uint32_t* out_dev);

@@ -21,7 +21,10 @@ namespace vk {
 // 1/(z - x) = -g(x)/m(x) with m the minimal polynomial of z over the base field and g = m/(X - z) (see k_reduce_openings; the host ships
 // [m0..m4][g0..g3] per point): no extension-field inversion.  Four consecutive rows per thread share ONE base-field inversion.
 constexpr int BARY_ROWS = 4;
-__global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t* __restrict__ mg, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ w) {
+// For n >= MFMA_DOT_MIN_ROWS the kernel also writes the weights as k_col_dot_mfma's A operand (`img`, see there): 7-bit digit planes, four rows
+// to a word, laid out so that a lane of that kernel fetches its four operand registers of a plane with one 16-byte load.
+__global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t* __restrict__ mg, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ w,
+                                                      uint32_t* __restrict__ img) {
     const uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * BARY_ROWS;
     if (j0 >= n) return;
     const uint32_t* g = mg + 5;
@@ -51,6 +54,18 @@ __global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t
         const Fp minv = inv * pre[q];
         inv = inv * mx[q];
         res[q] = gx[q] * (-(minv * r[q]));
+    }
+    if (img) {  // n is a multiple of 64 here
+        const uint64_t slab = j0 >> 6, gg = (j0 >> 4) & 3, qq = (j0 >> 2) & 3;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int a = 0; a < 5; a++) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int q = 0; q < BARY_ROWS; q++) word |= ((res[q].c[k].v >> (7 * a)) & 0x7fu) << (8 * q);
+                img[((((slab * 5 + a) * 4 + gg) * 5 + k) << 2) + qq] = word;
+            }
     }
     if (j0 + BARY_ROWS <= n) {  // n >= 4 is a power of two: the four rows of a limb are one aligned 16-byte store
 #pragma unroll
@@ -167,6 +182,92 @@ __global__ void __launch_bounds__(DOT_THREADS) k_col_dot(DMatView m, uint64_t n,
     for (int q = 0; q < DOT_MAX_PASSES; q++) {
         int idx = q * DOT_THREADS + threadIdx.x;
         if (idx < n_out) partial[(uint64_t)blockIdx.x * n_out + idx] = acc[q].reduce().v;
+    }
+}
+
+// ---- the same product on the matrix cores --------------------------------------------------------------
+// Y = W^T M is a skinny GEMM ((5 NP) x n times n x C) over F_p, and exact in integers if the operands are cut into 7-bit digits:
+// W = sum_a 128^a W_a, M = sum_b 128^b M_b, so Y = sum_s 128^s sum_{a+b=s} W_a^T M_b with every W_a^T M_b an i8 x i8 -> i32 MFMA
+// (v_mfma_i32_16x16x64_i8: 16 output rows = the 5 NP limbs, 16 columns of M, 64 rows of the reduction per instruction; nine i32
+// accumulator tiles, one per s, hold 16384 rows without overflow: 5 * 127^2 * 16384 < 2^31).  A wave owns 16 columns x one chunk of rows;
+// per 64 rows it loads its 16 values (four 16-byte loads), cuts them into the five digit planes (the only VALU work left: ~9 instructions
+// per element where the LDS-fed multiply-add loop above needs ~40), fetches the weights' planes ready-made (k_bary_weights' `img`) and
+// issues 25 MFMAs.  Operand convention checked on the device by tools/mfma_i8_probe.hip: lane l holds row / column l % 16 and
+// k = 16 (l / 16) .. + 15 in the bytes of its four registers, the same map for A and B; D at column l & 15, rows 4 (l >> 4) + r.
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr uint64_t MFMA_DOT_MIN_ROWS = 1024, MFMA_DOT_MAX_CHUNK = 16384;
+__host__ __device__ inline uint64_t mfma_dot_chunk_rows(uint64_t n) {
+    uint64_t c = n / 2048;  // up to 2048 row chunks x ceil(C / 16) column groups of waves
+    return c < 64 ? 64 : (c > MFMA_DOT_MAX_CHUNK ? MFMA_DOT_MAX_CHUNK : c);
+}
+
+template <int NP>
+__global__ void __launch_bounds__(256) k_col_dot_mfma(DMatView m, uint64_t n, const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, uint64_t chunk_rows,
+                                                      uint32_t* __restrict__ partial) {
+    constexpr int PK = NP * 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const uint64_t C = m.width, n_groups = (C + 15) / 16, n_chunks = n / chunk_rows;
+    const uint64_t item = (uint64_t)blockIdx.x * 4 + wave;
+    if (item >= n_groups * n_chunks) return;
+    const uint64_t group = item % n_groups, chunk = item / n_groups;
+    const uint64_t c = group * 16 + j;
+    // lanes beyond the 5 NP limbs / beyond the last column compute output rows / columns nobody reads: they load valid memory and are not masked
+    const bool col_live = c < C;
+    const uint32_t* img = (j < 5 || NP == 1) ? img0 : img1;
+    const int limb = j % 5;
+    const uint32_t* colp = m.data + (col_live ? c : 0) * m.stride + 16 * g;
+    v4i acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; s++) acc[s] = v4i{0, 0, 0, 0};
+    const uint64_t slab0 = chunk * chunk_rows / 64, slab1 = slab0 + chunk_rows / 64;
+    // software pipeline: the NEXT slab's operands are in flight while this one is cut into digits and multiplied
+    v4i A[5], An[5];
+    uint4 v[4], vn[4];
+    auto fetch = [&](uint64_t slab, v4i (&a5)[5], uint4 (&v4)[4]) {
+#pragma unroll
+        for (int a = 0; a < 5; a++) a5[a] = *reinterpret_cast<const v4i*>(img + ((((slab * 5 + a) * 4 + g) * 5 + limb) << 2));
+        const uint4* src = reinterpret_cast<const uint4*>(colp + slab * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) v4[q] = src[q];
+    };
+    fetch(slab0, A, v);
+    for (uint64_t slab = slab0; slab < slab1; slab++) {
+        fetch(slab + 1 < slab1 ? slab + 1 : slab, An, vn);  // the last iteration re-reads its own slab (no branch around the loads)
+        v4i B[5];
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t d0 = __builtin_amdgcn_ubfe(v[q].x, 7 * a, 7), d1 = __builtin_amdgcn_ubfe(v[q].y, 7 * a, 7);
+                const uint32_t d2 = __builtin_amdgcn_ubfe(v[q].z, 7 * a, 7), d3 = __builtin_amdgcn_ubfe(v[q].w, 7 * a, 7);
+                B[a][q] = (int)(d0 | (d1 << 8) | (d2 << 16) | (d3 << 24));
+            }
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int b = 0; b < 5; b++) acc[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a], B[b], acc[a + b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 5; a++) A[a] = An[a];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = vn[q];
+    }
+    // Y'(pk, c) = sum_s 128^s acc[s] is the INTEGER sum of products of the stored (Montgomery) words; the stored word of the field product
+    // is Y' / 2^32 mod p: evaluate in F_p (stored = Y' 2^32), then two Montgomery reductions
+    Fp pw[9];
+    pw[0] = Fp::one();
+    const Fp step = Fp::from_canonical(128);
+#pragma unroll
+    for (int s = 1; s < 9; s++) pw[s] = pw[s - 1] * step;
+    const uint64_t n_out = C * PK;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pk = 4 * g + r;
+        if (pk < PK && col_live) {
+            Fp y = Fp::zero();
+#pragma unroll
+            for (int s = 0; s < 9; s++) y += Fp::from_canonical((uint32_t)acc[s][r]) * pw[s];
+            partial[chunk * n_out + c * PK + pk] = vg::monty_reduce((uint64_t)vg::monty_reduce((uint64_t)y.v));
+        }
     }
 }
 
@@ -453,12 +554,15 @@ void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pendin
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
+// w: bary_buffer_words(n) words: 5 columns of height n, then (n >= MFMA_DOT_MIN_ROWS) the digit-plane image of the same weights
+uint64_t bary_buffer_words(uint64_t n) { return 5 * n + (n >= MFMA_DOT_MIN_ROWS ? (n / 64) * 400 : 0); }
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* min_poly_dev, Fp shift, const DeviceTables& tb, uint32_t* w) {
     ProfScope ps("k_bary_weights", st, 20.0 * n);
     const uint64_t threads = (n + BARY_ROWS - 1) / BARY_ROWS;
-    VK_LAUNCH(k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n, min_poly_dev, shift.v, tb, w);
+    VK_LAUNCH(k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n, min_poly_dev, shift.v, tb, w, n >= MFMA_DOT_MIN_ROWS ? w + 5 * n : (uint32_t*)nullptr);
 }
 uint64_t col_dot_slots(uint64_t n) {
+    if (n >= MFMA_DOT_MIN_ROWS) return n / mfma_dot_chunk_rows(n);
     uint64_t tiles = (n + DOT_TR - 1) / DOT_TR;
     return tiles < (uint64_t)DOT_MAX_BLOCKS ? tiles : (uint64_t)DOT_MAX_BLOCKS;
 }
@@ -471,6 +575,14 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
     const int pk = np * 5;
     size_t lds = (size_t)DOT_TRP * (m.width + pk) * 4;
     ProfScope ps("k_col_dot", st, 4.0 * n * (m.width + 5.0 * np));
+    if (n >= MFMA_DOT_MIN_ROWS) {  // matrix cores; w0 / w1 are bary_buffer_words(n) buffers: the digit planes follow the five weight columns
+        const uint64_t chunk = mfma_dot_chunk_rows(n), items = ((m.width + 15) / 16) * (n / chunk);
+        const unsigned grid = (unsigned)((items + 3) / 4);
+        if (np == 1) VK_LAUNCH(k_col_dot_mfma<1>, dim3(grid), dim3(256), 0, st, m, n, w0 + 5 * n, w1 + 5 * n, chunk, partial);
+        else VK_LAUNCH(k_col_dot_mfma<2>, dim3(grid), dim3(256), 0, st, m, n, w0 + 5 * n, w1 + 5 * n, chunk, partial);
+        VK_LAUNCH(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
+        return;
+    }
     if (np == 1) VK_LAUNCH(k_col_dot<1>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
     else VK_LAUNCH(k_col_dot<2>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
     VK_LAUNCH(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
