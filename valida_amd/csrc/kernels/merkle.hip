@@ -242,15 +242,17 @@ void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
         bytes += (double)(a.first_len >> l) * (96.0 + 4.0 * a.n_elems[l]);
         perms += (double)(a.first_len >> l) * node_perms(a.n_elems[l]);
     }
-    ProfScope ps("k_keccak_top", st, bytes, perms * KECCAK_VALU_PER_PERM / 64.0);
-    if (keccak_pairs_enabled() && a.first_len <= 512) { VK_LAUNCH(k_keccak_top_pair, dim3(1), dim3(1024), 0, st, a); return; }
+    const bool pairs = keccak_pairs_enabled() && a.first_len <= 512;
+    ProfScope ps(pairs ? "k_keccak_top_pair" : "k_keccak_top", st, bytes, perms * KECCAK_VALU_PER_PERM / 64.0);
+    if (pairs) { VK_LAUNCH(k_keccak_top_pair, dim3(1), dim3(1024), 0, st, a); return; }
     VK_LAUNCH(k_keccak_top, dim3(1), dim3(1024), 0, st, a);
 }
 
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
-    ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
-    if (keccak_pairs_enabled() && n_rows <= KECCAK_PAIR_MAX_NODES) {
+    const bool pairs = keccak_pairs_enabled() && n_rows <= KECCAK_PAIR_MAX_NODES;
+    ProfScope ps(pairs ? "k_keccak_leaves_pair" : "k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
+    if (pairs) {
         VK_LAUNCH(k_keccak_leaves_pair<PtrCols>, dim3((unsigned)((2 * n_rows + 255) / 256)), dim3(256), 0, st, PtrCols{cols_dev}, n_elems, n_rows, digests);
         return;
     }
@@ -258,8 +260,9 @@ void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n
 }
 void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
-    ProfScope ps("k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
-    if (keccak_pairs_enabled() && n_rows <= KECCAK_PAIR_MAX_NODES) {
+    const bool pairs = keccak_pairs_enabled() && n_rows <= KECCAK_PAIR_MAX_NODES;
+    ProfScope ps(pairs ? "k_keccak_leaves_pair" : "k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
+    if (pairs) {
         VK_LAUNCH(k_keccak_leaves_pair<StridedCols>, dim3((unsigned)((2 * n_rows + 255) / 256)), dim3(256), 0, st, StridedCols{base, stride}, n_elems, n_rows, digests);
         return;
     }
@@ -267,8 +270,9 @@ void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t
 }
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
     unsigned blocks = (unsigned)((n_out + 255) / 256);
-    ProfScope ps("k_keccak_compress", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * node_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
-    if (keccak_pairs_enabled() && n_out <= KECCAK_PAIR_MAX_NODES) {
+    const bool pairs = keccak_pairs_enabled() && n_out <= KECCAK_PAIR_MAX_NODES;
+    ProfScope ps(pairs ? "k_keccak_compress_pair" : "k_keccak_compress", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * node_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
+    if (pairs) {
         VK_LAUNCH(k_keccak_compress_pair, dim3((unsigned)((2 * n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
         return;
     }

@@ -574,7 +574,7 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
     unsigned blocks = (unsigned)col_dot_slots(n);
     const int pk = np * 5;
     size_t lds = (size_t)DOT_TRP * (m.width + pk) * 4;
-    ProfScope ps("k_col_dot", st, 4.0 * n * (m.width + 5.0 * np));
+    ProfScope ps(n >= MFMA_DOT_MIN_ROWS ? "k_col_dot_mfma" : "k_col_dot", st, 4.0 * n * (m.width + 5.0 * np));
     if (n >= MFMA_DOT_MIN_ROWS) {  // matrix cores; w0 / w1 are bary_buffer_words(n) buffers: the digit planes follow the five weight columns
         const uint64_t chunk = mfma_dot_chunk_rows(n), items = ((m.width + 15) / 16) * (n / chunk);
         const unsigned grid = (unsigned)((items + 3) / 4);
