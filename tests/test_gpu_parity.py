@@ -699,13 +699,17 @@ def test_proof_assembled_from_fine_grained_calls_is_the_same_proof(machine, rc, 
         assert first_mismatch(q[nat], dbg.debug_quotient(i)) is None
 
 
-def test_open_multi_batches_generic_shapes_match_oracle(machine, rc):
+@pytest.mark.parametrize("shapes", [
+    [[(64, 130), (64, 3)], [(256, 2), (8, 7), (1, 4)]],                       # every matrix below the matrix-core threshold (VALU k_col_dot)
+    [[(2048, 130), (1024, 3)], [(4096, 17), (1024, 33), (64, 5)]],            # k_col_dot_mfma: column groups of 16 with ragged tails, chunked columns
+])
+def test_open_multi_batches_generic_shapes_match_oracle(machine, rc, shapes):
     """Shapes Machine::prove never produces: one round with a 130-column matrix (column chunks in k_col_dot), five points on one
     matrix (point chunks, > 4 distinct points on one LDE height), a second round with mixed heights — against the oracle's
     pcs.commit_batches + open_multi_batches on the same matrices, points and transcript prefix."""
     p = va.Prover(machine, rc, num_queries=9, pow_bits=3)
     rng = np.random.default_rng(99)
-    rounds = [[rand_matrix(rng, 64, 130), rand_matrix(rng, 64, 3)], [rand_matrix(rng, 256, 2), rand_matrix(rng, 8, 7), rand_matrix(rng, 1, 4)]]
+    rounds = [[rand_matrix(rng, h, w) for h, w in rnd] for rnd in shapes]
     ext = lambda: [int(x) for x in rng.integers(1, P, 5)]
     pts = [ext() for _ in range(6)]
     points = [[[pts[0]], [pts[0], pts[1], pts[2], pts[3], pts[4]]], [[pts[5], pts[0]], [pts[1]], [pts[2], pts[3], pts[4]]]]
