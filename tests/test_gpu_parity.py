@@ -880,3 +880,46 @@ def test_uploads_beside_a_running_proof(machine, rc):
     got.append(ticket.wait().words.copy())
     for i, g in enumerate(got):
         assert first_mismatch(g, want[i % len(ws)]) is None, i
+
+
+@pytest.mark.gpu
+def test_traces_of_another_context_of_the_same_device(machine, rc):
+    """A side context uploads the operation logs and generates segment i+1's traces while the proving context is busy with segment i:
+    vgpu_prove(_async) accepts those handles (same device), waits for the side context's queued work, and gives the same proofs."""
+    p, side = va.Prover(machine, rc), va.Prover(machine, rc)
+    ws = [va.Workload.fib(1500 + 11 * k) for k in range(3)]
+    small = [i for i in range(va.NUM_CHIPS) if i not in va.GENERATED_CHIPS]
+    prep = [(c, p.upload(m)) for c, m in ws[0].preprocessed()]
+    want = [p.prove([p.upload(w.main_trace(c)) for c in range(va.NUM_CHIPS)], prep).words.copy() for w in ws]
+    ticket, got = None, []
+    for rep in range(2):
+        for w in ws:
+            log = side.upload_oplog(w.oplog())
+            tr = {c: side.generate_trace(log, c) for c in va.GENERATED_CHIPS}
+            tr.update({c: side.upload(w.main_trace(c)) for c in small})
+            if ticket is not None:
+                got.append(ticket.wait().words.copy())
+            ticket = p.prove_async([tr[c] for c in range(va.NUM_CHIPS)], prep, keep=(log, side))
+            del tr, log  # the ticket keeps what it works on alive
+    got.append(ticket.wait().words.copy())
+    for i, g in enumerate(got):
+        assert first_mismatch(g, want[i % len(ws)]) is None, i
+    sync = p.prove([side.upload(ws[0].main_trace(c)) for c in range(va.NUM_CHIPS)], prep)
+    assert first_mismatch(sync.words, want[0]) is None
+
+
+@pytest.mark.gpu
+def test_second_proof_on_a_busy_context_is_refused(machine, rc):
+    """One proof at a time per prover context: a second vgpu_prove_async while a ticket is outstanding fails cleanly (INVALID_ARG from its
+    own ticket) and does not disturb the first."""
+    p = va.Prover(machine, rc)
+    w = va.Workload.fib(3000)
+    main = [p.upload(w.main_trace(c)) for c in range(va.NUM_CHIPS)]
+    prep = [(c, p.upload(m)) for c, m in w.preprocessed()]
+    want = p.prove(main, prep).words.copy()
+    t1 = p.prove_async(main, prep)
+    t2 = p.prove_async(main, prep)
+    with pytest.raises(va.VgpuError) as e:
+        t2.wait()
+    assert "already running" in str(e.value)
+    assert first_mismatch(t1.wait().words, want) is None

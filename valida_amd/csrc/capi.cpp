@@ -1,6 +1,7 @@
 // extern "C" surface of libvgpu.so — see include/vgpu.h for the contract and the reference item each
 // entry point replaces.
 #include "../../include/vgpu.h"
+#include <algorithm>
 #include <cstring>
 #include <future>
 #include <memory>
@@ -617,10 +618,17 @@ int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uin
     })
 }
 
-// a trace handle handed to prove must exist and live in THIS prover's context (its stream and pool order the accesses)
-static void check_trace(const vgpu_prover_t* p, const vgpu_trace_t* t) {
+// A trace handle handed to prove must exist and live on THIS prover's device.  Traces of another context of the same device (a host that
+// uploads / generates segment i+1 on a context of its own while this one proves segment i) are accepted: `foreign` collects their
+// contexts, which the caller drains (their queued work must have produced the traces) and keeps alive for the duration of the proof.
+static void check_trace(const vgpu_prover_t* p, const vgpu_trace_t* t, std::vector<std::shared_ptr<Prover>>* foreign = nullptr) {
     if (!t || !t->t) throw std::invalid_argument("null trace");
-    if (t->owner != p->p) throw std::invalid_argument("trace belongs to another prover context");
+    if (t->owner == p->p) return;
+    if (!foreign || t->owner->ctx().device != p->p->ctx().device) throw std::invalid_argument("trace belongs to another prover context");
+    if (std::find(foreign->begin(), foreign->end(), t->owner) == foreign->end()) foreign->push_back(t->owner);
+}
+static void drain(const std::vector<std::shared_ptr<Prover>>& ctxs) {
+    for (auto& q : ctxs) { q->ctx().activate(); q->ctx().sync(); }
 }
 
 int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips, const vgpu_trace_t* const* prep,
@@ -628,9 +636,11 @@ int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n
     VG_TRY({
         if (!p || !main || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
         std::vector<const DeviceTrace*> m;
-        for (uint32_t i = 0; i < n_main; i++) { check_trace(p, main[i]); m.push_back(main[i]->t.get()); }
+        std::vector<std::shared_ptr<Prover>> foreign;
+        for (uint32_t i = 0; i < n_main; i++) { check_trace(p, main[i], &foreign); m.push_back(main[i]->t.get()); }
         std::vector<std::pair<int, const DeviceTrace*>> pr;
-        for (uint32_t i = 0; i < n_prep; i++) { check_trace(p, prep[i]); pr.push_back({(int)prep_chips[i], prep[i]->t.get()}); }
+        for (uint32_t i = 0; i < n_prep; i++) { check_trace(p, prep[i], &foreign); pr.push_back({(int)prep_chips[i], prep[i]->t.get()}); }
+        drain(foreign);
         auto proof = std::make_unique<vgpu_proof>();
         proof->dbg.keep_matrices = (debug_flags & 1) != 0;
         proof->dbg.check_constraints = (debug_flags & 2) != 0;
@@ -651,12 +661,14 @@ int32_t vgpu_prove_async(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint
             std::shared_ptr<Prover> prover;
             std::vector<std::shared_ptr<DeviceTrace>> main, prep;
             std::vector<int> chips;
+            std::vector<std::shared_ptr<Prover>> foreign;  // other contexts whose pools own some of the traces
         };
         auto job = std::make_shared<Job>();
         job->prover = p->p;
         if (n_prep && (!prep || !prep_chips)) throw std::invalid_argument("null argument");
-        for (uint32_t i = 0; i < n_main; i++) { check_trace(p, main[i]); job->main.push_back(main[i]->t); }
-        for (uint32_t i = 0; i < n_prep; i++) { check_trace(p, prep[i]); job->prep.push_back(prep[i]->t); job->chips.push_back((int)prep_chips[i]); }
+        for (uint32_t i = 0; i < n_main; i++) { check_trace(p, main[i], &job->foreign); job->main.push_back(main[i]->t); }
+        for (uint32_t i = 0; i < n_prep; i++) { check_trace(p, prep[i], &job->foreign); job->prep.push_back(prep[i]->t); job->chips.push_back((int)prep_chips[i]); }
+        drain(job->foreign);
         std::unique_ptr<vgpu_ticket> t(new vgpu_ticket());
         t->result = std::async(std::launch::async, [job]() {
             std::pair<int32_t, std::string> status{VGPU_OK, ""};

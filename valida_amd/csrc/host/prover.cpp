@@ -286,9 +286,11 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
                                     PhaseTimes* times, ProveDebugOut* dbg) {
     DeviceCtx& c = *ctx_;
     c.activate();
-    struct Running {
+    struct Running {  // one proof at a time per context: its streams, pool sections and pinned buffers are not shared
         std::atomic<int>& n;
-        explicit Running(std::atomic<int>& a) : n(a) { n.fetch_add(1); }
+        explicit Running(std::atomic<int>& a) : n(a) {
+            if (n.fetch_add(1) != 0) { n.fetch_sub(1); throw std::invalid_argument("prove: another proof is already running on this prover context (wait for its ticket first)"); }
+        }
         ~Running() { n.fetch_sub(1); }
     } running(c.proofs_running);
     const size_t NC = machine_.airs.size();
