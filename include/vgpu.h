@@ -276,6 +276,21 @@ int32_t vgpu_commit_batches_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const v
  * are device-to-device copies.  mats[r * n_mats + i] = matrix i as uploaded through provers[r]. */
 int32_t vgpu_commit_batches_sharded_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* mats, uint32_t n_mats,
                                           const uint32_t* coset_shifts, uint32_t root[8]);
+/* The WHOLE of Machine::prove (basic/src/lib.rs:147-675) for one proof over the ranks of `comm`: every committed LDE, every Merkle
+ * tree, the quotient evaluation, the opened values, the reduced openings and the FRI layers live and are computed in row-range shards
+ * (a rank's row range of a bit-reversed LDE on s H_L is the sub-coset s w_L^e H_{L/W}, again bit-reversed: the single-GPU kernels run on
+ * it with a shifted coset); the transcript is replicated.  Exchanges per proof: an all-to-all (columns -> row ranges) and a roots
+ * all-gather per commitment round, one halo exchange (the successor shard) and one all-to-all (rows -> columns) around the quotient,
+ * an all-gather of partial opened values, a roots all-gather per sharded FRI layer, an all-gather of the proof tail.  Every rank
+ * passes the SAME traces (they are replicated; what a proof's memory goes into — LDEs, trees, FRI layers — is sharded) and
+ * receives the SAME proof words vgpu_prove gives on one GPU.  Matrices whose LDE has fewer than max(4 world, 2^log_min_sharded) rows
+ * are computed whole by every rank.  Needs log_blowup = 1 and chips of log_quotient_degree 1; world must be a power of two. */
+int32_t vgpu_prove_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
+                           const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out);
+/* The same with `world` prover contexts of THIS process standing in for the ranks (device-to-device copies for the exchanges):
+ * main[r * n_main + i] / prep[r * n_prep + k] = the traces as uploaded through provers[r]. */
+int32_t vgpu_prove_sharded_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* main, uint32_t n_main,
+                                 const uint32_t* prep_chips, const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out);
 
 /* ---- trace generation on the device: Chip::generate_trace (machine/src/chip.rs:22) of the big
  * BasicMachine chips as kernels, fed by the VM's operation logs instead of host-built RowMajorMatrix traces.

@@ -1,0 +1,116 @@
+"""§8(f)-4 completed: ONE proof over W ranks (vgpu_prove_sharded / vgpu_prove_sharded_local) must be, word for word, the proof
+vgpu_prove produces on one GPU (which the parity suite bit-matches against the oracle).  `world` prover contexts on this box's single GPU
+stand in for the ranks (exchanges = device-to-device copies); over RCCL the same phases run with one rank per process — a world of one
+exercises that fabric here.
+
+Run on the MI355X box with `pytest -m gpu`.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import valida_amd as va
+from conftest import first_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+def where(words, at, n_chips=14):
+    """Name the region of the flat "VPF1" proof (DESIGN.md "Proof wire format") word `at` lies in: which stage of the sharded prover went wrong."""
+    if at < 2:
+        return "header"
+    if at < 26:
+        return ["main root", "permutation root", "quotient root"][(at - 2) // 8]
+    pos = 26
+    for chip in range(n_chips):
+        start = pos
+        pos += 1
+        for vec in range(5):
+            ln = int(words[pos])
+            pos += 1 + 5 * ln
+            if at < pos:
+                return "chip %d: opened vector %d (0/1 main at zeta / zeta g, 2/3 permutation, 4 quotient chunks)" % (chip, vec)
+        pos += 5
+        if at < pos:
+            return "chip %d: cumulative sum" % chip
+        assert start < pos
+    tail = at - pos
+    n_commits = int(words[pos])
+    if tail < 1 + 8 * n_commits:
+        return "FRI commit-phase root of layer %d" % ((tail - 1) // 8)
+    return "proof tail word %d (after the %d FRI roots: query openings / final polynomial / proof of work)" % (tail, n_commits)
+
+
+def assert_same_proof(got, want):
+    d = first_mismatch(got, want)
+    if d is not None:
+        at = int(np.nonzero(np.asarray(got).ravel()[: len(want)] != np.asarray(want).ravel()[: len(got)])[0][0]) if len(got) == len(want) else 0
+        raise AssertionError("%s -- first difference in: %s" % (d, where(want, at)))
+
+
+def single_and_inputs(machine, rc, workload, **cfg):
+    p = va.Prover(machine, rc, **cfg)
+    mt, prep = workload.main_traces(), workload.preprocessed()
+    proof = p.prove([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep])
+    return p, mt, prep, proof
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sharded_proof_of_fib25_is_the_single_gpu_proof(machine, rc, fib25, world):
+    """prove_fibonacci (basic/tests/test_prover.rs:473-486) with every chip above 4 * world LDE rows sharded: cpu / mem / add / mul / range /
+    program in row ranges (the two preprocessed traces included: halo of all three LDEs), the height-1 chips replicated and injected at the
+    subtree roots (world 2) or above them (world 4, 8); every FRI layer down to 4 * world elements sharded."""
+    p0, mt, prep, single = single_and_inputs(machine, rc, fib25)
+    provers = [p0] + [va.Prover(machine, rc) for _ in range(world - 1)]
+    sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=2)
+    assert_same_proof(sharded.words, single.words)
+
+
+@pytest.mark.parametrize("world,log_min", [(4, 12), (2, 10)])
+def test_sharded_proof_with_sharded_and_replicated_chips(machine, rc, world, log_min):
+    """fib(582): cpu 2^12 / mem 2^14 / add 2^12 rows sharded (shards of >= 1024 rows: the matrix-core opened values, strided NTT passes),
+    mul / range / program and the height-1 chips below the threshold: computed whole by every rank, row ranges of their LDEs hashed into the subtrees."""
+    w = va.Workload.fib(582)
+    p0, mt, prep, single = single_and_inputs(machine, rc, w)
+    provers = [p0] + [va.Prover(machine, rc) for _ in range(world - 1)]
+    sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=log_min)
+    assert_same_proof(sharded.words, single.words)
+
+
+def test_sharded_proof_of_the_alu_workload(machine, rc):
+    """C4's program (add, sub, xor / and / or, lt: six busy chips, wide bitwise and lt traces) over four ranks."""
+    w = va.Workload.alu(300)
+    p0, mt, prep, single = single_and_inputs(machine, rc, w)
+    provers = [p0] + [va.Prover(machine, rc) for _ in range(3)]
+    sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=6)
+    assert_same_proof(sharded.words, single.words)
+
+
+def test_sharded_proof_with_the_poseidon_mmcs(machine, rc, fib25):
+    p0, mt, prep, single = single_and_inputs(machine, rc, fib25, hash_kind=va.HASH_POSEIDON16)
+    provers = [p0, va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16)]
+    sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=3)
+    assert_same_proof(sharded.words, single.words)
+
+
+def test_sharded_proof_over_the_rccl_fabric_world_of_one(machine, rc, fib25):
+    """The RCCL realisation (one rank per process) on this box's single GPU: a world of one runs every phase through the communicator's
+    all-gather / grouped send-recv call paths."""
+    p, mt, prep, single = single_and_inputs(machine, rc, fib25)
+    comm = va.Comm(p, va.Comm.unique_id(), 0, 1)
+    sharded = comm.prove_sharded([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep], log_min_sharded=4)
+    assert_same_proof(sharded.words, single.words)
+
+
+def test_sharded_proof_refuses_what_it_does_not_implement(machine, rc, fib25):
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    provers = [va.Prover(machine, rc, log_blowup=2) for _ in range(2)]
+    with pytest.raises(va.VgpuError, match="log_blowup"):
+        va.prove_sharded_local(provers, mt, prep)
+    provers = [va.Prover(machine, rc) for _ in range(3)]
+    with pytest.raises(va.VgpuError, match="power of two"):
+        va.prove_sharded_local(provers, mt, prep)
+    p = va.Prover(machine, rc)
+    with pytest.raises(va.VgpuError, match="distinct"):
+        va.prove_sharded_local([p, p], mt, prep)

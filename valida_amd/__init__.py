@@ -493,6 +493,17 @@ class Comm:
         _check(lib().vgpu_commit_batches_sharded(self._prover._h, self._h, arr, ctypes.c_uint32(len(traces)), sh, root.ctypes.data_as(c_u32p)))
         return root
 
+    def prove_sharded(self, main, preprocessed, log_min_sharded=12):
+        """This rank's share of ONE proof sharded over the communicator's ranks (vgpu_prove_sharded); every rank passes the same traces
+        (uploaded through its own prover) and receives the proof vgpu_prove gives on one GPU."""
+        arr = (ctypes.c_void_p * len(main))(*[t._h for t in main])
+        chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
+        parr = (ctypes.c_void_p * max(1, len(preprocessed)))(*[t._h for _, t in preprocessed])
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_prove_sharded(self._prover._h, self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)),
+                                        ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
+        return Proof(h)
+
     def allgather_roots(self, words):
         w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1)
         out = np.zeros(w.size * self.world, dtype=np.uint32)
@@ -545,6 +556,22 @@ def commit_batches_sharded_local(provers, matrices, coset_shifts=None):
         shv, sh = _u32(coset_shifts)
     _check(lib().vgpu_commit_batches_sharded_local(parr, ctypes.c_uint32(len(provers)), arr, ctypes.c_uint32(len(matrices)), sh, root.ctypes.data_as(c_u32p)))
     return root
+
+
+def prove_sharded_local(provers, main_traces, preprocessed, log_min_sharded=12):
+    """ONE proof over len(provers) prover contexts of this process standing in for the ranks (vgpu_prove_sharded_local): main_traces are
+    host matrices (chip order), preprocessed a list of (chip, host matrix); every context gets its own upload (the traces are replicated,
+    the LDEs / trees / FRI layers are sharded).  Returns the Proof, word for word provers[0].prove(..) of the same traces."""
+    keep_m = [[p.upload(m) for m in main_traces] for p in provers]
+    keep_p = [[p.upload(m) for _, m in preprocessed] for p in provers]
+    arr = (ctypes.c_void_p * (len(provers) * len(main_traces)))(*[t._h for row in keep_m for t in row])
+    chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
+    parr = (ctypes.c_void_p * max(1, len(provers) * len(preprocessed)))(*[t._h for row in keep_p for t in row])
+    pv = (ctypes.c_void_p * len(provers))(*[p._h for p in provers])
+    h = ctypes.c_void_p()
+    _check(lib().vgpu_prove_sharded_local(pv, ctypes.c_uint32(len(provers)), arr, ctypes.c_uint32(len(main_traces)), chips, parr, ctypes.c_uint32(len(preprocessed)),
+                                          ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
+    return Proof(h)
 
 
 class Ticket:

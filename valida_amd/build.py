@@ -23,6 +23,7 @@ SOURCES = [
     "kernels/open.hip",
     "kernels/tracegen.hip",
     "host/prover.cpp",
+    "host/sharded_prover.cpp",
     "capi.cpp",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

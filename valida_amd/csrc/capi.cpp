@@ -9,6 +9,7 @@
 #include "host/cbor.hpp"
 #include "host/comm.hpp"
 #include "host/sharded.hpp"
+#include "host/sharded_prover.hpp"
 #include "host/verifier.hpp"
 #include "host/poseidon_opt.hpp"
 #include "host/prover.hpp"
@@ -799,6 +800,46 @@ int32_t vgpu_commit_batches_sharded_local(vgpu_prover_t* const* provers, uint32_
         std::vector<Fp> shifts;
         if (coset_shifts) for (uint32_t i = 0; i < n_mats; i++) shifts.push_back(Fp::from_canonical(coset_shifts[i]));
         commit_sharded_local(ctxs, np, coset_shifts ? &shifts : nullptr, provers[0]->p->fri(), root);
+    })
+}
+
+// ---- one proof over several ranks
+static ShardedInputs sharded_inputs(const vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips, const vgpu_trace_t* const* prep,
+                                    uint32_t n_prep) {
+    ShardedInputs in;
+    for (uint32_t i = 0; i < n_main; i++) { check_trace(p, main[i]); in.main.push_back(main[i]->t.get()); }
+    for (uint32_t i = 0; i < n_prep; i++) { check_trace(p, prep[i]); in.prep.push_back({(int)prep_chips[i], prep[i]->t.get()}); }
+    return in;
+}
+int32_t vgpu_prove_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
+                           const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out) {
+    VG_TRY({
+        if (!p || !comm || !main || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
+        if (comm->owner != p->p) throw std::invalid_argument("communicator of another prover context");
+        RcclFabric fabric(comm->comm.get());
+        std::vector<Prover*> provers{p->p.get()};
+        std::vector<ShardedInputs> in{sharded_inputs(p, main, n_main, prep_chips, prep, n_prep)};
+        auto proof = std::make_unique<vgpu_proof>();
+        proof->words = ShardedProof::run(fabric, provers, in, log_min_sharded);
+        *out = proof.release();
+    })
+}
+int32_t vgpu_prove_sharded_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* main, uint32_t n_main,
+                                 const uint32_t* prep_chips, const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out) {
+    VG_TRY({
+        if (!provers || !world || !main || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
+        LocalFabric fabric((int)world);
+        std::vector<Prover*> ps;
+        std::vector<ShardedInputs> in;
+        for (uint32_t r = 0; r < world; r++) {
+            if (!provers[r]) throw std::invalid_argument("null prover");
+            for (uint32_t q = 0; q < r; q++) if (provers[q]->p == provers[r]->p) throw std::invalid_argument("the ranks need distinct prover contexts");
+            ps.push_back(provers[r]->p.get());
+            in.push_back(sharded_inputs(provers[r], main + (size_t)r * n_main, n_main, prep_chips, n_prep ? prep + (size_t)r * n_prep : nullptr, n_prep));
+        }
+        auto proof = std::make_unique<vgpu_proof>();
+        proof->words = ShardedProof::run(fabric, ps, in, log_min_sharded);
+        *out = proof.release();
     })
 }
 

@@ -603,7 +603,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
 
 // k_reduce_openings' per-point table: g(X) = prod_{i=1..4} (X - frob^i z) = X^4 + g3 X^3 + .. + g0 over Ext5 and m(X) = (X - z) g(X), the minimal
 // polynomial of z over the base field (X^5 + m4 X^4 + .. + m0): 1/(z - x) = -g(x)/m(x) for x in the base field.  Words: [m0..m4][g0]..[g3].
-static void put_min_poly(std::vector<uint32_t>& w, const Ext5& z) {
+void put_min_poly(std::vector<uint32_t>& w, const Ext5& z) {
     Ext5 g[5] = {Ext5::one(), Ext5::zero(), Ext5::zero(), Ext5::zero(), Ext5::zero()};  // coefficients, low first; degree grows to 4
     Ext5 conj = z;
     for (int i = 1; i <= 4; i++) {

@@ -69,6 +69,10 @@ struct PcsOpening {
     double ms_values = 0, ms_reduce = 0, ms_fri = 0, ms_queries = 0;
 };
 
+// [m0..m4][g0 (5)]..[g3 (5)]: the minimal polynomial m of z over the base field and g = m / (X - z), as k_bary_weights / k_reduce_openings read
+// them (1 / (z - x) = -g(x) / m(x) for x in the base field)
+void put_min_poly(std::vector<uint32_t>& w, const Ext5& z);
+
 class Prover {
   public:
     Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_rc480, const FriParams& fri);
@@ -102,6 +106,7 @@ class Prover {
                          const Ext5& cumulative_sum);
 
   private:
+    friend struct ShardedProof;  // one proof over several prover contexts / GPUs (sharded_prover.cpp) drives the same private pieces
     std::unique_ptr<DeviceCtx> ctx_;
     MachineDesc machine_;
     FriParams fri_;

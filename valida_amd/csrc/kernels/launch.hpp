@@ -24,6 +24,24 @@ struct QuotientArgs {
     // the register-program interpreter (AIRs captured at run time through vgpu_air_*)
     static constexpr int INTERPRET = -2;
     int native_chip;
+    // Where the NEXT row of a point is read from: column 0 of main / perm / preprocessed LDEs with the strides of the views above, and the
+    // distance of the next row in natural index inside that LDE.  One GPU: the same LDEs, 2^lqd (the launchers fill these in when they
+    // are left null / zero).  A proof sharded over several GPUs (host/sharded_prover.cpp) evaluates a row range of the LDE, i.e. the
+    // sub-coset s w_L^e H_{L/W}: the successors of its points form ANOTHER sub-coset, a different rank's row range, at the same or the
+    // following natural index.
+    const uint32_t* main_nx;
+    const uint32_t* perm_nx;
+    const uint32_t* prep_nx;
+    uint32_t next_step_p1;  // 1 + that distance (0 = not set; the distance itself may be 0)
+    // defaults of the single-GPU case
+    QuotientArgs normalised() const {
+        QuotientArgs b = *this;
+        if (!b.main_nx) b.main_nx = b.main_lde.data;
+        if (!b.perm_nx) b.perm_nx = b.perm_lde.data;
+        if (!b.prep_nx) b.prep_nx = b.prep_lde.data;
+        if (!b.next_step_p1) b.next_step_p1 = 1u + (1u << (b.lqd > 0 ? b.lqd : 1));
+        return b;
+    }
 };
 
 

@@ -40,8 +40,8 @@ typedef uint32_t v32u __attribute__((ext_vector_type(32)));
 #define VG_INTERP_BODY(GET, SET)                                                                                                        \
     switch (in.op) {                                                                                                                    \
         case vair::OP_CONST: SET(in.dst, (uint32_t)in.a | ((uint32_t)in.b << 16)); break;                                               \
-        case vair::OP_LOAD_MAIN: SET(in.dst, a.main_lde.data[(uint64_t)in.a * a.main_lde.stride + (in.flag ? p.next_row : p.row)]); break; \
-        case vair::OP_LOAD_PREP: SET(in.dst, a.prep_lde.data[(uint64_t)in.a * a.prep_lde.stride + (in.flag ? p.next_row : p.row)]); break; \
+        case vair::OP_LOAD_MAIN: SET(in.dst, in.flag ? a.main_nx[(uint64_t)in.a * a.main_lde.stride + p.next_row] : a.main_lde.data[(uint64_t)in.a * a.main_lde.stride + p.row]); break; \
+        case vair::OP_LOAD_PREP: SET(in.dst, in.flag ? a.prep_nx[(uint64_t)in.a * a.prep_lde.stride + p.next_row] : a.prep_lde.data[(uint64_t)in.a * a.prep_lde.stride + p.row]); break; \
         case vair::OP_SEL_FIRST: SET(in.dst, p.is_first.v); break;                                                                      \
         case vair::OP_SEL_LAST: SET(in.dst, p.is_last.v); break;                                                                        \
         case vair::OP_SEL_TRANS: SET(in.dst, p.is_trans.v); break;                                                                      \
@@ -135,8 +135,8 @@ template <int CHIP>
 __device__ __forceinline__ Ext5 run_native(const QuotientArgs& a, const PointCtx& p) {
     if (CHIP < 0) return Ext5::zero();
     DeviceFolder f;
-    f.main_p = a.main_lde.data + p.row; f.main_n = a.main_lde.data + p.next_row; f.mstride = a.main_lde.stride;
-    f.prep_p = a.prep_lde.data + p.row; f.prep_n = a.prep_lde.data + p.next_row; f.pstride = a.prep_lde.stride;
+    f.main_p = a.main_lde.data + p.row; f.main_n = a.main_nx + p.next_row; f.mstride = a.main_lde.stride;
+    f.prep_p = a.prep_lde.data + p.row; f.prep_n = a.prep_nx + p.next_row; f.pstride = a.prep_lde.stride;
     f.first = p.is_first; f.last = p.is_last; f.trans = p.is_trans;
     f.apow = a.consts;
     f.total = Ext5::zero();
@@ -164,7 +164,7 @@ __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const Po
         pos += 2;
         uint32_t pos_n = pos;
         Fp mult_local = eval_vcol(iw, pos, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, p.row);
-        Fp mult_next = eval_vcol(iw, pos_n, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, p.next_row);
+        Fp mult_next = eval_vcol(iw, pos_n, a.main_nx, a.main_lde.stride, a.prep_nx, a.prep_lde.stride, p.next_row);
         // rlc = alpha_bus + sum_j beta^j f_j: Ext5 x base products accumulated four at a time per limb
         Ext5 rlc = ext_from_words(bus + 5 * m);
         for (uint32_t j0 = 0; j0 < nf; j0 += 4) {
@@ -179,13 +179,13 @@ __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const Po
             for (int c = 0; c < 5; c++) rlc.c[c] += Fp::raw(vg::monty_reduce_wide(t[c]));
         }
         const uint32_t* pcol = a.perm_lde.data + (uint64_t)(5 * m) * a.perm_lde.stride;
-        Ext5 pl = load_ext(pcol, a.perm_lde.stride, p.row), pn = load_ext(pcol, a.perm_lde.stride, p.next_row);
+        Ext5 pl = load_ext(pcol, a.perm_lde.stride, p.row), pn = load_ext(a.perm_nx + (uint64_t)(5 * m) * a.perm_lde.stride, a.perm_lde.stride, p.next_row);
         acc += ext_from_words(apow + 5 * m) * (rlc * pl - Fp::one());  // assert_one_ext(rlc * perm_local[m])
         Ext5 tl = pl * mult_local, tn = pn * mult_next;
         if (is_send) { phi_0 += tl; rhs += tn; } else { phi_0 -= tl; rhs -= tn; }
     }
     const uint32_t* phicol = a.perm_lde.data + (uint64_t)(5 * M) * a.perm_lde.stride;
-    Ext5 phi_local = load_ext(phicol, a.perm_lde.stride, p.row), phi_next = load_ext(phicol, a.perm_lde.stride, p.next_row);
+    Ext5 phi_local = load_ext(phicol, a.perm_lde.stride, p.row), phi_next = load_ext(a.perm_nx + (uint64_t)(5 * M) * a.perm_lde.stride, a.perm_lde.stride, p.next_row);
     acc += ext_from_words(apow + 5 * M) * (((phi_next - phi_local) - rhs) * p.is_trans);
     acc += ext_from_words(apow + 5 * (M + 1)) * ((phi_local - phi_0) * p.is_first);
     acc += ext_from_words(apow + 5 * (M + 2)) * ((phi_local - cumulative_sum) * p.is_last);
@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
     Fp id00 = ip01 * d01, id01 = ip01 * d00, id10 = ip23 * d11, id11 = ip23 * d10;
     const uint32_t par0 = i0 & 1u, par1 = i1 & 1u;
     PointCtx p0, p1;
-    p0.row = j0; p0.next_row = vg::reverse_bits_len((i0 + 2u) & Qmask, (unsigned)kq);
-    p1.row = j1; p1.next_row = vg::reverse_bits_len((i1 + 2u) & Qmask, (unsigned)kq);
+    p0.row = j0; p0.next_row = vg::reverse_bits_len((i0 + a.next_step_p1 - 1u) & Qmask, (unsigned)kq);
+    p1.row = j1; p1.next_row = vg::reverse_bits_len((i1 + a.next_step_p1 - 1u) & Qmask, (unsigned)kq);
     p0.is_trans = d01; p0.is_first = Fp::raw(a.zh[par0]) * id00; p0.is_last = Fp::raw(a.zh[par0]) * id01;
     p1.is_trans = d11; p1.is_first = Fp::raw(a.zh[par1]) * id10; p1.is_last = Fp::raw(a.zh[par1]) * id11;
     // The two points are evaluated one after the other (not unrolled): interleaving them only doubles the live
@@ -342,8 +342,8 @@ __global__ void __launch_bounds__(256) k_check_constraints(QuotientArgs a, unsig
         if (!run_program_lds(a, p, regs).is_zero()) code = 0xFFFDu;  // random fold of all AIR constraints
     } else if (CHIP >= 0) {
         DebugFolder f;
-        f.main_p = a.main_lde.data + p.row; f.main_n = a.main_lde.data + p.next_row; f.mstride = a.main_lde.stride;
-        f.prep_p = a.prep_lde.data + p.row; f.prep_n = a.prep_lde.data + p.next_row; f.pstride = a.prep_lde.stride;
+        f.main_p = a.main_lde.data + p.row; f.main_n = a.main_nx + p.next_row; f.mstride = a.main_lde.stride;
+        f.prep_p = a.prep_lde.data + p.row; f.prep_n = a.prep_nx + p.next_row; f.pstride = a.prep_lde.stride;
         f.first = p.is_first; f.last = p.is_last; f.trans = p.is_trans;
         f.k = 0; f.bad = 0xffffffffu;
         vchips::eval_chip(CHIP, f);
@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(256) k_check_constraints(QuotientArgs a, unsig
     if (code != 0xffffffffu) atomicMin(first_bad, (unsigned long long)((r << 16) | code));
 }
 
-void launch_check_constraints(hipStream_t st, const QuotientArgs& a, unsigned long long* first_bad_dev) {
+void launch_check_constraints(hipStream_t st, const QuotientArgs& a_in, unsigned long long* first_bad_dev) {
+    const QuotientArgs a = a_in.normalised();  // next rows come from the same traces
     const uint64_t n = 1ull << a.log_n;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     ProfScope ps("k_check_constraints", st, 4.0 * n * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width));
@@ -373,7 +374,8 @@ void launch_check_constraints(hipStream_t st, const QuotientArgs& a, unsigned lo
     }
 }
 
-void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& tb) {
+void launch_quotient(hipStream_t st, const QuotientArgs& a_in, const DeviceTables& tb) {
+    const QuotientArgs a = a_in.normalised();  // one GPU: next rows from the same LDEs, 2^lqd further in natural index
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
