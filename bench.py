@@ -359,7 +359,7 @@ def main():
             provers[0].prove(*inputs[0])
         prof1 = provers[0].profile()
         provers[0].set_profiling(False)
-    pcie_ms = oplog_ms = pcie_pinned_ms = None
+    pcie_ms = oplog_ms = pcie_pinned_ms = sharded_local = None
     if not args.no_extra_legs:
         # the same boundary with the host matrices in page-locked memory (vgpu_host_alloc): the upload is one DMA per matrix
         mt_pinned = [va.pinned_copy(m) for m in mt]
@@ -385,6 +385,28 @@ def main():
         torch.cuda.synchronize()
         oplog_ms = (time.perf_counter() - t0) / (4 * len(provers)) * 1e3
         del gen
+        # ONE proof over W prover contexts of this GPU standing in for W ranks (vgpu_prove_sharded_local).  All the work
+        # still runs on this one device, so the figures show what sharding COSTS (exchanges as device-to-device copies, the small chips and
+        # the permutation traces computed by every rank, the host steps between the phases) — not a speed-up.
+        if world == 1 and prover.log_blowup == 1 and os.environ.get("VGPU_BENCH_SHARDED", "1") == "1":
+            sharded_local = {}
+            ref_words = provers[0].prove(*inputs[0]).words
+            extra = []
+            for wn in (1, 2, 4, 8):
+                while len(provers) + len(extra) < wn:
+                    extra.append(va.Prover(machine, rc, log_blowup=1, device=local_rank, hash_kind=hash_kind))
+                ps = (provers + extra)[:wn]
+                up = va.upload_replicated(ps, mt, prep)
+                pr = va.prove_sharded_local(ps, mt, prep, uploaded=up)  # sizes the pools
+                same = bool(np.array_equal(pr.words, ref_words))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    va.prove_sharded_local(ps, mt, prep, uploaded=up)
+                torch.cuda.synchronize()
+                sharded_local[str(wn)] = {"ms_per_proof": (time.perf_counter() - t0) / 3 * 1e3, "same_words_as_the_single_gpu_proof": same}
+                del up
+            del extra
     # Per-kernel table: a few steps with events on EVERY launch, outside the timed region.  Timed region: events on the launches
     # of the dominant kernel only — a timed launch carries a pair of events, and 1270 of them per proof cost ~4 % of the throughput
     # being measured; the roofline needs that kernel's live average, the table does not need the timed region.
@@ -526,6 +548,9 @@ def main():
                                     "note": "operation logs uploaded and all 14 chip traces generated on the device for every step, on a prover context of their own "
                                             "while the proving contexts work on the previous segments (replaces host generate_trace, reported as "
                                             "tracegen_s, and the row-major upload)"},
+            "one_proof_over_w_ranks_on_this_gpu": None if not sharded_local else dict(sharded_local, note=(
+                "vgpu_prove_sharded_local: W prover contexts of this ONE device stand in for W ranks (row-range shards, exchanges as device-to-device "
+                "copies): what sharding costs, not a speed-up; the multi-GPU realisation (vgpu_prove_sharded over RCCL) is unmeasured here")),
             "prover_ms_single_proof_in_flight": single if single is not None else ms_per_step,
             "proof_words": int(p.words.size),
             "hbm_pool_peak_bytes": sum(p_.memory()[1] for p_ in provers),
@@ -537,6 +562,39 @@ def main():
                 po.set_mmcs_hash(1, rc)
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_rows if args.cpu_log_rows else headline, rc, args.log_rows)
         print(json.dumps(out), flush=True)
+    if world > 1 and lib_comm is not None and not comm_stuck and prover.log_blowup == 1 and os.environ.get("VGPU_BENCH_SHARDED", "1") == "1":
+        # After the contract line (nothing below can change it): ONE proof — rank 0's segment — over ALL the ranks (vgpu_prove_sharded over
+        # RCCL / xGMI: row-range shards), reported on stderr.  The first run of this path on real multi-GPU hardware:
+        # a watchdog bounds it and every rank leaves without further collectives.
+        import hashlib
+        import threading
+        res = {}
+
+        def sharded_leg():
+            try:
+                w0 = wl if rank == 0 else va.Workload.fib(segment_loop_bound(args.log_rows, 0)) if args.workload != "c4" else va.Workload.alu(((1 << args.log_rows) - 8) // 9)
+                m0, p0 = w0.main_traces(), w0.preprocessed()
+                dm, dp = [prover.upload(m) for m in m0], [(c, prover.upload(m)) for c, m in p0]
+                pr = lib_comm.prove_sharded(dm, dp)  # sizes the pools
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    pr = lib_comm.prove_sharded(dm, dp)
+                res["ms_per_proof"] = (time.perf_counter() - t0) / 3 * 1e3
+                res["sha256"] = hashlib.sha256(pr.words.tobytes()).hexdigest()
+                if rank == 0:
+                    res["same_words_as_the_single_gpu_proof"] = bool(np.array_equal(pr.words, prover.prove(dm, dp).words))
+            except Exception as e:  # noqa: BLE001
+                res["error"] = "%s: %s" % (type(e).__name__, e)
+
+        th = threading.Thread(target=sharded_leg, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("VGPU_BENCH_SHARDED_TIMEOUT", "180")))
+        if th.is_alive():
+            res["error"] = "still running after the deadline"
+        print("sharded_leg rank %d of %d: %s" % (rank, world, json.dumps(res)), file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         if comm_stuck:  # a thread is still inside the abandoned rendezvous: leave without waiting for it
             dist.barrier()

@@ -87,6 +87,17 @@ def test_sharded_proof_of_the_alu_workload(machine, rc):
     assert_same_proof(sharded.words, single.words)
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_proof_at_the_headline_size(machine, rc, world):
+    """C2 (fib 149 794: cpu 2^20, mem 2^22 rows; the single-GPU proof of these traces is bit-matched to the oracle in test_gpu_parity) with the
+    default threshold: cpu / mem / add sharded (row ranges of 2^18 .. 2^22 rows), everything else replicated, FRI layers sharded down to 2^12."""
+    w = va.Workload.fib(149794)
+    p0, mt, prep, single = single_and_inputs(machine, rc, w)
+    provers = [p0] + [va.Prover(machine, rc) for _ in range(world - 1)]
+    sharded = va.prove_sharded_local(provers, mt, prep)
+    assert_same_proof(sharded.words, single.words)
+
+
 def test_sharded_proof_with_the_poseidon_mmcs(machine, rc, fib25):
     p0, mt, prep, single = single_and_inputs(machine, rc, fib25, hash_kind=va.HASH_POSEIDON16)
     provers = [p0, va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16)]

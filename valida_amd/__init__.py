@@ -558,12 +558,18 @@ def commit_batches_sharded_local(provers, matrices, coset_shifts=None):
     return root
 
 
-def prove_sharded_local(provers, main_traces, preprocessed, log_min_sharded=12):
+def upload_replicated(provers, main_traces, preprocessed):
+    """The traces of one proof uploaded through every prover context (a sharded proof replicates the traces): (main, prep) handles for
+    prove_sharded_local(.., uploaded=..)."""
+    return [[p.upload(m) for m in main_traces] for p in provers], [[p.upload(m) for _, m in preprocessed] for p in provers]
+
+
+def prove_sharded_local(provers, main_traces, preprocessed, log_min_sharded=12, uploaded=None):
     """ONE proof over len(provers) prover contexts of this process standing in for the ranks (vgpu_prove_sharded_local): main_traces are
     host matrices (chip order), preprocessed a list of (chip, host matrix); every context gets its own upload (the traces are replicated,
-    the LDEs / trees / FRI layers are sharded).  Returns the Proof, word for word provers[0].prove(..) of the same traces."""
-    keep_m = [[p.upload(m) for m in main_traces] for p in provers]
-    keep_p = [[p.upload(m) for _, m in preprocessed] for p in provers]
+    the LDEs / trees / FRI layers are sharded) unless `uploaded` = upload_replicated(..) hands them in.  Returns the Proof, word for word
+    provers[0].prove(..) of the same traces."""
+    keep_m, keep_p = uploaded if uploaded is not None else upload_replicated(provers, main_traces, preprocessed)
     arr = (ctypes.c_void_p * (len(provers) * len(main_traces)))(*[t._h for row in keep_m for t in row])
     chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
     parr = (ctypes.c_void_p * max(1, len(provers) * len(preprocessed)))(*[t._h for row in keep_p for t in row])
