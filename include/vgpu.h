@@ -266,7 +266,7 @@ int32_t vgpu_comm_init(vgpu_prover_t* p, const uint8_t id[VGPU_COMM_ID_BYTES], u
 int32_t vgpu_comm_allgather_roots(vgpu_comm_t* c, const uint32_t* words, uint32_t n_words, uint32_t* out);
 void vgpu_comm_destroy(vgpu_comm_t* c);
 
-/* ---- ONE proof sharded over several GPUs, first step: pcs.commit_batches of one round sharded over the
+/* ---- ONE proof sharded over several GPUs.  Its commitment round alone: pcs.commit_batches of one round sharded over the
  * ranks of `comm` — column-sharded LDEs, an all-to-all into row-range shards, a subtree per rank, an all-gather of the subtree
  * roots.  Every rank passes the SAME matrices (only its own columns are extended) and receives the SAME root that
  * vgpu_commit_batches gives on one GPU.  world must be a power of two. */
