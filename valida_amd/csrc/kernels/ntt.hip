@@ -56,13 +56,16 @@ __device__ __forceinline__ void ntt_round(uint32_t* buf, const uint32_t* tw, int
             const int st = DIT ? step : R - 1 - step;  // stage s = s_lo + st pairs g differing in bit st
             const int half = 1 << st;
             const uint32_t* t = tw + ((1 << (lowbits + st)) - 1) + low;
+            // LB == 0 (stages 1 .. R: the first DIT / last DIF round): the twiddle of butterfly p is w^(p & (half - 1)) with a compile-time
+            // exponent, and exponent 0 is the factor 1 — 15 of a radix-16 round's 32 butterflies need no multiplication at all
             Fp wv[G / 2];
 #pragma unroll
             for (int k = 0; k < G / 2; k++)
-                if (k < half) wv[k] = Fp::raw(t[k << lowbits]);
+                if (k < half && !(LB == 0 && k == 0)) wv[k] = Fp::raw(t[k << lowbits]);
 #pragma unroll
             for (int p = 0; p < G / 2; p++) {
                 const int g0 = ((p >> st) << (st + 1)) | (p & (half - 1)), g1 = g0 | half;
+                if (LB == 0 && (p & (half - 1)) == 0) { Fp u = x[g0], v = x[g1]; x[g0] = u + v; x[g1] = u - v; continue; }
                 const Fp wk = wv[p & (half - 1)];
                 if (DIT) { Fp u = x[g0], v = x[g1] * wk; x[g0] = u + v; x[g1] = u - v; }
                 else {
@@ -86,6 +89,15 @@ __device__ __forceinline__ void ntt_round(uint32_t* buf, const uint32_t* tw, int
 
 template <bool DIT, bool PAD>
 __device__ __forceinline__ void ntt_round_dispatch(int R, uint32_t* buf, const uint32_t* tw, int logn, int s_lo, int logT, int LD) {
+    if (s_lo == 1) {  // the round that holds stage 1: compile-time twiddle exponents, the trivial ones dropped (block-uniform branch)
+        switch (R) {
+            case 1: ntt_round<1, DIT, PAD, 0>(buf, tw, logn, 1, logT, LD); break;
+            case 2: ntt_round<2, DIT, PAD, 0>(buf, tw, logn, 1, logT, LD); break;
+            case 3: ntt_round<3, DIT, PAD, 0>(buf, tw, logn, 1, logT, LD); break;
+            default: ntt_round<4, DIT, PAD, 0>(buf, tw, logn, 1, logT, LD); break;
+        }
+        return;
+    }
     switch (R) {
         case 1: ntt_round<1, DIT, PAD, -1>(buf, tw, logn, s_lo, logT, LD); break;
         case 2: ntt_round<2, DIT, PAD, -1>(buf, tw, logn, s_lo, logT, LD); break;
