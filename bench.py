@@ -8,6 +8,10 @@ One "step" = one complete proof per rank (from HBM-resident main traces to the a
 the host) + one RCCL all-gather of that proof's three 32-byte commitment roots over xGMI when N > 1, issued
 as soon as the rank's proof is complete (segments are independent).  Rank 0 prints ONE JSON
 line.  Scaling is weak (one segment per GPU).
+
+Beside the headline the line carries (N = 1) the latency of a lone proof, the PCIe-inclusive and operation-log legs, the CPU baseline
+and `one_proof_over_w_ranks_on_this_gpu`: ONE proof sharded over W prover contexts of this device.  With N > 1
+the ranks finish by proving one segment TOGETHER through vgpu_prove_sharded (RCCL) — after the JSON line, reported on stderr.
 """
 import argparse
 import json

@@ -115,3 +115,129 @@ def test_sharded_commit_protocol_over_gloo():
         assert p.exitcode == 0
     for rank, root, want in results:
         assert root == want, rank  # every rank ends with the root pcs.commit_batches gives on one machine
+
+
+# ---- the exchanges of the WHOLE sharded prover (valida_amd/csrc/host/sharded_prover.cpp) over a real process
+# group: four ranks on gloo, the CPU oracle standing in for the device kernels.  Every rank holds a row range of the committed LDE and
+# checks, against the oracle's whole-domain results, what the device code relies on:
+#   halo       the shard received from next_rank() holds, at natural index m + d, the successor of every local point (quotient phase);
+#   rows->cols the all-to-all that hands the quotient chunks' columns to their owners reassembles whole columns;
+#   openings   the partial barycentric sums over the shards add up to p(z);
+#   FRI        a shard folded with beta w^-e is the row range of the folded vector; the gathered layer is the oracle's;
+#   queries    tails filled in by their owners and OR-ed give the whole tail.
+def _brev(x, bits):
+    r = 0
+    for i in range(bits):
+        r |= ((x >> i) & 1) << (bits - 1 - i)
+    return r
+
+
+def _sharded_prover_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from oracle import pyoracle as po
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    P = 2013265921
+    g27 = pow(31, 15, P)
+    root = lambda bits: pow(g27, 1 << (27 - bits), P)
+    logW = world.bit_length() - 1
+    e = _brev(rank, logW)
+    rng = np.random.default_rng(5)  # the same trace on every rank (a sharded proof replicates the traces)
+    logn, width = 6, 3
+    n, L, logL = 1 << logn, 2 << logn, logn + 1
+    Lp, logLp = L // world, logL - logW
+    trace = rng.integers(0, P, (n, width), dtype=np.uint32)
+    lde = po.committed_lde(trace, 1, 31)  # whole LDE, committed order (the test's ground truth)
+    shard = lde[rank * Lp:(rank + 1) * Lp].copy()
+
+    def exchange(send_to):  # send_to[s] = object for rank s; returns what every rank sent to this one (gloo has no all-to-all)
+        box = [None] * world
+        dist.all_gather_object(box, send_to)
+        return [box[src][rank] for src in range(world)]
+
+    # ---- halo: my shard goes to pred_rank, I receive next_rank's
+    nxt = _brev((e + 2) % world, logW)
+    pred = _brev((e + world - 2 % world) % world, logW)
+    got = exchange([shard if s == pred else None for s in range(world)])
+    assert [s for s in range(world) if got[s] is not None] == [nxt]
+    halo, d = got[nxt], (e + 2) // world
+    for jl in range(Lp):
+        m = _brev(jl, logLp)
+        i = _brev(rank * Lp + jl, logL)                    # natural index of my row in the whole domain
+        assert i == e + world * m
+        succ = lde[_brev((i + 2) % L, logL)]               # x g_n: two steps further in the LDE domain of blowup 2
+        assert np.array_equal(halo[_brev((m + d) % Lp, logLp)], succ)
+    # ---- rows -> columns: rank r's rows of column c go to the column's owner ((col_base + c) mod W)
+    chunks = rng.integers(0, P, (n, 10), dtype=np.uint32)  # a chunk matrix (rows at committed positions), the same on every rank
+    mine_rows = chunks[rank * (n // world):(rank + 1) * (n // world)]
+    col_base = 10 * 3
+    got = exchange([mine_rows[:, [c for c in range(10) if (col_base + c) % world == s]] for s in range(world)])
+    own = [c for c in range(10) if (col_base + c) % world == rank]
+    assert np.array_equal(np.concatenate(got, axis=0), chunks[:, own])
+    # ---- opened values: p(z) = (z^L - s^L) / (L s^(L-1)) sum_j y_j r_j / (z - s r_j), split over the shards
+    s, z, wL = 31, int(rng.integers(2, P)), root(logL)
+    coef = [int(v) for v in po.dft(trace[:, 0], inverse=True)]  # column 0 as a polynomial
+
+    def ev(x):
+        r = 0
+        for c in reversed(coef):
+            r = (r * x + c) % P
+        return r
+
+    def domain_point(j):
+        r, b = 1, 0
+        while j >> b:
+            if (j >> b) & 1:
+                r = r * root(b + 1) % P
+            b += 1
+        return r
+
+    assert ev(s * pow(wL, _brev(5, logL), P) % P) == int(lde[5, 0])  # the interpolation convention of the oracle's DFT
+    rho = pow(wL, e, P)
+    sp = s * rho % P
+    part = sum(int(shard[jl, 0]) * domain_point(jl) % P * pow((z - sp * domain_point(jl)) % P, P - 2, P) for jl in range(Lp)) % P
+    scale = (pow(z, L, P) - pow(s, L, P)) * pow(L * pow(s, L - 1, P) % P, P - 2, P) % P
+    parts = [None] * world
+    dist.all_gather_object(parts, scale * rho % P * part % P)
+    assert sum(parts) % P == ev(z)
+    # ---- FRI: fold my range with beta w^-e, gather the layer
+    f = rng.integers(0, P, (L, 5), dtype=np.uint32)
+    beta = rng.integers(0, P, 5, dtype=np.uint32)
+    winv = pow(wL, (P - 1 - e) % (P - 1), P)
+    beta_local = np.array([int(b) * winv % P for b in beta], dtype=np.uint32)  # Ext5 times a base-field element: limb-wise
+    folded = po.fri_fold(f[rank * Lp:(rank + 1) * Lp], beta_local)
+    layers = [None] * world
+    dist.all_gather_object(layers, folded)
+    assert np.array_equal(np.concatenate(layers, axis=0), po.fri_fold(f, beta))
+    # ---- queries: every rank fills in the rows it holds, the tails are OR-ed
+    queries = [int(x) for x in rng.integers(0, L, 9)]
+    tail = np.zeros((len(queries), width), dtype=np.uint32)
+    for k, row in enumerate(queries):
+        if row // Lp == rank:
+            tail[k] = shard[row % Lp]
+    tails = [None] * world
+    dist.all_gather_object(tails, tail)
+    merged = np.zeros_like(tail)
+    for t in tails:
+        merged |= t
+    assert np.array_equal(merged, lde[queries])
+    q.put(rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_prover_exchanges_over_gloo():
+    world, port = 4, 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_prover_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    done = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert done == list(range(world))
