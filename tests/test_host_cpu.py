@@ -355,3 +355,84 @@ def test_c99_host_links_and_runs(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "chip 0: width 51" in r.stdout
     assert ("no device: code -3" in r.stdout) or ("proof words" in r.stdout)
+
+
+def test_makefile_builds_the_same_sources_as_build_py():
+    """Two build routes (valida_amd/build.py for the Python tests, the top-level Makefile for a Rust / C host's build script) must not drift."""
+    from valida_amd import build as b
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mk = open(os.path.join(root, "Makefile")).read()
+    m = re.search(r"^SRCS := (.*?)\n(?=\S)", mk, re.S | re.M)
+    srcs = m.group(1).replace("\\\n", " ").split()
+    assert sorted(srcs) == sorted(b.SOURCES)
+    for flag in b.FLAGS:
+        if flag.startswith("--offload-arch"):
+            continue
+        assert flag in mk, flag
+
+
+def test_rust_sys_binding_is_generated_from_the_header_and_complete(tmp_path):
+    """bindings/rust/src/lib.rs (the thin #[repr(C)] FFI layer of BASELINE.json's north star; no Rust toolchain here, so it is generated, not
+    compiled): up to date with include/vgpu.h, declares every symbol the library exports, and every #[repr(C)] struct has the size and field
+    offsets gcc gives its C twin."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_rust_bindings as g
+
+    text, info = g.generate()
+    assert open(os.path.join(root, "bindings", "rust", "src", "lib.rs")).read() == text, "run python tools/gen_rust_bindings.py"
+    exported = set(re.findall(r"\bT (vgpu_\w+)", subprocess.run(["nm", "-D", "--defined-only", os.path.join(root, "valida_amd", "libvgpu.so")], capture_output=True, text=True, check=True).stdout))
+    declared = set(re.findall(r"pub fn (vgpu_\w+)\(", text))
+    assert declared == exported
+    # layout: sizes / offsets from gcc against the System V layout of the Rust field types
+    size_align = {"u8": (1, 1), "u32": (4, 4), "i32": (4, 4), "u64": (8, 8), "i64": (8, 8), "f64": (8, 8)}
+    structs = {}
+    for m in re.finditer(r"pub struct (\w+) \{  // (\w+)\n(.*?)\n\}", text, re.S):
+        fields = re.findall(r"pub (\w+): ([^,\n]+),", m.group(3))
+        structs[m.group(2)] = (m.group(1), fields)
+
+    def layout(ty):
+        ty = ty.strip()
+        a = re.match(r"\[(.+); (\d+)\]$", ty)
+        if a:
+            s, al = layout(a.group(1))
+            return s * int(a.group(2)), al
+        if ty.startswith("*"):
+            return 8, 8
+        if ty in size_align:
+            return size_align[ty]
+        for cname, (rname, fields) in structs.items():
+            if rname == ty:
+                return struct_layout(fields)[0:2]
+        raise AssertionError(ty)
+
+    def struct_layout(fields):
+        off, al_max, offs = 0, 1, []
+        for _, ty in fields:
+            s, al = layout(ty)
+            off = (off + al - 1) // al * al
+            offs.append(off)
+            off += s
+            al_max = max(al_max, al)
+        return (off + al_max - 1) // al_max * al_max, al_max, offs
+
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "vgpu.h"', "int main(void) {"]
+    for cname, (_, fields) in structs.items():
+        prog.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in fields:
+            prog.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        prog.append('printf("\\n");')
+    prog.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", exe], check=True, capture_output=True)
+    lines = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    assert len(lines) == len(structs) >= 8
+    for line in lines:
+        cname, size, *offs = line.split()
+        want_size, _, want_offs = struct_layout(structs[cname][1])
+        assert (int(size), [int(o) for o in offs]) == (want_size, want_offs), cname
