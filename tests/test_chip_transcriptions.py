@@ -187,3 +187,42 @@ def test_interaction_columns_are_the_reference_fields(machine, shapes):
         for side, its in (("product", machine.interactions(i)), ("oracle", va.decode_interaction_words(po.interactions(i)))):
             got = [{"count": (x["count"][0], [tuple(t) for t in x["count"][1]]), "fields": [(c, [tuple(t) for t in ts]) for c, ts in x["fields"]]} for x in its]
             assert got == want[name], (name, side)
+
+
+def test_transcript_order_of_the_rust_prover_replays_the_proof(shapes, rc, fib25):
+    """The Fiat-Shamir events of `fn prove` (basic/src/lib.rs:185-263,601-619), extracted from the Rust source IN SOURCE ORDER, replayed on a
+    fresh challenger with the commitments of an actual proof, must give that proof's permutation challenges, alpha and zeta: the order in
+    which the restated prover (and the device prover, whose proofs equal its) observes and samples is the reference's, not a recollection."""
+    import valida_amd as va
+    from oracle import pyoracle as po
+
+    t = shapes["transcript"]
+    # verify observes the same things in the same order (its names differ: the proof's commitments)
+    assert [(e[0], e[2] if e[0] == "sample_ext" else None) for e in t["prove"]][:-1] == [(e[0], e[2] if e[0] == "sample_ext" else None) for e in t["verify"]][:-1]
+    assert t["prove"][-1] == ["pcs", "open_multi_batches"] and t["verify"][-1] == ["pcs", "verify_multi_batches"]
+    assert t["opened_rounds"] == [["main_data", "zeta_and_next"], ["perm_data", "zeta_and_next"], ["quotient_data", "zeta_exp_quotient_degree"]]
+    assert t["points"] == {"zeta_and_next": "g_subgroups.map(|g| vec![zeta, zeta * g])",
+                           "zeta_exp_quotient_degree": "log_quotient_degrees.map(|log_deg| vec![zeta.exp_power_of_2(log_deg)])"}
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    proof = po.prove_basic(mt, prep[0][1], prep[1][1], rc, num_queries=4)
+    commits = {"preprocessed_commit": proof.transcript[0:8], "main_commit": proof.words[2:10], "perm_commit": proof.words[10:18], "quotient_commit": proof.words[18:26]}
+    ch = va.Challenger(rc)
+    sampled = {}
+    for ev in t["prove"]:
+        if ev[0] == "observe":
+            ch.observe(commits[ev[1]])
+        elif ev[0] == "sample_ext":
+            sampled[ev[1]] = ch.sample(5 * ev[2])
+    assert sampled["perm_challenges"].tolist() == proof.transcript[8:23].tolist()
+    assert sampled["alpha"].tolist() == proof.transcript[23:28].tolist()
+    assert sampled["zeta"].tolist() == proof.transcript[28:33].tolist()
+    # every chip is opened at two points in the main and permutation rounds and at one in the quotient round (the proof's five vectors per chip)
+    pos = 26
+    for chip in range(14):
+        pos += 1
+        lens = []
+        for _ in range(5):
+            lens.append(int(proof.words[pos]))
+            pos += 1 + 5 * lens[-1]
+        pos += 5
+        assert lens[0] == lens[1] and lens[2] == lens[3] and lens[4] == 10

@@ -310,11 +310,41 @@ def interactions_of(chip, consts):
     return out
 
 
+# ---------------------------------------------------------------- transcript order of Machine::prove / verify
+def transcript():
+    """The Fiat-Shamir events of `fn prove` and `fn verify` of basic/src/lib.rs in source order: what is observed, what is sampled (with the
+    loop count where a sample sits in a `for _ in 0..N`), where the PCS takes the challenger over, and the opening points per round."""
+    src = strip_comments(read("basic/src/lib.rs"))
+    out = {}
+    for fn in ("prove", "verify"):
+        body = fn_body(src, fn)
+        events = []
+        for m in re.finditer(r"challenger\.observe\((\w+)|(\w+)(?:\.push\()?\s*(?::[^=;]*)?=?\s*challenger\s*\.sample_ext_element|pcs\s*\.(open_multi_batches|verify_multi_batches)\(", body):
+            if m.group(1):
+                events.append(["observe", m.group(1)])
+            elif m.group(3):
+                events.append(["pcs", m.group(3)])
+            else:
+                name = m.group(2)
+                count = 1
+                head = body[:m.start()]
+                loop = re.search(r"for _ in 0\.\.(\d+)\s*\{\s*$", head)
+                if loop:
+                    count = int(loop.group(1))
+                events.append(["sample_ext", name, count])
+        out[fn] = events
+    body = fn_body(src, "prove")
+    rounds = re.search(r"let prover_data_and_points = \[(.*?)\];", body, re.S).group(1)
+    out["opened_rounds"] = re.findall(r"\(&(\w+), (\w+)\.as_slice\(\)\)", rounds)
+    out["points"] = {k: re.sub(r"\s+", " ", v) for k, v in re.findall(r"let (zeta_and_next|zeta_exp_quotient_degree): [^=]*=\s*([^;]*);", body)}
+    return out
+
+
 def main():
     consts = constants()
     order = chip_order()
     shapes = {"source": "valida-xyz/valida Rust sources (tools/extract_reference_shapes.py)", "constants": consts, "opcodes": opcodes(), "chip_order": order,
-              "buses": bus_ids(), "chips": {}}
+              "buses": bus_ids(), "transcript": transcript(), "chips": {}}
     for chip in order:
         shape = columns(chip, consts)
         cons = eval_constraints(chip, shape, consts)
