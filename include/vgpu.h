@@ -219,6 +219,19 @@ int32_t vgpu_verify_multi_batches(const vgpu_config_t* cfg, const uint32_t* comm
                                   const uint32_t* widths, const uint32_t* n_points, const uint32_t* points, const uint32_t* values, uint64_t n_value_words,
                                   const uint32_t* proof, uint64_t n_proof_words, vgpu_challenger_t* ch);
 
+/* Machine::verify (basic/src/lib.rs:677-1064; verify_constraints, machine/src/verify.rs:11-107): checks a proof produced by vgpu_prove
+ * (flat "VPF1" words) against `machine` on the HOST — transcript, pcs.verify_multi_batches over the three rounds, every chip's AIR and
+ * permutation constraints out of domain against Z_H(zeta) * quotient(zeta), and that the chips' cumulative sums cancel.  Needs no device.
+ * preprocessed_commit: the commitment of the preprocessed traces (8 words; the reference's verifier recomputes it with
+ * pcs.commit_batches(preprocessed_traces), lib.rs:791-804: vgpu_host_commit_root does that on the host), or NULL for a machine without
+ * preprocessed traces.  Returns VGPU_OK when the proof is accepted, VGPU_ERR_INVALID_ARG with the reason in vgpu_last_error when not. */
+int32_t vgpu_verify(const vgpu_config_t* cfg, const vgpu_machine_t* machine, const uint32_t* preprocessed_commit, const uint32_t* proof_words,
+                    uint64_t n_words);
+/* pcs.commit_batches / commit_shifted_batches on the HOST (the same LDE and MMCS conventions as vgpu_commit_batches, plain O(n log n)
+ * code): for the small matrices a verifier commits itself.  mats[i]: canonical row-major heights[i] x widths[i]. */
+int32_t vgpu_host_commit_root(const vgpu_config_t* cfg, const uint32_t* const* mats, const uint64_t* heights, const uint64_t* widths, uint32_t n_mats,
+                              const uint32_t* coset_shifts, uint32_t root[8]);
+
 /* FRI fold_even_odd of an Ext5 vector (n x 5 words, bit-reversed domain order) — App. B10 */
 int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uint32_t beta[5], uint32_t* out);
 

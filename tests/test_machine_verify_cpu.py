@@ -1,0 +1,102 @@
+"""Machine::verify of the product (vgpu_verify, valida_amd/csrc/host/machine_verifier.hpp: basic/src/lib.rs:677-1064 + machine/src/verify.rs:11-107)
+and the host commit a verifier needs for the preprocessed traces (vgpu_host_commit_root) — host-only code, so everything here runs without
+a device.  Proofs come from the oracle (whose proofs the device prover reproduces word for word in the -m gpu suite); the oracle's own restated
+verifier is the second opinion."""
+import numpy as np
+import pytest
+
+import valida_amd as va
+from conftest import pow_machine, pow_trace
+from oracle import pyoracle as po
+
+P = va.P
+
+
+@pytest.mark.parametrize("hash_kind", [va.HASH_KECCAK256, va.HASH_POSEIDON16])
+def test_host_commit_root_is_the_oracles(rc, hash_kind):
+    """Mixed heights, injection at several levels, wide rows, coset shifts: the host LDE + MMCS give the root of the restated pcs.commit_batches."""
+    rng = np.random.default_rng(3)
+    shapes = [(64, 5), (256, 3), (64, 2), (8, 37), (1, 3), (256, 70), (2, 1)]
+    mats = [rng.integers(0, P, s, dtype=np.uint32) for s in shapes]
+    po.set_mmcs_hash(1 if hash_kind == va.HASH_POSEIDON16 else 0, rc)
+    try:
+        assert va.host_commit_root(mats, rc, hash_kind=hash_kind).tolist() == po.commit_root(mats).tolist()
+        shifts = [int(x) for x in rng.integers(1, P, len(mats))]
+        assert va.host_commit_root(mats, rc, coset_shifts=shifts, hash_kind=hash_kind).tolist() == po.commit_root(mats, shifts=shifts).tolist()
+        assert va.host_commit_root(mats[:3], rc, log_blowup=2, hash_kind=hash_kind).tolist() == po.commit_root(mats[:3], log_blowup=2).tolist()
+    finally:
+        po.set_mmcs_hash(0)
+
+
+def _prep_commit(prep, rc, **kw):
+    return va.host_commit_root([m for _, m in prep], rc, **kw)
+
+
+@pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(40), lambda: va.Workload.named("static_data")], ids=["fib25", "alu40", "static_data"])
+def test_verify_accepts_honest_proofs_and_recomputes_the_preprocessed_commitment(machine, rc, make):
+    w = make()
+    mt, prep = w.main_traces(), w.preprocessed()
+    proof = po.prove_basic(mt, prep[0][1], prep[1][1], rc, num_queries=6)
+    pc = _prep_commit(prep, rc)
+    assert pc.tolist() == proof.transcript[0:8].tolist()  # what the prover observed first (lib.rs:200)
+    assert va.verify(machine, rc, proof.words, pc, num_queries=6) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc, num_queries=6) is None
+    # the preprocessed commitment is part of the statement
+    bad = pc.copy()
+    bad[3] ^= 1
+    assert va.verify(machine, rc, proof.words, bad, num_queries=6) is not None
+    assert va.verify(machine, rc, proof.words, None, num_queries=6) is not None
+    # another configuration is another transcript
+    assert va.verify(machine, rc, proof.words, pc, num_queries=6, pow_bits=24) is not None  # the 8-bit witness would have to carry 16 more zero bits
+    assert va.verify(machine, rc, proof.words, pc, num_queries=7) is not None
+
+
+def test_verify_rejects_every_kind_of_tampering(machine, rc, fib25):
+    """One mutated word anywhere — roots, opened values, cumulative sums, FRI roots, sibling values, paths, final polynomial, witness, opened
+    rows — must be rejected, with the product's verifier agreeing with the oracle's on every sample."""
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    proof = po.prove_basic(mt, prep[0][1], prep[1][1], rc, num_queries=3)
+    pc = _prep_commit(prep, rc)
+    words = proof.words
+    assert va.verify(machine, rc, words, pc, num_queries=3) is None
+    rng = np.random.default_rng(9)
+    # every word of the head (roots, per-chip openings, cumulative sums) in strides, plus random positions of the tail
+    head_end = 26
+    for _ in range(14):
+        head_end += 1
+        for _ in range(5):
+            head_end += 1 + 5 * int(words[head_end])
+        head_end += 5
+    positions = list(range(2, head_end, 7)) + [int(x) for x in rng.integers(head_end, words.size, 160)]
+    reasons = set()
+    for at in positions:
+        bad = words.copy()
+        bad[at] = (int(bad[at]) + 1) % P if bad[at] < P else 0
+        if np.array_equal(bad, words):
+            continue
+        got = va.verify(machine, rc, bad, pc, num_queries=3)
+        assert got is not None, "mutation of word %d accepted" % at
+        assert po.verify_basic(prep[0][1], prep[1][1], bad, rc, num_queries=3) is not None
+        reasons.add(got.split(":")[-1].strip()[:40])
+    assert len(reasons) >= 5  # several different checks fired: Merkle openings, folded values, constraint mismatch, length fields, sums ..
+    # a cumulative sum moved from one chip to another keeps the total but breaks both chips' last-row constraint
+    assert va.verify(machine, rc, words[:-1], pc, num_queries=3) is not None
+    assert va.verify(machine, rc, np.concatenate([words, [0]]).astype(np.uint32), pc, num_queries=3) is not None
+
+
+def test_verify_of_captured_airs_with_higher_quotient_degree(rc):
+    """AIRs captured through vgpu_air_* (degree 5 and 9: log_quotient_degree 2 and 3, four and eight quotient chunks recomposed with
+    reverse_slice_index_bits), blowup 8, no preprocessed traces."""
+    mach, codes = pow_machine([("pow9", 9, True), ("pow5", 5, False)])
+    assert codes == [0, 0]
+    traces = [pow_trace(8, 9, 3), pow_trace(32, 5, 3)]
+    proof = po.prove_machine([po.TEST_POW9, po.TEST_POW5], traces, rc, log_blowup=3, num_queries=5, pow_bits=4)
+    kw = dict(log_blowup=3, num_queries=5, pow_bits=4)
+    assert va.verify(mach, rc, proof.words, None, **kw) is None
+    assert po.verify_machine([po.TEST_POW9, po.TEST_POW5], proof.words, rc, **kw) is None
+    bad = proof.words.copy()
+    bad[30] = (int(bad[30]) + 1) % P
+    assert va.verify(mach, rc, bad, None, **kw) is not None
+    # the same words against a machine whose first chip does not pin its first row: another AIR, another fold
+    other, _ = pow_machine([("pow9", 9, False), ("pow5", 5, False)])
+    assert va.verify(other, rc, proof.words, None, **kw) is not None

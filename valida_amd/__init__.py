@@ -544,6 +544,42 @@ def verify_multi_batches(commits, heights, widths, points, values, proof_words, 
     return None if code == 0 else lib().vgpu_last_error().decode()
 
 
+def _config(rc, log_blowup=1, num_queries=40, pow_bits=8, hash_kind=HASH_KECCAK256, observe_final_poly=False):
+    cfg = VgpuConfig()
+    cfg.log_blowup, cfg.num_queries, cfg.pow_bits, cfg.hash_kind, cfg.observe_final_poly = log_blowup, num_queries, pow_bits, int(hash_kind), int(observe_final_poly)
+    r = np.ascontiguousarray(rc, dtype=np.uint32)
+    ctypes.memmove(cfg.poseidon_rc, r.ctypes.data, 480 * 4)
+    return cfg
+
+
+def verify(machine, rc, proof_words, preprocessed_commit=None, **cfg_kw):
+    """Machine::verify on the host (vgpu_verify; no device needed): None if the proof is accepted, else the rejection message.
+    preprocessed_commit: 8 words (host_commit_root of the preprocessed traces, as the reference's verifier recomputes it), None for a machine without."""
+    cfg = _config(rc, **cfg_kw)
+    pw, pwp = _u32(proof_words)
+    pc = None
+    if preprocessed_commit is not None:
+        pcv, pc = _u32(preprocessed_commit)
+    code = lib().vgpu_verify(ctypes.byref(cfg), machine._h, pc, pwp, ctypes.c_uint64(pw.size))
+    return None if code == 0 else lib().vgpu_last_error().decode()
+
+
+def host_commit_root(matrices, rc, coset_shifts=None, **cfg_kw):
+    """pcs.commit_batches on the host (vgpu_host_commit_root): the root vgpu_commit_batches gives on the device; for the small matrices a
+    verifier commits itself."""
+    cfg = _config(rc, **cfg_kw)
+    keep = [np.ascontiguousarray(m, dtype=np.uint32) for m in matrices]
+    ptrs = (c_u32p * len(keep))(*[k.ctypes.data_as(c_u32p) for k in keep])
+    hs = (ctypes.c_uint64 * len(keep))(*[k.shape[0] for k in keep])
+    ws = (ctypes.c_uint64 * len(keep))(*[k.shape[1] for k in keep])
+    sh = None
+    if coset_shifts is not None:
+        shv, sh = _u32(coset_shifts)
+    root = np.zeros(8, dtype=np.uint32)
+    _check(lib().vgpu_host_commit_root(ctypes.byref(cfg), ptrs, hs, ws, ctypes.c_uint32(len(keep)), sh, root.ctypes.data_as(c_u32p)))
+    return root
+
+
 def commit_batches_sharded_local(provers, matrices, coset_shifts=None):
     """One commitment round sharded over len(provers) prover contexts of this process (vgpu_commit_batches_sharded_local):
     returns the root, which equals provers[0].commit_batches(..).root."""

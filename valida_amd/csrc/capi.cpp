@@ -11,6 +11,7 @@
 #include "host/sharded.hpp"
 #include "host/sharded_prover.hpp"
 #include "host/verifier.hpp"
+#include "host/machine_verifier.hpp"
 #include "host/poseidon_opt.hpp"
 #include "host/prover.hpp"
 #include "workload/basic_vm.hpp"
@@ -558,6 +559,34 @@ int32_t vgpu_verify_multi_batches(const vgpu_config_t* cfg, const uint32_t* comm
         }
         if (vw != n_value_words) throw std::invalid_argument("verify: too many opened values");
         verify_multi_batches(rounds, proof, (size_t)n_proof_words, *ch->ch, cfg->log_blowup, cfg->num_queries, cfg->pow_bits, cfg->observe_final_poly != 0, mmcs);
+    })
+}
+static FriParams fri_of(const vgpu_config_t* cfg) {
+    FriParams f;
+    f.log_blowup = cfg->log_blowup; f.num_queries = cfg->num_queries; f.pow_bits = cfg->pow_bits;
+    f.observe_final_poly = cfg->observe_final_poly != 0; f.hash_kind = (int)cfg->hash_kind;
+    return f;
+}
+int32_t vgpu_verify(const vgpu_config_t* cfg, const vgpu_machine_t* machine, const uint32_t* preprocessed_commit, const uint32_t* proof_words,
+                    uint64_t n_words) {
+    VG_TRY({
+        if (!cfg || !machine || !proof_words) throw std::invalid_argument("null argument");
+        if (cfg->hash_kind > 1) throw std::invalid_argument("unknown hash kind");
+        Poseidon16 perm(cfg->poseidon_rc);
+        verify_machine_proof(machine->desc, fri_of(cfg), perm, preprocessed_commit, proof_words, (size_t)n_words);
+    })
+}
+int32_t vgpu_host_commit_root(const vgpu_config_t* cfg, const uint32_t* const* mats, const uint64_t* heights, const uint64_t* widths, uint32_t n_mats,
+                              const uint32_t* coset_shifts, uint32_t root[8]) {
+    VG_TRY({
+        if (!cfg || !mats || !heights || !widths || !n_mats || !root) throw std::invalid_argument("null argument");
+        if (cfg->hash_kind > 1) throw std::invalid_argument("unknown hash kind");
+        Poseidon16 perm(cfg->poseidon_rc);
+        HostMmcs mmcs{(int)cfg->hash_kind, &perm};
+        std::vector<HostMatrixView> v;
+        for (uint32_t i = 0; i < n_mats; i++) { if (!mats[i]) throw std::invalid_argument("null matrix"); v.push_back({mats[i], heights[i], widths[i]}); }
+        Digest8 d = host_commit_root(v, coset_shifts, cfg->log_blowup, mmcs);
+        memcpy(root, d.data(), 32);
     })
 }
 uint64_t vgpu_opening_values_len(const vgpu_opening_t* o) { return o->values.size(); }
