@@ -257,6 +257,10 @@ int32_t vgpu_ticket_wait(vgpu_ticket_t* t, vgpu_proof_t** out);   /* consumes th
 #define VGPU_CBOR_CANONICAL_FIELDS 1u  /* BabyBear as canonical u32 instead of the derived {"value": <Montgomery word>} */
 #define VGPU_CBOR_PLAIN_DIGESTS 2u     /* commitments as [Val; 8] instead of Hash { value, _marker } */
 int64_t vgpu_proof_cbor(const uint32_t* proof_words, uint64_t n_words, uint32_t flags, uint8_t* out, uint64_t cap_bytes);
+/* The way back (ciborium::from_reader on the verifier's side; the reference's tests verify a proof after exactly this round trip,
+ * basic/tests/test_prover.rs:456-469): CBOR image -> proof words.  Accepts either setting of the two switches per value.  Returns the word
+ * count (copies when out has room), or a negative status with the reason in vgpu_last_error. */
+int64_t vgpu_proof_from_cbor(const uint8_t* bytes, uint64_t n_bytes, uint32_t* out, uint64_t cap_words);
 uint64_t vgpu_proof_len(const vgpu_proof_t* pr);            /* u32 words of the flat "VPF1" encoding */
 const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr);
 /* 11 doubles, ms: ingest, commit_main, perm, commit_perm, quotient, commit_quotient, open_values, open_reduce, fri, queries, total */

@@ -100,3 +100,47 @@ def test_verify_of_captured_airs_with_higher_quotient_degree(rc):
     # the same words against a machine whose first chip does not pin its first row: another AIR, another fold
     other, _ = pow_machine([("pow9", 9, False), ("pow5", 5, False)])
     assert va.verify(other, rc, proof.words, None, **kw) is not None
+
+
+@pytest.mark.parametrize("flags", [0, va.CBOR_CANONICAL_FIELDS, va.CBOR_PLAIN_DIGESTS, va.CBOR_CANONICAL_FIELDS | va.CBOR_PLAIN_DIGESTS])
+def test_verify_after_the_cbor_round_trip_like_the_references_tests(machine, rc, fib25, flags):
+    """basic/tests/test_prover.rs:456-469: the reference serialises the proof with ciborium, reads it back and verifies THAT.  Here: proof
+    words -> vgpu_proof_cbor -> vgpu_proof_from_cbor -> vgpu_verify, for either setting of the two encoding switches; the decoder is also
+    held against the independent Python encoder of the serde data model (oracle/cbor_ref.py)."""
+    from oracle import cbor_ref
+
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    words = po.prove_basic(mt, prep[0][1], prep[1][1], rc, num_queries=5).words
+    blob = va.proof_cbor(words, flags)
+    back = va.proof_from_cbor(blob)
+    assert np.array_equal(back, words)
+    assert va.verify(machine, rc, back, va.host_commit_root([m for _, m in prep], rc), num_queries=5) is None
+    model = cbor_ref.model(words, bool(flags & va.CBOR_CANONICAL_FIELDS), bool(flags & va.CBOR_PLAIN_DIGESTS))
+    assert np.array_equal(va.proof_from_cbor(cbor_ref.encode(model)), words)
+    # malformed images are refused: truncation, trailing bytes, a renamed field, a field element out of range, an indefinite-length array
+    for bad in (blob[:-1], blob + b"\x00", blob.replace(b"perm_trace", b"perm_tracf"), blob.replace(b"log_degree", b"log_degred"), b"", b"\x9f\xff"):
+        with pytest.raises(va.VgpuError):
+            va.proof_from_cbor(bad)
+    if flags & va.CBOR_CANONICAL_FIELDS:
+        out_of_range = cbor_ref.model(words, True, bool(flags & va.CBOR_PLAIN_DIGESTS))
+        out_of_range["opening_proof"]["fri_proof"]["pow_witness"] = va.P
+        with pytest.raises(va.VgpuError):
+            va.proof_from_cbor(cbor_ref.encode(out_of_range))
+
+
+def test_verify_command_line(tmp_path, rc, fib25):
+    """python -m valida_amd.verify_cli: the product's `valida verify` (no oracle behind it) on CBOR and on raw proof words."""
+    from valida_amd import verify_cli as tool
+
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    words = po.prove_basic(mt, prep[0][1], prep[1][1], rc).words
+    f = tmp_path / "proof.cbor"
+    for flags in (0, va.CBOR_CANONICAL_FIELDS | va.CBOR_PLAIN_DIGESTS):
+        f.write_bytes(va.proof_cbor(words, flags))
+        assert tool.main([str(f), "--program", "fib", "--n", "25"]) == 0
+    assert tool.main([str(f), "--program", "fib", "--n", "26"]) == 1  # another program's ROM: another preprocessed commitment
+    assert tool.main([str(f), "--program", "fib", "--n", "25", "--queries", "39"]) == 1
+    f.write_bytes(words.astype("<u4").tobytes())
+    assert tool.main([str(f), "--program", "fib", "--n", "25"]) == 0
+    f.write_bytes(b"not a proof")
+    assert tool.main([str(f), "--program", "fib", "--n", "25"]) == 1

@@ -468,6 +468,21 @@ def proof_cbor(words, flags=0):
     return bytes(buf)
 
 
+def proof_from_cbor(data):
+    """VPF1 proof words from the CBOR image of a MachineProof (vgpu_proof_from_cbor: what `ciborium::from_reader` does on the verifier's
+    side; host-only).  Either setting of the two encoding switches is accepted.  Raises VgpuError on malformed input."""
+    b = bytes(data)
+    buf = (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(b if b else b"\0")
+    L = lib()
+    L.vgpu_proof_from_cbor.restype = ctypes.c_int64
+    n = L.vgpu_proof_from_cbor(buf, ctypes.c_uint64(len(b)), None, ctypes.c_uint64(0))
+    if n < 0:
+        _check(int(n))
+    out = np.zeros(int(n), dtype=np.uint32)
+    L.vgpu_proof_from_cbor(buf, ctypes.c_uint64(len(b)), out.ctypes.data_as(c_u32p), ctypes.c_uint64(int(n)))
+    return out
+
+
 class Comm:
     """RCCL communicator owned by the library (one process per GPU): the path's one collective without Python in the loop."""
 

@@ -18,6 +18,7 @@
 //   CBOR_PLAIN_DIGESTS      commitments / path nodes as bare [Val; 8] (default: Hash { value: [Val; 8], _marker: PhantomData })
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -154,5 +155,146 @@ class ProofCborEncoder {
 };
 
 inline std::vector<uint8_t> proof_to_cbor(const uint32_t* words, size_t n, uint32_t flags) { return ProofCborEncoder(words, n, flags).encode(); }
+
+// The way back (`ciborium::from_reader`, basic/src/bin/valida.rs verify path; the reference's tests verify a proof after exactly this round
+// trip, basic/tests/test_prover.rs:456-469): the CBOR image -> "VPF1" proof words.  Strict about structure (the maps' keys in declaration
+// order, definite lengths, shortest-form integers are not required on input), and it accepts either setting of the two encoding switches
+// per value (a field element is a bare integer or {"value": <Montgomery word>}; a digest a bare array or {value, _marker}).
+class ProofCborDecoder {
+  public:
+    ProofCborDecoder(const uint8_t* bytes, size_t n) : b_(bytes), n_(n) {}
+    std::vector<uint32_t> decode() {
+        std::vector<uint32_t> roots, chips, pcs;
+        map(3);
+        key("commitments");
+        map(3);
+        const char* names[3] = {"main_trace", "perm_trace", "quotient_chunks"};
+        for (int r = 0; r < 3; r++) { key(names[r]); digest(roots); }
+        key("opening_proof");
+        pcs_proof(pcs);
+        key("chip_proofs");
+        const uint64_t nc = array();
+        if (nc > 4096) bad("implausible number of chip proofs");
+        for (uint64_t c = 0; c < nc; c++) chip_proof(chips);
+        if (pos_ != n_) bad("trailing bytes after the proof");
+        std::vector<uint32_t> w;
+        w.reserve(2 + roots.size() + chips.size() + pcs.size());
+        w.push_back(0x31465056u);
+        w.push_back((uint32_t)nc);
+        w.insert(w.end(), roots.begin(), roots.end());
+        w.insert(w.end(), chips.begin(), chips.end());
+        w.insert(w.end(), pcs.begin(), pcs.end());
+        return w;
+    }
+
+  private:
+    const uint8_t* b_;
+    size_t n_, pos_ = 0;
+    [[noreturn]] static void bad(const char* why) { throw std::invalid_argument(std::string("cbor: ") + why); }
+    uint8_t byte() { if (pos_ >= n_) bad("truncated input"); return b_[pos_++]; }
+    // (major type, argument) of the next item; only the definite-length forms a serde / ciborium writer produces
+    std::pair<unsigned, uint64_t> head() {
+        const uint8_t ib = byte();
+        const unsigned major = ib >> 5, info = ib & 31;
+        uint64_t v = info;
+        if (info >= 24) {
+            if (info > 27) bad("indefinite lengths / reserved forms are not part of a proof");
+            const int nbytes = 1 << (info - 24);
+            v = 0;
+            for (int i = 0; i < nbytes; i++) v = (v << 8) | byte();
+        }
+        return {major, v};
+    }
+    uint64_t expect(unsigned major, const char* what) { auto h = head(); if (h.first != major) bad(what); return h.second; }
+    void map(uint64_t n) { if (expect(5, "expected a map") != n) bad("a struct has the wrong number of fields"); }
+    uint64_t array() { return expect(4, "expected an array"); }
+    void array(uint64_t n) { if (array() != n) bad("an array has the wrong length"); }
+    void key(const char* name) {
+        const uint64_t len = expect(3, "expected a field name");
+        const size_t want = std::char_traits<char>::length(name);
+        if (len != want || pos_ + len > n_ || memcmp(b_ + pos_, name, want) != 0) bad("unexpected field name (fields come in declaration order)");
+        pos_ += len;
+    }
+    uint32_t word(const char* what) { const uint64_t v = expect(0, what); if (v > 0xffffffffull) bad("integer out of range"); return (uint32_t)v; }
+    uint32_t len(uint64_t unit) { const uint64_t l = array(); if (l * unit > n_ - pos_) bad("a length exceeds the input"); return (uint32_t)l; }
+    uint32_t val() {  // canonical field element
+        if (pos_ < n_ && (b_[pos_] >> 5) == 5) {
+            map(1); key("value");
+            const uint32_t m = word("expected a field element");
+            if (m >= vg::P) bad("field element out of range");
+            return vg::Fp::raw(m).canonical();
+        }
+        const uint32_t c = word("expected a field element");
+        if (c >= vg::P) bad("field element out of range");
+        return c;
+    }
+    void ext(std::vector<uint32_t>& out) {
+        if (pos_ < n_ && (b_[pos_] >> 5) == 5) { map(1); key("value"); }
+        array(5);
+        for (int k = 0; k < 5; k++) out.push_back(val());
+    }
+    void digest(std::vector<uint32_t>& out) {
+        const bool wrapped = pos_ < n_ && (b_[pos_] >> 5) == 5;
+        if (wrapped) { map(2); key("value"); }
+        array(8);
+        for (int k = 0; k < 8; k++) out.push_back(val());
+        if (wrapped) { key("_marker"); if (byte() != 0xf6) bad("expected null for PhantomData"); }
+    }
+    void path(std::vector<uint32_t>& out) {
+        const uint32_t l = len(9);
+        out.push_back(l);
+        for (uint32_t i = 0; i < l; i++) { array(8); for (int k = 0; k < 8; k++) out.push_back(val()); }
+    }
+    void ext_vec(std::vector<uint32_t>& out) { const uint32_t l = len(6); out.push_back(l); for (uint32_t i = 0; i < l; i++) ext(out); }
+    void chip_proof(std::vector<uint32_t>& out) {
+        map(3);
+        key("log_degree"); out.push_back(word("expected log_degree"));
+        key("opened_values");
+        map(7);
+        key("preprocessed_local"); array(0);
+        key("preprocessed_next"); array(0);
+        const char* names[5] = {"trace_local", "trace_next", "permutation_local", "permutation_next", "quotient_chunks"};
+        for (int v = 0; v < 5; v++) { key(names[v]); ext_vec(out); }
+        key("cumulative_sum"); ext(out);
+    }
+    void pcs_proof(std::vector<uint32_t>& out) {
+        map(2);
+        key("fri_proof");
+        map(4);
+        key("commit_phase_commits");
+        const uint32_t n_commits = len(9);
+        out.push_back(n_commits);
+        for (uint32_t i = 0; i < n_commits; i++) digest(out);
+        key("query_proofs");
+        const uint32_t nq = len(1);
+        out.push_back(nq);
+        for (uint32_t q = 0; q < nq; q++) {
+            map(1);
+            key("commit_phase_openings");
+            const uint32_t nl = len(1);
+            out.push_back(nl);
+            for (uint32_t l = 0; l < nl; l++) { map(2); key("sibling_value"); ext(out); key("opening_proof"); path(out); }
+        }
+        key("final_poly"); ext(out);
+        key("pow_witness"); out.push_back(val());
+        key("query_openings");
+        const uint32_t nq2 = len(1);
+        out.push_back(nq2);
+        for (uint32_t q = 0; q < nq2; q++) {
+            const uint32_t nr = len(1);
+            out.push_back(nr);
+            for (uint32_t r = 0; r < nr; r++) {
+                map(2);
+                key("opened_values");
+                const uint32_t nm = len(1);
+                out.push_back(nm);
+                for (uint32_t m = 0; m < nm; m++) { const uint32_t wd = len(1); out.push_back(wd); for (uint32_t k = 0; k < wd; k++) out.push_back(val()); }
+                key("opening_proof"); path(out);
+            }
+        }
+    }
+};
+
+inline std::vector<uint32_t> proof_from_cbor(const uint8_t* bytes, size_t n) { return ProofCborDecoder(bytes, n).decode(); }
 
 }  // namespace vhost
