@@ -144,3 +144,32 @@ def test_verify_command_line(tmp_path, rc, fib25):
     assert tool.main([str(f), "--program", "fib", "--n", "25"]) == 0
     f.write_bytes(b"not a proof")
     assert tool.main([str(f), "--program", "fib", "--n", "25"]) == 1
+
+
+def test_decoder_and_verifier_survive_random_corruption(machine, rc, fib25):
+    """A verifier reads adversarial input: random byte corruption of the CBOR image and random word corruption of the proof (including absurd
+    length fields) must end in a refusal — never in a crash, never in an accepted proof that differs from the honest one."""
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    words = po.prove_basic(mt, prep[0][1], prep[1][1], rc, num_queries=4).words
+    pc = va.host_commit_root([m for _, m in prep], rc)
+    blob = va.proof_cbor(words, va.CBOR_CANONICAL_FIELDS | va.CBOR_PLAIN_DIGESTS)
+    rng = np.random.default_rng(0)
+    refused = 0
+    for _ in range(600):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        try:
+            got = va.proof_from_cbor(bytes(b))
+        except va.VgpuError:
+            refused += 1
+            continue
+        if va.verify(machine, rc, got, pc, num_queries=4) is None:
+            assert np.array_equal(got, words)
+        else:
+            refused += 1
+    assert refused > 550
+    for _ in range(600):
+        bad = words.copy()
+        bad[int(rng.integers(0, bad.size))] = int(rng.integers(0, 2**32))
+        assert va.verify(machine, rc, bad, pc, num_queries=4) is not None or np.array_equal(bad, words)

@@ -125,3 +125,16 @@ def test_sharded_proof_refuses_what_it_does_not_implement(machine, rc, fib25):
     p = va.Prover(machine, rc)
     with pytest.raises(va.VgpuError, match="distinct"):
         va.prove_sharded_local([p, p], mt, prep)
+
+
+def test_device_proofs_pass_the_products_own_verifier(machine, rc, fib25):
+    """prove on the device, verify with the library's host-side Machine::verify (vgpu_verify; preprocessed commitment recomputed on the host by
+    vgpu_host_commit_root and equal to the one the device committed): the pair a host of this library uses, no oracle involved."""
+    for w in (fib25, va.Workload.alu(40)):
+        p0, mt, prep, single = single_and_inputs(machine, rc, w)
+        pc = va.host_commit_root([m for _, m in prep], rc)
+        assert first_mismatch(pc, single.transcript[0:8]) is None
+        assert va.verify(machine, rc, single.words, pc) is None
+        bad = single.words.copy()
+        bad[40] = (int(bad[40]) + 1) % va.P
+        assert va.verify(machine, rc, bad, pc) is not None
