@@ -37,6 +37,12 @@ def test_no_oracle_in_product_path():
                 assert "liboracle" not in src and "pyoracle" not in src and 'oracle/' not in src.replace("ORACLE", ""), os.path.join(base, f)
     out = subprocess.run(["ldd", os.path.join(ROOT, "valida_amd", "libvgpu.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+    # the verifier's host-side commit (vgpu_host_commit_root: host_ntt + a host MMCS, for the small preprocessed traces) is no fallback of the
+    # prover: no proving source reaches it
+    host = os.path.join(ROOT, "valida_amd", "csrc", "host")
+    for f in ("prover.cpp", "prover.hpp", "pcs.hpp", "sharded.hpp", "sharded_prover.cpp", "sharded_prover.hpp", "fabric.hpp", "runtime.hpp"):
+        src = open(os.path.join(host, f)).read()
+        assert "host_commit_root" not in src and "host_ntt" not in src and "machine_verifier" not in src, f
 
 
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
