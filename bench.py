@@ -10,7 +10,8 @@ as soon as the rank's proof is complete (segments are independent; SURVEY.md §8
 line.  Scaling is weak (one segment per GPU).
 
 Beside the headline the line carries (N = 1) the latency of a lone proof, the PCIe-inclusive and operation-log legs, the CPU baseline
-and `one_proof_over_w_ranks_on_this_gpu`: ONE proof sharded over W prover contexts of this device.  With N > 1
+`one_proof_over_w_ranks_on_this_gpu` (ONE proof sharded over W prover contexts of this device) and
+`proof_checked_by_vgpu_verify`: the last timed proof through the library's own host-side Machine::verify.  With N > 1
 the ranks finish by proving one segment TOGETHER through vgpu_prove_sharded (RCCL) — after the JSON line, reported on stderr.
 """
 import argparse
@@ -442,6 +443,18 @@ def main():
             prof[k] = (a[0] + v[0], a[1] + v[1], a[2] + v[2], a[3] + v[3])
         p_.set_profiling(False)
 
+    # the last proof of the timed region through the library's own Machine::verify (host code; never inside a timed region)
+    verified = None
+    try:
+        t0 = time.perf_counter()
+        pc_host = va.host_commit_root([m for _, m in prep], rc, log_blowup=prover.log_blowup, hash_kind=hash_kind)
+        msg = va.verify(machine, rc, p.words, pc_host, log_blowup=prover.log_blowup, num_queries=prover.num_queries, pow_bits=prover.pow_bits, hash_kind=hash_kind)
+        verified = {"accepted": msg is None, "ms": (time.perf_counter() - t0) * 1e3}
+        if msg is not None:
+            verified["reason"] = msg
+    except Exception as e:  # noqa: BLE001 - reporting only
+        verified = {"accepted": False, "reason": "%s: %s" % (type(e).__name__, e)}
+
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -557,6 +570,7 @@ def main():
                 "copies): what sharding costs, not a speed-up; the multi-GPU realisation (vgpu_prove_sharded over RCCL) is unmeasured here")),
             "prover_ms_single_proof_in_flight": single if single is not None else ms_per_step,
             "proof_words": int(p.words.size),
+            "proof_checked_by_vgpu_verify": verified,  # Machine::verify of the library (host) on the last timed proof
             "hbm_pool_peak_bytes": sum(p_.memory()[1] for p_ in provers),
         }
         if not args.no_cpu_baseline and world == 1:
