@@ -173,3 +173,18 @@ def test_decoder_and_verifier_survive_random_corruption(machine, rc, fib25):
         bad = words.copy()
         bad[int(rng.integers(0, bad.size))] = int(rng.integers(0, 2**32))
         assert va.verify(machine, rc, bad, pc, num_queries=4) is not None or np.array_equal(bad, words)
+
+
+def test_committed_proof_file_is_accepted(rc):
+    """tests/golden/fib25_q4_proof.cbor: prove_fibonacci (n = 25) proved by the oracle with 4 queries, written as CBOR (canonical fields, plain
+    digests) — the file `python -m valida_amd.verify_cli tests/golden/fib25_q4_proof.cbor --program fib --n 25 --queries 4` accepts."""
+    import os
+
+    from valida_amd import verify_cli
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib25_q4_proof.cbor")
+    assert verify_cli.main([path, "--program", "fib", "--n", "25", "--queries", "4"]) == 0
+    assert verify_cli.main([path, "--program", "fib", "--n", "25"]) == 1  # 40 queries expected, 4 given
+    words = va.proof_from_cbor(open(path, "rb").read())
+    assert words[0] == 0x31465056 and words[1] == 14
+    assert va.proof_cbor(words, va.CBOR_CANONICAL_FIELDS | va.CBOR_PLAIN_DIGESTS) == open(path, "rb").read()
