@@ -41,6 +41,19 @@ def make(n, name, log_blowup=1, out_dir=HERE, debug_check=True):
     print(name, out["proof_sha256"])
 
 
+def make_proof_file(out_dir=HERE):
+    """fib25_q4_proof.cbor: prove_fibonacci proved by the oracle with 4 queries, as the CBOR image the product writes (canonical fields,
+    plain digests) — the committed input of `python -m valida_amd.verify_cli` (tests/test_machine_verify_cpu.py)."""
+    rc = va.poseidon_round_constants()
+    w = va.Workload.fib(25)
+    mt, prep = w.main_traces(), w.preprocessed()
+    res = po.prove_basic(mt, prep[0][1], prep[1][1], rc, num_queries=4)
+    blob = va.proof_cbor(res.words, va.CBOR_CANONICAL_FIELDS | va.CBOR_PLAIN_DIGESTS)
+    with open(os.path.join(out_dir, "fib25_q4_proof.cbor"), "wb") as f:
+        f.write(blob)
+    print("fib25_q4_proof.cbor", hashlib.sha256(blob).hexdigest())
+
+
 def make_full(out_dir, which):
     """BASELINE.json's full-size configurations (C2, C4, C3): minutes of oracle time on a many-core host — run once on the
     GPU box's host through gpurun (`python tests/golden/make_golden.py --full gpurun_out/golden c2 c4 c3`), then commit the
@@ -62,3 +75,4 @@ if __name__ == "__main__":
     for prog in ("left_imm_ops", "signed_inequality", "loadfp", "static_data"):  # basic/tests/test_prover.rs:190-402, test_static_data.rs:31-59
         make(prog, prog + "_oracle.json")
     make(("alu", 100), "alu100_oracle.json")
+    make_proof_file()
