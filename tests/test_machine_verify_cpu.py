@@ -188,3 +188,22 @@ def test_committed_proof_file_is_accepted(rc):
     words = va.proof_from_cbor(open(path, "rb").read())
     assert words[0] == 0x31465056 and words[1] == 14
     assert va.proof_cbor(words, va.CBOR_CANONICAL_FIELDS | va.CBOR_PLAIN_DIGESTS) == open(path, "rb").read()
+
+
+def test_verify_with_the_poseidon_mmcs(machine, rc, fib25):
+    """hash_kind = VGPU_HASH_POSEIDON16 end to end on the verifier's side: host commit of the preprocessed traces, Merkle openings, FRI layer trees."""
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    po.set_mmcs_hash(1, rc)
+    try:
+        proof = po.prove_basic(mt, prep[0][1], prep[1][1], rc, num_queries=5)
+        assert po.verify_basic(prep[0][1], prep[1][1], proof.words, rc, num_queries=5) is None
+    finally:
+        po.set_mmcs_hash(0)
+    kw = dict(num_queries=5, hash_kind=va.HASH_POSEIDON16)
+    pc = va.host_commit_root([m for _, m in prep], rc, hash_kind=va.HASH_POSEIDON16)
+    assert pc.tolist() == proof.transcript[0:8].tolist()
+    assert va.verify(machine, rc, proof.words, pc, **kw) is None
+    assert va.verify(machine, rc, proof.words, pc, num_queries=5) is not None  # a Keccak verifier does not accept a Poseidon-committed proof
+    bad = proof.words.copy()
+    bad[-3] = (int(bad[-3]) + 1) % P
+    assert va.verify(machine, rc, bad, pc, **kw) is not None
