@@ -92,3 +92,16 @@ def test_a_fold_of_a_shard_is_the_shard_of_the_fold():
             sh = f[r * Lp:(r + 1) * Lp]
             out = [((sh[2 * i] + sh[2 * i + 1]) * i2 + bp * (sh[2 * i] - sh[2 * i + 1]) % P * i2 % P * inv(domain_point(2 * i))) % P for i in range(Lp // 2)]
             assert out == ref[r * Lp // 2:(r + 1) * Lp // 2]
+
+
+def test_model_of_the_ntt_pipeline_without_a_bit_reversal_pass():
+    """tools/ntt_fused_model.py: the pass structure planned for folding k_bitrev_rows into the transforms, as integers mod p,
+    gives the oracle's committed LDE."""
+    import os
+    import subprocess
+    import sys
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root_dir, "tools", "ntt_fused_model.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("gives the committed LDE") == 4
