@@ -17,15 +17,17 @@ import valida_amd as va  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 
-def make(n, name, log_blowup=1, out_dir=HERE, debug_check=True):
-    """n: Fibonacci loop bound, or the name of one of the reference's other pinned programs / ("alu", iters)."""
+def make(n, name, log_blowup=1, out_dir=HERE, debug_check=True, hash_kind=0):
+    """n: Fibonacci loop bound, or the name of one of the reference's other pinned programs / ("alu", iters).
+    hash_kind 1: the Poseidon-16 MMCS (BASELINE.json's north-star Merkle variant) instead of the reference's Keccak-256."""
     rc = va.poseidon_round_constants()
+    po.set_mmcs_hash(hash_kind, rc)
     w = va.Workload.fib(n) if isinstance(n, int) else va.Workload.alu(n[1]) if isinstance(n, tuple) else va.Workload.named(n)
     mt, prep = w.main_traces(), w.preprocessed()
     res = po.prove_basic(mt, prep[0][1], prep[1][1], rc, log_blowup=log_blowup, debug_check=debug_check)
     assert po.verify_basic(prep[0][1], prep[1][1], res.words, rc, log_blowup=log_blowup) is None
     out = {
-        "log_blowup": log_blowup, "oracle_seconds": round(res.seconds, 2), "host_cores": os.cpu_count(),
+        "log_blowup": log_blowup, "hash_kind": hash_kind, "oracle_seconds": round(res.seconds, 2), "host_cores": os.cpu_count(),
         "n": n,
         "poseidon_seed": "0x56414C494441",
         "cycles": w.cycles, "mem_ops": w.mem_ops, "add_ops": w.add_ops, "result": w.result,
@@ -38,6 +40,7 @@ def make(n, name, log_blowup=1, out_dir=HERE, debug_check=True):
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, name), "w") as f:
         json.dump(out, f, indent=1)
+    po.set_mmcs_hash(0)
     print(name, out["proof_sha256"])
 
 
@@ -64,6 +67,8 @@ def make_full(out_dir, which):
         make(("alu", 116507), "full_c4_alu116507.json", 1, out_dir, debug_check=False)
     if "c3" in which:
         make(599183, "full_c3_fib599183_blowup4.json", 2, out_dir, debug_check=False)
+    if "c2p" in which:  # the configuration `bench.py --mmcs poseidon` times
+        make(149794, "full_c2_fib149794_poseidon.json", 1, out_dir, debug_check=False, hash_kind=1)
 
 
 if __name__ == "__main__":

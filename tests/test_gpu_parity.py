@@ -292,9 +292,17 @@ def test_full_size_c4_alu_2_20(prover, rc):
 def test_full_size_c3_fib_2_22_blowup4(machine, rc):
     w = va.Workload.fib(599183)
     assert w.cpu_height == 1 << 22 and w.main_trace(2).shape[0] == 1 << 24
-    # the oracle would need a quarter of an hour here: this size gets the round-trip properties (restated verifier, determinism,
-    # tamper rejection); the same configuration is compared word for word at 2^18 rows in the next test
-    _full_size_round_trip(va.Prover(machine, rc, log_blowup=2), w, rc, 2, oracle_words=False)
+    # every word is pinned by the fixture (the oracle's proof of this workload: tests/golden/make_golden.py --full .. c3, a quarter of an
+    # hour of host time, done once); the same configuration is also compared word for word at 2^18 rows in the next test
+    assert _golden_full("full_c3_fib599183_blowup4.json") is not None
+    _full_size_round_trip(va.Prover(machine, rc, log_blowup=2), w, rc, 2, golden="full_c3_fib599183_blowup4.json", oracle_words=False)
+
+
+def test_full_size_c2_poseidon_mmcs(machine, rc, poseidon_oracle):
+    # the configuration `bench.py --mmcs poseidon` times (C2 with the Poseidon-16 MMCS): pinned by the oracle's proof of it
+    w = va.Workload.fib(149794)
+    assert _golden_full("full_c2_fib149794_poseidon.json") is not None
+    _full_size_round_trip(va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16), w, rc, 1, golden="full_c2_fib149794_poseidon.json", oracle_words=False)
 
 
 def test_c3_shape_at_2_18_blowup4_every_word(machine, rc):
@@ -397,7 +405,8 @@ def test_bad_inputs_are_rejected_not_crashed(prover, fib25, rc):
 
 
 # ---- LDE at the large heights: both four-step splits (2^12-point tiles up to 2^22, 2^14-point tiles from 2^23) ------
-@pytest.mark.parametrize("log_h,w,log_blowup", [(18, 3, 1), (20, 2, 1), (22, 1, 1), (23, 1, 1), (24, 1, 1), (22, 1, 2), (23, 2, 2)])
+@pytest.mark.parametrize("log_h,w,log_blowup", [(13, 5, 1), (14, 3, 2), (16, 2, 1), (18, 3, 1), (20, 2, 1), (22, 1, 1), (23, 1, 1), (24, 1, 1), (22, 1, 2), (23, 2, 2),
+                                                   (24, 1, 2)])  # (24, 1, 2): the 2^26-row LDE of C3's memory chip, element for element
 def test_large_lde_matches_oracle(machine, rc, log_h, w, log_blowup):
     p = va.Prover(machine, rc, log_blowup=log_blowup)
     rng = np.random.default_rng(4000 + log_h)

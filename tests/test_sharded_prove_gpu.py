@@ -1,10 +1,13 @@
 """§8(f)-4 completed: ONE proof over W ranks (vgpu_prove_sharded / vgpu_prove_sharded_local) must be, word for word, the proof
-vgpu_prove produces on one GPU (which the parity suite bit-matches against the oracle).  `world` prover contexts on this box's single GPU
+vgpu_prove produces on one GPU AND the oracle's proof of the same traces (computed here for the small workloads, the committed fixture
+tests/golden/full_c2_fib149794.json at the headline size): a regression that moves the single-GPU and the sharded prover together is caught.  `world` prover contexts on this box's single GPU
 stand in for the ranks (exchanges = device-to-device copies); over RCCL the same phases run with one rank per process — a world of one
 exercises that fabric here.
 
 Run on the MI355X box with `pytest -m gpu`.
 """
+import hashlib
+import json
 import os
 
 import numpy as np
@@ -12,6 +15,7 @@ import pytest
 
 import valida_amd as va
 from conftest import first_mismatch
+from oracle import pyoracle as po  # checker only
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +53,26 @@ def assert_same_proof(got, want):
         raise AssertionError("%s -- first difference in: %s" % (d, where(want, at)))
 
 
+def assert_oracle_proof(words, mt, prep, rc, hash_kind=0, log_blowup=1):
+    """The oracle proves the same traces now: every word of the sharded proof against it (not only against the single-GPU product proof)."""
+    po.set_mmcs_hash(hash_kind, rc)
+    try:
+        ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc, log_blowup=log_blowup)
+    finally:
+        po.set_mmcs_hash(0)
+    assert_same_proof(words, ref.words)
+
+
+def assert_fixture(proof, mt, name):
+    """Committed fixture of the oracle's proof (tests/golden/make_golden.py --full): commitments, transcript, length, sha256 of the bytes."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", name)) as f:
+        g = json.load(f)
+    assert hashlib.sha256(b"".join(m.tobytes() for m in mt)).hexdigest() == g["traces_sha256"]
+    assert [int(x) for x in proof.words[2:26]] == g["commitments"]
+    assert int(proof.words.size) == g["proof_words"]
+    assert hashlib.sha256(proof.bytes()).hexdigest() == g["proof_sha256"]
+
+
 def single_and_inputs(machine, rc, workload, **cfg):
     p = va.Prover(machine, rc, **cfg)
     mt, prep = workload.main_traces(), workload.preprocessed()
@@ -65,6 +89,7 @@ def test_sharded_proof_of_fib25_is_the_single_gpu_proof(machine, rc, fib25, worl
     provers = [p0] + [va.Prover(machine, rc) for _ in range(world - 1)]
     sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=2)
     assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc)
 
 
 @pytest.mark.parametrize("world,log_min", [(4, 12), (2, 10)])
@@ -76,6 +101,7 @@ def test_sharded_proof_with_sharded_and_replicated_chips(machine, rc, world, log
     provers = [p0] + [va.Prover(machine, rc) for _ in range(world - 1)]
     sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=log_min)
     assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc)
 
 
 def test_sharded_proof_of_the_alu_workload(machine, rc):
@@ -85,6 +111,7 @@ def test_sharded_proof_of_the_alu_workload(machine, rc):
     provers = [p0] + [va.Prover(machine, rc) for _ in range(3)]
     sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=6)
     assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc)
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -96,6 +123,7 @@ def test_sharded_proof_at_the_headline_size(machine, rc, world):
     provers = [p0] + [va.Prover(machine, rc) for _ in range(world - 1)]
     sharded = va.prove_sharded_local(provers, mt, prep)
     assert_same_proof(sharded.words, single.words)
+    assert_fixture(sharded, mt, "full_c2_fib149794.json")  # the ORACLE's proof of these traces, pinned
 
 
 def test_sharded_proof_with_the_poseidon_mmcs(machine, rc, fib25):
@@ -103,6 +131,7 @@ def test_sharded_proof_with_the_poseidon_mmcs(machine, rc, fib25):
     provers = [p0, va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16)]
     sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=3)
     assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc, hash_kind=va.HASH_POSEIDON16)
 
 
 def test_sharded_proof_over_the_rccl_fabric_world_of_one(machine, rc, fib25):
@@ -112,6 +141,7 @@ def test_sharded_proof_over_the_rccl_fabric_world_of_one(machine, rc, fib25):
     comm = va.Comm(p, va.Comm.unique_id(), 0, 1)
     sharded = comm.prove_sharded([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep], log_min_sharded=4)
     assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc)
 
 
 def test_sharded_proof_refuses_what_it_does_not_implement(machine, rc, fib25):
