@@ -126,6 +126,21 @@ def exchange_roots(dist, torch, commitments, device):
     return out.reshape(world, local.numel())
 
 
+def roofline_object(name, stat, achieved_gbs, traffic, traffic_src, valu, steps):
+    """The bench line's `roofline`: the BINDING roofline of the dominant kernel first (`bound` says which), the HBM figures the
+    contract asks for always present under `hbm` (and they are the primary ones when the kernel is HBM-bound)."""
+    launches, ms, nbytes, _ = stat
+    hbm = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+           "traffic_source": "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)" % traffic_src,
+           "algorithmic_bytes_per_launch": nbytes / launches if launches else None}
+    common = {"kernel": name, "launches_per_step": launches / steps, "avg_launch_ms": ms / launches if launches else None}
+    if valu is None:
+        return dict(hbm, **common, limited_by="hbm", hbm=hbm)
+    return dict(common, bound="valu", achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"], frac=valu["frac"], traffic=traffic,
+                limited_by="integer VALU issue (31-bit modular / Keccak lane arithmetic; no MFMA form exists), not HBM: `hbm` holds the contract's HBM figures",
+                peak_is=valu.get("peak_is"), hbm=hbm)
+
+
 def cpu_baseline(log_rows, rc, headline_log_rows):
     """The oracle (CPU restatement of the reference's algorithm, C++/OpenMP on every host core) timed on the SAME workload the GPU
     is timed on — the headline 2^20-row segment itself by default, one proof, no extrapolation.  It is a port ("kind": "port"):
@@ -523,13 +538,7 @@ def main():
                 "parallelism": ("segments: one independent proof per GPU + all-gather of 3 roots per proof via " + comm_note) if world > 1 else "single GPU",
                 "proofs_in_flight_per_gpu": len(provers),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)" % traffic_src,
-                "limited_by": "integer VALU issue, not HBM: see valu_roofline" if valu_ops > 0 else "hbm",
-                "launches_per_step": launches / args.steps, "avg_launch_ms": ms / launches if launches else None,
-                "algorithmic_bytes_per_launch": nbytes / launches if launches else None,
-            },
+            "roofline": roofline_object(name, prof[name], achieved, traffic, traffic_src, keccak_roofline(prof[name]) if valu_ops > 0 else None, args.steps),
             # The dominant kernel is Keccak-f[1600] over Merkle nodes: 32-bit integer VALU work, ~4200 instructions per 96 B moved, so
             # its binding roofline is the VALU issue rate, not HBM (SURVEY.md §8(d) caveat; DESIGN.md "Rooflines").
             "valu_roofline": None if valu_ops <= 0 else dict(keccak_roofline(prof[name]), kernel=name, microbench=mb["source"],
@@ -578,7 +587,12 @@ def main():
             if args.mmcs == "poseidon":
                 from oracle import pyoracle as po
                 po.set_mmcs_hash(1, rc)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_log_rows if args.cpu_log_rows else headline, rc, args.log_rows)
+            out["cpu_baseline"] = cb = cpu_baseline(args.cpu_log_rows if args.cpu_log_rows else headline, rc, args.log_rows)
+            if "note" not in cb and args.workload == "c2":  # the baseline proved the very workload `value` is quoted on
+                # BASELINE.md publishes no number; its one quantitative target is ">= 20x the CPU baseline timed in the same run" (section 2):
+                # that ratio, against what the baseline IS here (kind "port": scalar restatement, not Plonky3's packed AVX prover)
+                out["vs_baseline"] = value / cb["value"]
+                out["vs_baseline_is"] = "value / cpu_baseline.value of this run (kind: %s; BASELINE.md section 2 target >= 20x; no published number exists)" % cb["kind"]
         print(json.dumps(out), flush=True)
     if world > 1 and lib_comm is not None and not comm_stuck and prover.log_blowup == 1 and os.environ.get("VGPU_BENCH_SHARDED", "1") == "1":
         # After the contract line (nothing below can change it): ONE proof — rank 0's segment — over ALL the ranks (vgpu_prove_sharded over

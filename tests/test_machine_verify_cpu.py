@@ -2,6 +2,8 @@
 and the host commit a verifier needs for the preprocessed traces (vgpu_host_commit_root) — host-only code, so everything here runs without
 a device.  Proofs come from the oracle (whose proofs the device prover reproduces word for word in the -m gpu suite); the oracle's own restated
 verifier is the second opinion."""
+import os
+
 import numpy as np
 import pytest
 
@@ -45,7 +47,9 @@ def test_verify_accepts_honest_proofs_and_recomputes_the_preprocessed_commitment
     bad = pc.copy()
     bad[3] ^= 1
     assert va.verify(machine, rc, proof.words, bad, num_queries=6) is not None
-    assert va.verify(machine, rc, proof.words, None, num_queries=6) is not None
+    # a machine with preprocessed traces verified WITHOUT their commitment is refused outright (the reference's verifier always observes it,
+    # basic/src/lib.rs:791-804): never a silently different transcript
+    assert "preprocessed commitment is required" in va.verify(machine, rc, proof.words, None, num_queries=6)
     # another configuration is another transcript
     assert va.verify(machine, rc, proof.words, pc, num_queries=6, pow_bits=24) is not None  # the 8-bit witness would have to carry 16 more zero bits
     assert va.verify(machine, rc, proof.words, pc, num_queries=7) is not None
@@ -207,3 +211,17 @@ def test_verify_with_the_poseidon_mmcs(machine, rc, fib25):
     bad = proof.words.copy()
     bad[-3] = (int(bad[-3]) + 1) % P
     assert va.verify(machine, rc, bad, pc, **kw) is not None
+
+
+def test_cbor_decoder_survives_a_length_whose_product_wraps_64_bits():
+    """A hostile array header: l = 0x1C71C71C71C71C72 elements (x 9 bytes per element wraps to 2): rejected at the header, not after 2^32 iterations."""
+    import time
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib25_q4_proof.cbor"), "rb") as f:
+        blob = f.read()
+    evil = bytes([0x9B]) + (0x1C71C71C71C71C72).to_bytes(8, "big")
+    t0 = time.time()
+    for cut in range(1, 400, 7):  # spliced in at many offsets: whichever `len()` call meets it must refuse
+        with pytest.raises(va.VgpuError):
+            va.proof_from_cbor(blob[:cut] + evil + blob[cut:])
+    assert time.time() - t0 < 5

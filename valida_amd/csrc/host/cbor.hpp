@@ -216,7 +216,8 @@ class ProofCborDecoder {
         pos_ += len;
     }
     uint32_t word(const char* what) { const uint64_t v = expect(0, what); if (v > 0xffffffffull) bad("integer out of range"); return (uint32_t)v; }
-    uint32_t len(uint64_t unit) { const uint64_t l = array(); if (l * unit > n_ - pos_) bad("a length exceeds the input"); return (uint32_t)l; }
+    // compared by division: l * unit may wrap 64 bits (l = 0x1C71C71C71C71C72, unit 9 gives 2) and pass the bound on hostile input
+    uint32_t len(uint64_t unit) { const uint64_t l = array(); if (l > 0xffffffffull || l > (uint64_t)(n_ - pos_) / (unit ? unit : 1)) bad("a length exceeds the input"); return (uint32_t)l; }
     uint32_t val() {  // canonical field element
         if (pos_ < n_ && (b_[pos_] >> 5) == 5) {
             map(1); key("value");

@@ -205,6 +205,12 @@ inline void verify_machine_proof(const MachineDesc& machine, const FriParams& fr
         c.cumulative_sum = r.e();
     }
     Challenger ch(&perm16);
+    // The reference's verifier ALWAYS recomputes and observes the preprocessed commitment (basic/src/lib.rs:791-804).  A machine with
+    // preprocessed traces verified without it would run another transcript: honest proofs rejected, and a proof made without the ROM /
+    // range table bound into the transcript accepted.  Refuse the call instead.
+    if (!preprocessed_commit)
+        for (auto& a : machine.airs)
+            if (a.prep_width > 0) throw std::invalid_argument("verify: chip " + a.name + " has a preprocessed trace: the preprocessed commitment is required (vgpu_host_commit_root)");
     if (preprocessed_commit) ch.observe_digest(preprocessed_commit);
     ch.observe_digest(main_commit.data());
     Ext5 rnd[3];

@@ -190,12 +190,22 @@ struct DeviceCtx {
         static const bool on = [] { const char* e = getenv("VGPU_SPIN_WAIT"); return e && e[0] == '1'; }();
         return on;
     }
+    // Host-side staging state (the pinned ring of upload_async, the lazily created polling event, the pinned download buffer) is shared by
+    // every ABI entry point that works on this context; the one-proof-at-a-time guard covers prove only, so a caller thread that commits /
+    // opens / builds a permutation trace beside an outstanding ticket meets the proof thread here: one lock around all of it.
+    std::recursive_mutex host_mu;
     void sync() {
         if (!spin_wait()) { VG_HIP_CHECK(hipStreamSynchronize(stream)); return; }
-        if (!sync_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&sync_ev, hipEventDisableTiming));
-        VG_HIP_CHECK(hipEventRecord(sync_ev, stream));
+        hipEvent_t ev;
+        {
+            // one polling event per waiting thread would be cleaner; waits of one context are rare enough to share it under the lock
+            std::lock_guard<std::recursive_mutex> lk(host_mu);
+            if (!sync_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&sync_ev, hipEventDisableTiming));
+            ev = sync_ev;
+            VG_HIP_CHECK(hipEventRecord(ev, stream));
+        }
         for (;;) {
-            hipError_t e = hipEventQuery(sync_ev);
+            hipError_t e = hipEventQuery(ev);
             if (e == hipSuccess) return;
             if (e != hipErrorNotReady) throw std::runtime_error(std::string("hipEventQuery: ") + hipGetErrorString(e));
 #if defined(__x86_64__)
@@ -232,6 +242,7 @@ struct DeviceCtx {
     }
     // small D2H through pinned memory (a pageable destination makes hipMemcpyAsync take the slow staged path)
     void download_small(void* dst, const void* src, size_t bytes) {
+        std::lock_guard<std::recursive_mutex> lk(host_mu);  // the pinned buffer is shared (and may be re-allocated)
         void* pin = pinned_buffer(bytes);
         VG_HIP_CHECK(hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, stream));
         sync();
@@ -242,6 +253,7 @@ struct DeviceCtx {
     void upload_async(void* dst, const void* src, size_t bytes) {
         if (!bytes) return;
         if (bytes > STAGE_BYTES / 2) { upload(dst, src, bytes); return; }
+        std::lock_guard<std::recursive_mutex> lk(host_mu);  // ring position + the wrap's drain
         if (!stage) VG_HIP_CHECK(hipHostMalloc((void**)&stage, STAGE_BYTES));
         size_t pos = (stage_pos + 63) & ~(size_t)63;
         if (pos + bytes > STAGE_BYTES) {  // wrap: everything staged so far must have been read by the copy engine
