@@ -311,6 +311,29 @@ int32_t vgpu_prove_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace
 int32_t vgpu_prove_sharded_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* main, uint32_t n_main,
                                  const uint32_t* prep_chips, const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out);
 
+/* The same over the HOST'S OWN transport: one rank per process (or per thread with its own prover), the exchanges carried by two
+ * callbacks over host buffers — what a Rust host plugs its MPI / TCP / shared-memory layer into, and how the sharded prover runs one rank
+ * per process where no RCCL communicator exists.  Both callbacks are collective (every rank calls them in the same order with matching
+ * sizes), block until this rank's data has arrived, and return 0 on success (anything else aborts the proof on every rank).
+ *   all_gather : every rank contributes n_words words; out receives world * n_words words, rank-major.
+ *   all_to_all : send[s] (send_words[s] words) goes to rank s, recv[s] (recv_words[s] words) arrives from rank s; the entries of s == rank
+ *                are null / 0 (the library keeps its own block on the device).  Device blocks are staged through page-locked host memory.
+ * Failure protocol: before every exchange the ranks all_gather one status word; a rank whose proof fails (bad shapes, out of memory, a
+ * HIP error) reports it there instead of going on, and EVERY rank returns an error (VGPU_ERR_*; vgpu_last_error names the failing rank)
+ * instead of blocking in an exchange its peer never enters. */
+typedef struct vgpu_fabric {
+    void* user;
+    uint32_t rank, world;   /* world: a power of two */
+    int32_t (*all_gather)(void* user, const uint32_t* words, uint64_t n_words, uint32_t* out);
+    int32_t (*all_to_all)(void* user, const uint32_t* const* send, const uint64_t* send_words, uint32_t* const* recv, const uint64_t* recv_words);
+} vgpu_fabric_t;
+int32_t vgpu_prove_sharded_fabric(vgpu_prover_t* p, const vgpu_fabric_t* fabric, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
+                                  const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out);
+/* Host-only check of a transport before proofs depend on it (no device needed): a status round, an all_gather of n_words rank-dependent
+ * words and an all_to_all of rank-pair-dependent blocks of different sizes, every received word verified.  fail_rank < world makes that
+ * rank fail between two exchanges the way a failing proof would: every rank must then return a non-zero status — none may hang. */
+int32_t vgpu_fabric_selftest(const vgpu_fabric_t* fabric, uint32_t n_words, uint32_t fail_rank);
+
 /* ---- trace generation on the device: Chip::generate_trace (machine/src/chip.rs:22) of the big
  * BasicMachine chips as kernels, fed by the VM's operation logs instead of host-built RowMajorMatrix traces.
  * The logs are what the reference's chips hold after Machine::run: Cpu::operations + pc/fp/instruction per cycle

@@ -241,3 +241,52 @@ def test_sharded_prover_exchanges_over_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert done == list(range(world))
+
+
+# ---- the caller-supplied fabric of the C ABI (vgpu_fabric_t) with one rank per PROCESS: the library's own exchange code
+# (CallbackFabric: status rounds, all_gather, all_to_all over host buffers) driven through torch.distributed gloo --------------------
+def _fabric_worker(rank, world, port, q, fail_rank):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import valida_amd as va
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    fab = va.Fabric.over_torch_distributed(dist)
+    msg = fab.selftest(n_words=33, fail_rank=fail_rank)
+    q.put((rank, msg, [repr(e) for e in fab.errors]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_fabric(world, fail_rank):
+    port = 31000 + (os.getpid() % 2000) + 7 * world + (0 if fail_rank > world else 3 + fail_rank)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fabric_worker, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+def test_caller_supplied_fabric_over_gloo_world_2_and_4():
+    for world in (2, 4):
+        for rank, msg, errors in _run_fabric(world, 0xFFFFFFFF):
+            assert msg is None and not errors, (world, rank, msg, errors)
+
+
+def test_one_failing_rank_fails_every_rank_instead_of_hanging_them():
+    """a rank that throws between two collectives used to leave its peers blocked in the next one.  Now it reports
+    its failure in the status round and EVERY rank returns an error naming it."""
+    for world, bad in ((2, 1), (4, 2)):
+        for rank, msg, errors in _run_fabric(world, bad):
+            assert msg is not None and not errors, (world, rank, msg, errors)
+            if rank == bad:
+                assert "fails on request" in msg
+            else:
+                assert "rank %d failed" % bad in msg

@@ -615,6 +615,99 @@ def upload_replicated(provers, main_traces, preprocessed):
     return [[p.upload(m) for m in main_traces] for p in provers], [[p.upload(m) for _, m in preprocessed] for p in provers]
 
 
+class VgpuFabric(ctypes.Structure):
+    """vgpu_fabric_t (include/vgpu.h): the host's own transport for a sharded proof, two collective callbacks over host buffers."""
+    ALL_GATHER = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, c_u32p, ctypes.c_uint64, c_u32p)
+    ALL_TO_ALL = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(c_u32p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_u32p),
+                                  ctypes.POINTER(ctypes.c_uint64))
+    _fields_ = [("user", ctypes.c_void_p), ("rank", ctypes.c_uint32), ("world", ctypes.c_uint32), ("all_gather", ALL_GATHER), ("all_to_all", ALL_TO_ALL)]
+
+
+class Fabric:
+    """A caller-supplied fabric from two Python callables (what a Rust host would write against its own transport):
+        all_gather(mine: np.uint32[n]) -> np.uint32[world, n]
+        all_to_all(send: list of np.uint32 arrays or None per rank, recv_words: list of int) -> list of np.uint32 arrays (None where 0 words)
+    Exceptions inside a callback become a non-zero status: the proof is abandoned on every rank (the library's failure protocol)."""
+
+    def __init__(self, rank, world, all_gather, all_to_all):
+        self.rank, self.world = rank, world
+        self.errors = []
+
+        def ag(_user, words, n, out):
+            try:
+                mine = np.ctypeslib.as_array(words, shape=(int(n),)).copy()
+                got = np.ascontiguousarray(all_gather(mine), dtype=np.uint32).reshape(world, int(n))
+                ctypes.memmove(out, got.ctypes.data, got.nbytes)
+                return 0
+            except Exception as e:  # noqa: BLE001 - must not unwind into C
+                self.errors.append(e)
+                return 1
+
+        def a2a(_user, send, send_words, recv, recv_words):
+            try:
+                sb = [np.ctypeslib.as_array(send[s], shape=(int(send_words[s]),)).copy() if send_words[s] else None for s in range(world)]
+                rw = [int(recv_words[s]) for s in range(world)]
+                got = all_to_all(sb, rw)
+                for s in range(world):
+                    if rw[s]:
+                        g = np.ascontiguousarray(got[s], dtype=np.uint32).reshape(-1)
+                        assert g.size == rw[s], "all_to_all delivered %d words from rank %d, expected %d" % (g.size, s, rw[s])
+                        ctypes.memmove(recv[s], g.ctypes.data, g.nbytes)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self.errors.append(e)
+                return 1
+
+        self._ag, self._a2a = VgpuFabric.ALL_GATHER(ag), VgpuFabric.ALL_TO_ALL(a2a)  # kept alive with the object
+        self.c = VgpuFabric(None, rank, world, self._ag, self._a2a)
+
+    @staticmethod
+    def over_torch_distributed(dist, group=None):
+        """The exchanges through a torch.distributed process group on CPU tensors (gloo): all_gather, and pairwise isend / irecv."""
+        import torch
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def all_gather(mine):
+            outs = [torch.zeros(mine.size, dtype=torch.int32) for _ in range(world)]
+            dist.all_gather(outs, torch.from_numpy(mine.view(np.int32).copy()), group=group)
+            return np.stack([o.numpy().view(np.uint32) for o in outs])
+
+        def all_to_all(send, recv_words):
+            reqs, bufs = [], [None] * world
+            for s in range(world):
+                if s != rank and recv_words[s]:
+                    bufs[s] = torch.zeros(recv_words[s], dtype=torch.int32)
+                    reqs.append(dist.irecv(bufs[s], src=s, group=group))
+            keep = []
+            for s in range(world):
+                if s != rank and send[s] is not None:
+                    t = torch.from_numpy(send[s].view(np.int32))
+                    keep.append(t)
+                    reqs.append(dist.isend(t, dst=s, group=group))
+            for r in reqs:
+                r.wait()
+            return [None if b is None else b.numpy().view(np.uint32) for b in bufs]
+
+        return Fabric(rank, world, all_gather, all_to_all)
+
+    def selftest(self, n_words=17, fail_rank=0xFFFFFFFF):
+        """vgpu_fabric_selftest: None if this rank's exchanges were all correct, else the library's message (a failing peer included)."""
+        code = lib().vgpu_fabric_selftest(ctypes.byref(self.c), ctypes.c_uint32(n_words), ctypes.c_uint32(fail_rank))
+        return None if code == 0 else lib().vgpu_last_error().decode()
+
+    def prove_sharded(self, prover, main, preprocessed, log_min_sharded=12):
+        """This rank's share of ONE proof sharded over the fabric's ranks (vgpu_prove_sharded_fabric): every rank passes the same traces,
+        uploaded through its own prover, and receives the proof vgpu_prove gives on one GPU."""
+        arr = (ctypes.c_void_p * len(main))(*[t._h for t in main])
+        chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
+        parr = (ctypes.c_void_p * max(1, len(preprocessed)))(*[t._h for _, t in preprocessed])
+        h = ctypes.c_void_p()
+        _check(lib().vgpu_prove_sharded_fabric(prover._h, ctypes.byref(self.c), arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)),
+                                               ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
+        return Proof(h)
+
+
 def prove_sharded_local(provers, main_traces, preprocessed, log_min_sharded=12, uploaded=None):
     """ONE proof over len(provers) prover contexts of this process standing in for the ranks (vgpu_prove_sharded_local): main_traces are
     host matrices (chip order), preprocessed a list of (chip, host matrix); every context gets its own upload (the traces are replicated,

@@ -861,6 +861,65 @@ int32_t vgpu_prove_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace
         *out = proof.release();
     })
 }
+int32_t vgpu_prove_sharded_fabric(vgpu_prover_t* p, const vgpu_fabric_t* fabric, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
+                                  const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out) {
+    VG_TRY({
+        if (!p || !fabric || !main || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
+        CallbackFabric fab((int)fabric->rank, (int)fabric->world, fabric->all_gather, fabric->all_to_all, fabric->user);
+        std::vector<Prover*> provers{p->p.get()};
+        std::vector<ShardedInputs> in;
+        try {
+            in.push_back(sharded_inputs(p, main, n_main, prep_chips, prep, n_prep));
+        } catch (...) {  // the peers are (or will be) inside the prover: tell them
+            fab.fail();
+            throw;
+        }
+        auto proof = std::make_unique<vgpu_proof>();
+        proof->words = ShardedProof::run(fab, provers, in, log_min_sharded);
+        *out = proof.release();
+    })
+}
+int32_t vgpu_fabric_selftest(const vgpu_fabric_t* fabric, uint32_t n_words, uint32_t fail_rank) {
+    VG_TRY({
+        if (!fabric) throw std::invalid_argument("null argument");
+        CallbackFabric fab((int)fabric->rank, (int)fabric->world, fabric->all_gather, fabric->all_to_all, fabric->user);
+        const uint32_t W = fabric->world, me = fabric->rank;
+        auto word = [](uint32_t from, uint32_t to, uint32_t k) { return 0x9E3779B9u * (from + 1) + 0x85EBCA6Bu * (to + 1) + k; };
+        try {
+            // 1. all_gather through the guarded entry point (status round first)
+            std::vector<uint32_t> mine(n_words), all;
+            for (uint32_t k = 0; k < n_words; k++) mine[k] = word(me, W, k);
+            fab.all_gather({mine.data()}, n_words, all);
+            for (uint32_t r = 0; r < W; r++)
+                for (uint32_t k = 0; k < n_words; k++)
+                    if (all[(size_t)r * n_words + k] != word(r, W, k)) throw std::runtime_error("fabric selftest: all_gather delivered a wrong word");
+            // 2. a rank that fails between two exchanges, as a failing proof would
+            if (me == fail_rank) throw std::invalid_argument("fabric selftest: rank " + std::to_string(me) + " fails on request");
+            // 3. all_to_all of blocks whose size depends on the pair
+            fab.agree();
+            std::vector<std::vector<uint32_t>> sb(W), rb(W);
+            std::vector<const uint32_t*> sp(W, nullptr);
+            std::vector<uint32_t*> rp(W, nullptr);
+            std::vector<uint64_t> sw(W, 0), rw(W, 0);
+            for (uint32_t s = 0; s < W; s++) {
+                if (s == me) continue;
+                sb[s].resize(n_words + 3 * me + s); rb[s].resize(n_words + 3 * s + me);
+                for (size_t k = 0; k < sb[s].size(); k++) sb[s][k] = word(me, s, (uint32_t)k);
+                sp[s] = sb[s].data(); sw[s] = sb[s].size(); rp[s] = rb[s].data(); rw[s] = rb[s].size();
+            }
+            fab.host_all_to_all(sp, sw, rp, rw);
+            for (uint32_t s = 0; s < W; s++)
+                for (size_t k = 0; k < rb[s].size(); k++)
+                    if (rb[s][k] != word(s, me, (uint32_t)k)) throw std::runtime_error("fabric selftest: all_to_all delivered a wrong word");
+            fab.agree();  // and a last round, in which a late failure of a peer would still surface
+        } catch (const FabricPeerFailure&) {
+            throw;
+        } catch (...) {
+            fab.fail();
+            throw;
+        }
+    })
+}
 int32_t vgpu_prove_sharded_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* main, uint32_t n_main,
                                  const uint32_t* prep_chips, const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out) {
     VG_TRY({

@@ -103,7 +103,20 @@ struct Rank {
 
 }  // namespace
 
+// One failing rank must fail every rank (fabric.hpp, FAILURE PROTOCOL): whatever this rank throws between two collectives — a shape
+// mismatch, an allocation failure, a HIP error — is reported to its peers through the status round they run before their next collective.
 std::vector<uint32_t> ShardedProof::run(Fabric& f, const std::vector<Prover*>& provers, const std::vector<ShardedInputs>& in, unsigned log_min_sharded) {
+    try {
+        return run_impl(f, provers, in, log_min_sharded);
+    } catch (const FabricPeerFailure&) {
+        throw;  // a peer failed first and everyone already knows
+    } catch (...) {
+        f.fail();
+        throw;
+    }
+}
+
+std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover*>& provers, const std::vector<ShardedInputs>& in, unsigned log_min_sharded) {
     const int W = f.world, NH = (int)f.hosted.size();
     if (W < 1 || (W & (W - 1)) || W > 1024) throw std::invalid_argument("sharded prove: the number of ranks must be a power of two (at most 1024)");
     if (NH < 1 || (int)provers.size() != NH || (int)in.size() != NH) throw std::invalid_argument("sharded prove: one prover context and one set of traces per hosted rank");
@@ -354,6 +367,19 @@ std::vector<uint32_t> ShardedProof::run(Fabric& f, const std::vector<Prover*>& p
     const std::vector<unsigned>& log_deg = rk[0].log_deg;
     const std::vector<int>& prep_slot = rk[0].prep_slot;
     const size_t NP = in[0].prep.size();
+    if (NH < W) {
+        // ranks in other processes: every exchange below is sized from the shapes, so they must be THE SAME everywhere before the first one
+        std::vector<uint32_t> shape;
+        for (size_t i = 0; i < NC; i++) { shape.push_back(log_deg[i]); shape.push_back((uint32_t)(prep_slot[i] + 1)); }
+        shape.push_back(log_min_sharded); shape.push_back(fri.log_blowup); shape.push_back(fri.num_queries); shape.push_back(fri.pow_bits); shape.push_back((uint32_t)fri.hash_kind);
+        std::vector<const uint32_t*> contrib((size_t)NH, shape.data());
+        std::vector<uint32_t> all;
+        f.all_gather(contrib, shape.size(), all);
+        for (int r = 0; r < W; r++)
+            if (memcmp(all.data() + (size_t)r * shape.size(), shape.data(), shape.size() * 4) != 0)
+                throw FabricPeerFailure("sharded prove: rank " + std::to_string(r) + " was called with traces of other shapes or another configuration than rank " +
+                                        std::to_string(f.hosted[0]) + " (every rank sees this and gives up the proof)");
+    }
 
     // ---------------------------------------------------------------------------------------------------------------------------
     // preprocessed + main commitments (lib.rs:189-225)

@@ -17,7 +17,11 @@ struct ShardedInputs {
 struct ShardedProof {
     // provers[k] / in[k]: the prover context and traces of hosted rank fabric.hosted[k].  Matrices whose LDE has at least
     // max(4 W, 2^log_min_sharded) rows are sharded, shorter ones are computed by every rank.  Returns the proof words (the same on every rank).
+    // Multi-process fabrics: if this rank throws, its peers are told (Fabric::fail) and throw FabricPeerFailure at their next collective.
     static std::vector<uint32_t> run(Fabric& fabric, const std::vector<Prover*>& provers, const std::vector<ShardedInputs>& in, unsigned log_min_sharded);
+
+  private:
+    static std::vector<uint32_t> run_impl(Fabric& fabric, const std::vector<Prover*>& provers, const std::vector<ShardedInputs>& in, unsigned log_min_sharded);
 };
 
 }  // namespace vhost
