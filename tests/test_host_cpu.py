@@ -397,7 +397,7 @@ def test_rust_sys_binding_is_generated_from_the_header_and_complete(tmp_path):
     size_align = {"u8": (1, 1), "u32": (4, 4), "i32": (4, 4), "u64": (8, 8), "i64": (8, 8), "f64": (8, 8)}
     structs = {}
     for m in re.finditer(r"pub struct (\w+) \{  // (\w+)\n(.*?)\n\}", text, re.S):
-        fields = re.findall(r"pub (\w+): ([^,\n]+),", m.group(3))
+        fields = re.findall(r"pub (\w+): (Option<[^\n]+>|[^,\n]+),\n", m.group(3) + "\n")
         structs[m.group(2)] = (m.group(1), fields)
 
     def layout(ty):
@@ -406,7 +406,7 @@ def test_rust_sys_binding_is_generated_from_the_header_and_complete(tmp_path):
         if a:
             s, al = layout(a.group(1))
             return s * int(a.group(2)), al
-        if ty.startswith("*"):
+        if ty.startswith("*") or ty.startswith("Option<unsafe extern"):
             return 8, 8
         if ty in size_align:
             return size_align[ty]

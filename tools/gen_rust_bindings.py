@@ -100,6 +100,10 @@ def parse(src):
                 f = f.strip()
                 if not f:
                     continue
+                fp = re.match(r"^(.*?)\(\s*\*\s*(\w+)\s*\)\s*\((.*)\)$", f, re.S)
+                if fp:  # a callback: "int32_t (*all_gather)(void* user, ...)" -> Option<unsafe extern "C" fn(..) -> ..>
+                    fields.append((("fn", fp.group(1).strip(), [split_decl(a) for a in fp.group(3).split(",")]), fp.group(2), None))
+                    continue
                 # "uint32_t clk, addr, value, is_write" and "uint32_t a[4]"
                 first, *rest = [x.strip() for x in f.split(",")]
                 ty, name, arr = split_decl(first)
@@ -155,6 +159,11 @@ def generate():
     for s, fields in structs:
         out.append("#[repr(C)]\n#[derive(Clone, Copy)]\npub struct %s {  // %s" % (names[s], s))
         for ty, name, arr in fields:
+            if isinstance(ty, tuple):  # nullable C function pointer: same size and alignment as a pointer
+                ps = ", ".join("%s: %s" % (an, rust_type(aty, names)) for aty, an, _ in ty[2])
+                rt = 'Option<unsafe extern "C" fn(%s)%s>' % (ps, "" if ty[1] == "void" else " -> " + rust_type(ty[1], names))
+                out.append("    pub %s: %s," % (name, rt))
+                continue
             rt = rust_type(ty, names)
             if arr is not None:
                 rt = "[%s; %s]" % (rt, arr)
