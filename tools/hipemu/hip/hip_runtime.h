@@ -1,0 +1,131 @@
+// hipemu: a host stand-in for the HIP execution model, enough to run this repository's plain-C++ kernels (no wave intrinsics, no inline
+// asm) on a CPU: every workgroup runs as `blockDim.x` cooperative FIBERS (ucontext) on one OS thread, __syncthreads() yields to the next
+// fiber and returns when every fiber of the block has arrived (or finished), workgroups run one after the other.  Dynamic LDS is one
+// global array (stale between workgroups, as on the device).  What it checks: the INDEX ARITHMETIC and the barrier structure of a kernel
+// (a read of data another thread writes later in the same phase sees stale data, since fiber t runs its whole phase before fiber t + 1) —
+// before GPU minutes are spent on it.  What it cannot check: performance, wave-level primitives, real data races.
+// Test infrastructure (tools/ + tests/); nothing in the product includes it.
+#pragma once
+#include <ucontext.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __restrict__
+#define __shared__
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorNotReady = 600 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
+
+namespace hipemu {
+struct State {
+    dim3 threadIdx, blockIdx, blockDim, gridDim;
+};
+inline State& st() { static State s; return s; }
+constexpr size_t STACK = 256 * 1024;
+struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = false; };
+struct Sched {
+    ucontext_t main;
+    std::vector<Fiber> fib;
+    int cur = -1;
+    std::function<void()> body;
+    unsigned long barriers = 0;
+};
+inline Sched& sched() { static Sched s; return s; }
+inline void trampoline() {
+    Sched& s = sched();
+    s.body();
+    s.fib[(size_t)s.cur].done = true;
+    swapcontext(&s.fib[(size_t)s.cur].ctx, &s.main);
+}
+inline void syncthreads() {
+    Sched& s = sched();
+    s.barriers++;
+    swapcontext(&s.fib[(size_t)s.cur].ctx, &s.main);
+}
+// one workgroup: phases until every fiber has finished
+inline void run_block(unsigned nthreads) {
+    Sched& s = sched();
+    if (s.fib.size() < nthreads) {
+        size_t old = s.fib.size();
+        s.fib.resize(nthreads);
+        for (size_t i = old; i < nthreads; i++) s.fib[i].stack = (char*)malloc(STACK);
+    }
+    for (unsigned t = 0; t < nthreads; t++) {
+        Fiber& f = s.fib[t];
+        f.done = false;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STACK;
+        f.ctx.uc_link = &s.main;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    for (;;) {
+        bool any = false;
+        for (unsigned t = 0; t < nthreads; t++) {
+            Fiber& f = s.fib[t];
+            if (f.done) continue;
+            any = true;
+            s.cur = (int)t;
+            st().threadIdx = dim3(t, 0, 0);
+            swapcontext(&s.main, &f.ctx);
+        }
+        if (!any) break;
+    }
+}
+template <class F>
+inline void launch(dim3 grid, dim3 block, size_t lds_bytes, F&& f) {
+    if (block.y != 1 || block.z != 1) throw std::runtime_error("hipemu: one-dimensional workgroups only");
+    if (lds_bytes > 160 * 1024) throw std::runtime_error("hipemu: more than 160 KiB of LDS");
+    Sched& s = sched();
+    s.body = f;
+    st().blockDim = block; st().gridDim = grid;
+    for (unsigned z = 0; z < grid.z; z++)
+        for (unsigned y = 0; y < grid.y; y++)
+            for (unsigned x = 0; x < grid.x; x++) {
+                st().blockIdx = dim3(x, y, z);
+                run_block(block.x);
+            }
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::st().threadIdx)
+#define blockIdx (hipemu::st().blockIdx)
+#define blockDim (hipemu::st().blockDim)
+#define gridDim (hipemu::st().gridDim)
+inline void __syncthreads() { hipemu::syncthreads(); }
+inline unsigned __brev(unsigned x) {
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+}
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) hipemu::launch(grid, block, lds, [=]() { kernel(__VA_ARGS__); })
+#define hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, e0, e1, flags, ...) hipemu::launch(grid, block, lds, [=]() { kernel(__VA_ARGS__); })

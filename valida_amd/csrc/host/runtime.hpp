@@ -12,6 +12,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 #include "../kernels/launch.hpp"
 
@@ -88,6 +89,7 @@ struct DeviceCtx {
         for (auto& kv : free_blocks) (void)hipFree(kv.second);
         for (auto& kv : live_blocks) (void)hipFree(kv.first);
         if (table_mem) (void)hipFree(table_mem);
+        for (auto& kv : lde_tabs) (void)hipFree(kv.second);
         if (upload_stream) { (void)hipStreamSynchronize(upload_stream); (void)hipStreamDestroy(upload_stream); (void)hipEventDestroy(upload_ev); }
         if (pinned) (void)hipHostFree(pinned);
         if (stage) (void)hipHostFree(stage);
@@ -264,6 +266,26 @@ struct DeviceCtx {
         VG_HIP_CHECK(hipMemcpyAsync(dst, stage + pos, bytes, hipMemcpyHostToDevice, stream));
         stage_pos = pos + bytes;
     }
+    // Tables of the fused LDE per (log height, log blowup, coset shift): built on the host the first time a shape is extended in this
+    // context (a few thousand field products), copied synchronously — every later launch on any stream of the context sees them — and
+    // kept for the context's lifetime (a proof uses a handful of shapes; words per entry: b (n_lo + n_hi) <= 2^16).
+    std::map<std::tuple<int, int, uint32_t>, uint32_t*> lde_tabs;
+    std::mutex lde_tabs_mu;
+    vk::LdeTables lde_tables(int k, int log_blowup, Fp shift) {
+        std::lock_guard<std::mutex> lk(lde_tabs_mu);
+        const auto key = std::make_tuple(k, log_blowup, shift.v);
+        auto it = lde_tabs.find(key);
+        if (it == lde_tabs.end()) {
+            std::vector<uint32_t> h(vk::lde_tables_words(k, log_blowup));
+            vk::build_lde_tables(k, log_blowup, shift, h.data());
+            uint32_t* d = nullptr;
+            VG_HIP_CHECK(hipMalloc((void**)&d, h.size() * 4));
+            VG_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            it = lde_tabs.emplace(key, d).first;
+        }
+        const size_t n_lo = (size_t)1 << vk::lde_k_lo(k);
+        return vk::LdeTables{it->second, it->second + ((size_t)1 << log_blowup) * n_lo};
+    }
     uint32_t* upload_words(const std::vector<uint32_t>& w) {
         uint32_t* d = alloc_words(w.size());
         upload_async(d, w.data(), w.size() * 4);
@@ -272,42 +294,11 @@ struct DeviceCtx {
 
   private:
     void init_tables() {
-        constexpr int TWC = 1 << 14;  // compact tables cover stages 1..14 (contiguous NTT tiles of up to 2^14 points)
-        std::vector<uint32_t> t(2048 * 4 + 64 + 2 * TWC, 0);
-        Fp roots[28], inv_roots[28];
-        for (int i = 0; i <= 27; i++) { roots[i] = vg::two_adic_generator(i); inv_roots[i] = roots[i].inv(); }
-        for (int i = 0; i < 28; i++) { tables.roots[i] = roots[i].v; tables.inv_roots[i] = inv_roots[i].v; }
-        auto fill = [&](uint32_t* dst, int count, int first_bit, const Fp* r) {
-            for (int j = 0; j < count; j++) {
-                Fp p = Fp::one();
-                for (int b = 0; (j >> b) != 0; b++) if ((j >> b) & 1) p *= r[first_bit + b + 1];
-                dst[j] = p.v;
-            }
-        };
-        uint32_t* h = t.data();
-        fill(h, 2048, 0, roots);              // brt_lo
-        fill(h + 2048, 2048, 11, roots);      // brt_hi
-        fill(h + 4096, 32, 22, roots);        // brt_top (bits 22..26 -> roots up to index 27)
-        fill(h + 4096 + 32, 2048, 0, inv_roots);
-        fill(h + 4096 + 32 + 2048, 2048, 11, inv_roots);
-        fill(h + 4096 + 32 + 4096, 32, 22, inv_roots);
-        uint32_t* twc = h + 4096 + 32 + 4096 + 32;
-        // compact per-stage tables: stage s (1..14) at offset 2^(s-1) - 1 holds w_{2^s}^j, j < 2^(s-1)
-        for (int s = 1; s <= 14; s++) {
-            Fp ws = roots[s], wsi = inv_roots[s], a = Fp::one(), b = Fp::one();
-            int off = (1 << (s - 1)) - 1;
-            for (int j = 0; j < (1 << (s - 1)); j++) { twc[off + j] = a.v; twc[TWC + off + j] = b.v; a *= ws; b *= wsi; }
-        }
+        std::vector<uint32_t> t(vk::device_tables_words(), 0);
+        vk::build_device_tables(tables, t.data());
         VG_HIP_CHECK(hipMalloc((void**)&table_mem, t.size() * 4));
         VG_HIP_CHECK(hipMemcpy(table_mem, t.data(), t.size() * 4, hipMemcpyHostToDevice));
-        tables.brt_lo = table_mem;
-        tables.brt_hi = table_mem + 2048;
-        tables.brt_top = table_mem + 4096;
-        tables.ibrt_lo = table_mem + 4096 + 32;
-        tables.ibrt_hi = table_mem + 4096 + 32 + 2048;
-        tables.ibrt_top = table_mem + 4096 + 32 + 4096;
-        tables.twc = table_mem + 4096 + 32 + 4096 + 32;
-        tables.itwc = tables.twc + TWC;
+        vk::bind_device_tables(tables, table_mem);
     }
 };
 

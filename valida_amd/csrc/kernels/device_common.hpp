@@ -43,6 +43,71 @@ struct DeviceTables {
     const uint32_t* itwc;     // same with inverse roots
 };
 
+// Host-side image of the tables (one allocation of `device_tables_words()` words; bind_device_tables points the struct into it).
+// Shared by DeviceCtx::init_tables and the host emulation of the kernels (tools/hipemu, tests/emu).
+constexpr int DEVICE_TABLES_TWC = 1 << 14;  // compact tables cover stages 1..14 (contiguous NTT tiles of up to 2^14 points)
+inline size_t device_tables_words() { return 2048 * 4 + 64 + 2 * DEVICE_TABLES_TWC; }
+inline void build_device_tables(DeviceTables& tb, uint32_t* h) {
+    Fp roots[28], inv_roots[28];
+    for (int i = 0; i <= 27; i++) { roots[i] = vg::two_adic_generator(i); inv_roots[i] = roots[i].inv(); }
+    for (int i = 0; i < 28; i++) { tb.roots[i] = roots[i].v; tb.inv_roots[i] = inv_roots[i].v; }
+    auto fill = [&](uint32_t* dst, int count, int first_bit, const Fp* r) {
+        for (int j = 0; j < count; j++) {
+            Fp p = Fp::one();
+            for (int b = 0; (j >> b) != 0; b++) if ((j >> b) & 1) p *= r[first_bit + b + 1];
+            dst[j] = p.v;
+        }
+    };
+    for (size_t i = 0; i < device_tables_words(); i++) h[i] = 0;
+    fill(h, 2048, 0, roots);              // brt_lo
+    fill(h + 2048, 2048, 11, roots);      // brt_hi
+    fill(h + 4096, 32, 22, roots);        // brt_top (bits 22..26 -> roots up to index 27)
+    fill(h + 4096 + 32, 2048, 0, inv_roots);
+    fill(h + 4096 + 32 + 2048, 2048, 11, inv_roots);
+    fill(h + 4096 + 32 + 4096, 32, 22, inv_roots);
+    uint32_t* twc = h + 4096 + 32 + 4096 + 32;
+    // compact per-stage tables: stage s (1..14) at offset 2^(s-1) - 1 holds w_{2^s}^j, j < 2^(s-1)
+    for (int s = 1; s <= 14; s++) {
+        Fp ws = roots[s], wsi = inv_roots[s], a = Fp::one(), b = Fp::one();
+        int off = (1 << (s - 1)) - 1;
+        for (int j = 0; j < (1 << (s - 1)); j++) { twc[off + j] = a.v; twc[DEVICE_TABLES_TWC + off + j] = b.v; a *= ws; b *= wsi; }
+    }
+}
+inline void bind_device_tables(DeviceTables& tb, const uint32_t* base) {
+    tb.brt_lo = base;
+    tb.brt_hi = base + 2048;
+    tb.brt_top = base + 4096;
+    tb.ibrt_lo = base + 4096 + 32;
+    tb.ibrt_hi = base + 4096 + 32 + 2048;
+    tb.ibrt_top = base + 4096 + 32 + 4096;
+    tb.twc = base + 4096 + 32 + 4096 + 32;
+    tb.itwc = tb.twc + DEVICE_TABLES_TWC;
+}
+
+// Per-(height, blowup, shift) tables of the fused LDE (ntt.hip, k_lde_mid): for coset t < b = 2^log_blowup, sigma_t = shift w_{bN}^t,
+//   fac[t n_lo + i] = (sigma_t^n_hi)^bitrev_{k_lo}(i) / N     scale of the coefficient at tile position i before the forward transform
+//   sig[t n_hi + a] = sigma_t^a                                the block's share of the coset powers
+// words = b (n_lo + n_hi); built on the host (build_lde_tables), cached per context.
+struct LdeTables { const uint32_t* fac; const uint32_t* sig; };
+inline int lde_k_lo(int k) { return k < 12 ? k : (k >= 23 ? 14 : 12); }
+inline size_t lde_tables_words(int k, int log_blowup) { const int k_lo = lde_k_lo(k); return ((size_t)1 << log_blowup) * (((size_t)1 << k_lo) + ((size_t)1 << (k - k_lo))); }
+inline void build_lde_tables(int k, int log_blowup, Fp shift, uint32_t* h) {
+    const int k_lo = lde_k_lo(k), k_hi = k - k_lo;
+    const size_t n_lo = (size_t)1 << k_lo, n_hi = (size_t)1 << k_hi, b = (size_t)1 << log_blowup;
+    const Fp w = vg::two_adic_generator((unsigned)(k + log_blowup)), ninv = Fp::from_canonical((uint32_t)(((uint64_t)1 << k) % vg::P)).inv();
+    uint32_t* fac = h;
+    uint32_t* sig = h + b * n_lo;
+    Fp sigma = shift;
+    for (size_t t = 0; t < b; t++) {
+        const Fp g = sigma.exp_power_of_2((unsigned)k_hi);
+        Fp pw = ninv;  // g^j / N
+        for (size_t j = 0; j < n_lo; j++) { fac[t * n_lo + (k_lo ? vg::reverse_bits_len((uint32_t)j, (unsigned)k_lo) : 0)] = pw.v; pw *= g; }
+        Fp a = Fp::one();
+        for (size_t c = 0; c < n_hi; c++) { sig[t * n_hi + c] = a.v; a *= sigma; }
+        sigma *= w;
+    }
+}
+
 __device__ __forceinline__ Fp domain_point(const DeviceTables& t, uint32_t j) {  // w^{bitrev(j)}
     Fp r = Fp::raw(t.brt_lo[j & 2047]);
     if (j >> 11) r *= Fp::raw(t.brt_hi[(j >> 11) & 2047]);
