@@ -140,6 +140,20 @@ inline DMat coset_lde(DeviceCtx* c, hipStream_t st, const CommitInput& in, unsig
     if (n == 0 || (n & (n - 1))) throw std::invalid_argument("commit: matrix heights must be powers of two");
     if (vg::log2_strict_u64(n) + log_blowup > 27)  // BabyBear's two-adicity: no larger multiplicative subgroup exists
         throw std::invalid_argument("commit: LDE height 2^" + std::to_string(vg::log2_strict_u64(n) + log_blowup) + " exceeds the field's two-adicity (2^27)");
+    const unsigned k = vg::log2_strict_u64(n);
+    // natural-order input: the fused three-pass pipeline (kernels/ntt.hip, k_lde_a / k_lde_mid / k_lde_c) — no bit-reversal copy, the
+    // coefficients stay in LDS.  VGPU_LDE_FUSED=0 keeps the unfused passes (A/B runs).
+    static const bool fused = [] { const char* e = getenv("VGPU_LDE_FUSED"); return !(e && e[0] == '0'); }();
+    if (!in.rows_bitrev && fused) {
+        DMat lde(c, n * b, in.mat->width);
+        const vk::LdeTables lt = c->lde_tables((int)k, (int)log_blowup, lde_shift);
+        DMat s1, s2;
+        if (k > 12) { s1 = DMat(c, n, in.mat->width); s2 = DMat(c, n * b, in.mat->width); }
+        vk::launch_lde_natural(st, in.mat->view(), lde.view(), (int)log_blowup, c->tables, lt, s1.empty() ? vk::DMatView{nullptr, 0, 0, 0} : s1.view(),
+                               s2.empty() ? vk::DMatView{nullptr, 0, 0, 0} : s2.view());
+        c->check_launch("coset_lde");
+        return lde;  // s1 / s2 return to the pool while the kernels may still be queued: safe for the same reason as `coeffs` below
+    }
     DMat coeffs;
     if (in.rows_bitrev && in.consume) coeffs = std::move(*in.mat);
     else {
@@ -149,7 +163,6 @@ inline DMat coset_lde(DeviceCtx* c, hipStream_t st, const CommitInput& in, unsig
     }
     vk::launch_intt(st, coeffs.view(), c->tables);
     DMat lde(c, n * b, coeffs.width);
-    const unsigned k = vg::log2_strict_u64(n);
     Fp w = vg::two_adic_generator(k + log_blowup), wt = Fp::one();
     for (uint64_t t = 0; t < b; t++) {
         uint64_t block = vg::reverse_bits_len((uint32_t)t, log_blowup);

@@ -52,6 +52,8 @@ void launch_export_rows(hipStream_t st, DMatView src, uint64_t row0, uint64_t nr
 // ntt.hip
 void launch_intt(hipStream_t st, DMatView m, const DeviceTables& tb);
 void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t dst_row0, Fp shift, const DeviceTables& tb);
+// natural-order evaluations -> committed (bit-reversed) LDE in 3 fused passes (1 for heights <= 2^12); lt: build_lde_tables(k, log_blowup, shift)
+void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blowup, const DeviceTables& tb, const LdeTables& lt, DMatView s1, DMatView s2);
 // merkle.hip
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);
 void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests);

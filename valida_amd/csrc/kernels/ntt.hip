@@ -324,6 +324,142 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
     }
 }
 
+// =======================================================================================================
+// Fused LDE for NATURAL-order input: no row bit-reversal pass, the inverse transform's second pass and the forward transforms' first
+// pass of every coset fused in LDS (the coefficients never travel to HBM), the committed (bit-reversed) row order produced by the last
+// pass's store.  Per column of N = n_hi n_lo evaluations A[i], i = i_hi n_lo + i_lo (index sets: tools/ntt_fused_model.py):
+//   k_lde_a    tile = all i_hi x T consecutive i_lo: DIF over i_hi with inverse roots -> row p holds c_a = bitrev(p); times
+//              w_N^-(i_lo c_a); written to scratch S1 at (p, i_lo).                                          read N, write N
+//   k_lde_mid  block p of S1 (n_lo contiguous words): DIF over i_lo (inverse roots) -> position i holds c_b = bitrev(i): the
+//              coefficient c = c_a + n_hi c_b (times N), which stays in LDS; for every coset t: times fac_t[i] = sigma_t^(n_hi c_b) / N,
+//              DIT over c_b (forward roots) -> position q holds f_b = q, times sigma_t^c_a w_N^(c_a q), written to scratch S2
+//              (coset t, block p).                                                                          read N, write b N
+//   k_lde_c    tile = all blocks (row h = block bitrev(h), i.e. c_a = h) x T consecutive q of S2: DIF over c_a (forward roots) ->
+//              row p'' holds f_a = bitrev(p''); element (p'', q) is the evaluation f = q + n_lo f_a and goes to its committed position
+//              bitrev_k(f) = bitrev(q) n_hi + p'' of LDE block bitrev(t): runs of n_hi consecutive words.     read b N, write b N
+// Traffic (3 + 3 b) N words per column against (1 + 2 + 2 b) 2 N of the unfused passes (b = 2: 9 N instead of 14 N; b = 4: 15 N / 22 N),
+// and 3 launches per matrix instead of 3 + 2 b.  A column of at most 2^12 rows is one tile: k_lde_mid alone (one launch instead of 2 + b).
+// Correctness of the index arithmetic is checked on the CPU by running these kernels under tools/hipemu (tests/test_ntt_emu_cpu.py).
+
+// ---- pass A: inverse, strided, natural input: grid = (n_lo / T, columns) -------------------------------
+__global__ void k_lde_a(DMatView src, DMatView dst, int k, int k_lo, int logT, DeviceTables tb) {
+    extern __shared__ uint32_t lds[];
+    const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
+    const uint64_t n_lo = 1ull << k_lo, r0 = (uint64_t)strided_tile_of_block(blockIdx.x, gridDim.x) * T;
+    uint32_t* tw = lds + n_hi * LD;
+    const uint32_t* in = src.col(blockIdx.y) + r0;
+    uint32_t* out = dst.col(blockIdx.y) + r0;
+    const int total = n_hi << logT;
+    {
+        int e = threadIdx.x;
+        for (; e + 7 * (int)blockDim.x < total; e += 8 * blockDim.x) {  // eight independent loads in flight per thread
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int eu = e + u * (int)blockDim.x; v[u] = in[(uint64_t)(eu >> logT) * n_lo + (eu & (T - 1))]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int eu = e + u * (int)blockDim.x; lds[(eu >> logT) * LD + (eu & (T - 1))] = v[u]; }
+        }
+        for (; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; lds[h * LD + c] = in[(uint64_t)h * n_lo + c]; }
+    }
+    stage_twiddles(tw, tb.itwc, k_hi);
+    __syncthreads();
+    tile_transform<false, false>(lds, tw, k_hi, logT, LD);  // DIF with inverse roots: row p holds c_a = bitrev(p)
+    for (int p = threadIdx.x; p < n_hi; p += blockDim.x) {  // times w_N^-(c_a i_lo): thread per row, running product over the T consecutive i_lo
+        const uint32_t ca = __brev((uint32_t)p) >> (32 - k_hi);  // k_hi >= 1 in this kernel
+        const Fp base = inv_root_pow(tb, k, ca);
+        Fp cur = inv_root_pow(tb, k, (uint32_t)(((uint64_t)ca * r0) & ((1ull << k) - 1)));
+        for (int c = 0; c < T; c++) { lds[p * LD + c] = (Fp::raw(lds[p * LD + c]) * cur).v; cur *= base; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; out[(uint64_t)h * n_lo + c] = lds[h * LD + c]; }
+}
+
+// ---- pass B: contiguous, persistent blocks over (n_hi x columns) tiles: inverse second half + forward first half of every coset ----
+// src: S1 (or the natural-order input itself when the column is one tile).  dst: S2 (coset t at rows [t N, (t + 1) N)) — or, one-tile
+// columns, the LDE itself (block bitrev(t), rows in committed order).  LDS: two padded tiles (coefficients, work).
+__global__ void k_lde_mid(DMatView src, DMatView dst, int k, int k_lo, int lb, DeviceTables tb, LdeTables lt) {
+    extern __shared__ uint32_t lds[];
+    const int n_lo = 1 << k_lo, k_hi = k - k_lo, n_hi = 1 << k_hi, b = 1 << lb;
+    uint32_t* A = lds;
+    uint32_t* W = lds + padded_words(n_lo);
+    const uint64_t N = 1ull << k, tiles_per_col = (uint64_t)n_hi, total = tiles_per_col * src.width;
+    const uint32_t nmask = (uint32_t)(N - 1);
+    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return src.col(cidx) + (t - cidx * tiles_per_col) * n_lo; };
+    uint32_t pre[CONTIG_MAX_PER_THREAD];
+    if (blockIdx.x < total) prefetch_tile(pre, tile_ptr(blockIdx.x), n_lo);
+    for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint64_t cidx = t / tiles_per_col, p = t - cidx * tiles_per_col;
+        commit_tile(pre, A, n_lo);
+        __syncthreads();
+        if (t + gridDim.x < total) prefetch_tile(pre, tile_ptr(t + gridDim.x), n_lo);
+        tile_transform<false, true>(A, tb.itwc, k_lo, 0, 0);  // position i holds (N times) the coefficient with c_b = bitrev(i)
+        const uint32_t ca = k_hi ? __brev((uint32_t)p) >> (32 - k_hi) : 0u;
+        for (int tc = 0; tc < b; tc++) {
+            const uint32_t* fac = lt.fac + (size_t)tc * n_lo;
+            for (int i = threadIdx.x; i < n_lo; i += blockDim.x) W[tile_addr<true>(i, 0, 0)] = (Fp::raw(A[tile_addr<true>(i, 0, 0)]) * Fp::raw(fac[i])).v;
+            __syncthreads();
+            tile_transform<true, true>(W, tb.twc, k_lo, 0, 0);  // DIT with forward roots: position q holds f_b = q
+            if (k_hi > 0) {
+                uint32_t* out = dst.col(cidx) + (uint64_t)tc * N + p * n_lo;
+                const Fp step = root_pow(tb, k, (ca * blockDim.x) & nmask);
+                Fp cur = Fp::raw(lt.sig[(size_t)tc * n_hi + ca]) * root_pow(tb, k, (ca * threadIdx.x) & nmask);
+                for (int q = threadIdx.x; q < n_lo; q += blockDim.x) { out[q] = (Fp::raw(W[tile_addr<true>(q, 0, 0)]) * cur).v; cur *= step; }
+            } else {
+                // the whole column is this tile: committed position of the evaluation q is bitrev_k(q) — permuted on the LDS side, the
+                // global store stays coalesced
+                const uint32_t blk = lb ? __brev((uint32_t)tc) >> (32 - lb) : 0u;
+                uint32_t* out = dst.col(cidx) + (uint64_t)blk * N;
+                for (int j = threadIdx.x; j < n_lo; j += blockDim.x) {
+                    const int q = k ? (int)(__brev((uint32_t)j) >> (32 - k)) : 0;
+                    out[j] = W[tile_addr<true>(q, 0, 0)];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- pass C: forward, strided, transposing store: grid = (n_lo / T, columns, cosets) --------------------
+__global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int logT, DeviceTables tb) {
+    extern __shared__ uint32_t lds[];
+    const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
+    const uint64_t n_lo = 1ull << k_lo, N = 1ull << k, q0 = (uint64_t)strided_tile_of_block(blockIdx.x, gridDim.x) * T;
+    const uint32_t tc = blockIdx.z, blk = lb ? __brev(tc) >> (32 - lb) : 0u;
+    uint32_t* tw = lds + n_hi * LD;
+    const uint32_t* in = src.col(blockIdx.y) + (uint64_t)tc * N + q0;
+    uint32_t* out = dst.col(blockIdx.y) + (uint64_t)blk * N;
+    const int total = n_hi << logT;
+    {
+        // tile row h (= c_a) lives in block bitrev(h) of S2
+        int e = threadIdx.x;
+        for (; e + 7 * (int)blockDim.x < total; e += 8 * blockDim.x) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int eu = e + u * (int)blockDim.x;
+                const uint32_t h = (uint32_t)(eu >> logT), pb = __brev(h) >> (32 - k_hi);
+                v[u] = in[(uint64_t)pb * n_lo + (eu & (T - 1))];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int eu = e + u * (int)blockDim.x; lds[(eu >> logT) * LD + (eu & (T - 1))] = v[u]; }
+        }
+        for (; e < total; e += blockDim.x) {
+            const int c = e & (T - 1);
+            const uint32_t h = (uint32_t)(e >> logT), pb = __brev(h) >> (32 - k_hi);
+            lds[h * LD + c] = in[(uint64_t)pb * n_lo + c];
+        }
+    }
+    stage_twiddles(tw, tb.twc, k_hi);
+    __syncthreads();
+    tile_transform<false, false>(lds, tw, k_hi, logT, LD);  // DIF with forward roots: row p'' holds f_a = bitrev(p'')
+    // element (p'', q0 + c) -> out[bitrev_{k_lo}(q0 + c) n_hi + p'']: n_hi consecutive words per c (LDS read with the odd stride LD: conflict-free)
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int p2 = e & (n_hi - 1), c = e >> k_hi;
+        const uint32_t qb = __brev((uint32_t)(q0 + c)) >> (32 - k_lo);
+        out[(uint64_t)qb * n_hi + p2] = lds[p2 * LD + c];
+    }
+}
+
 // ---- host launchers -----------------------------------------------------------------------------------
 struct NttPlan { int k, k_lo, k_hi, logT; unsigned threads_contig, threads_strided; size_t lds_contig, lds_strided; };
 static NttPlan make_plan(int k) {
@@ -353,6 +489,9 @@ static void set_lds_limit() {
     (void)hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_intt_contig, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_ntt_contig, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_a, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_mid, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_c, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     done = true;
 }
 
@@ -406,6 +545,35 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
         ProfScope ps("k_ntt_contig", st, pass_bytes);
         VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1);
     }
+}
+
+// The bit-reversed LDE of the natural-order evaluations `nat` (column-major, height N = 2^k) on shift * H_{N << log_blowup}, into `lde`
+// (height N << log_blowup).  s1 (N x width) and s2 ((N << log_blowup) x width) are scratch, needed only when N > 2^12 (null views otherwise).
+void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blowup, const DeviceTables& tb, const LdeTables& lt, DMatView s1, DMatView s2) {
+    set_lds_limit();
+    const int k = (int)vg::log2_strict_u64(nat.height);
+    NttPlan p = make_plan(k);
+    const uint64_t tiles = ((uint64_t)1 << p.k_hi) * nat.width;
+    dim3 gm((unsigned)(tiles < 4096 ? tiles : 4096));
+    const size_t lds_mid = 2 * (size_t)padded_words(1 << p.k_lo) * 4;
+    const double nw = 4.0 * nat.height * nat.width, b = (double)(1u << log_blowup);
+    if (p.k_hi == 0) {
+        ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
+        VK_LAUNCH(k_lde_mid, gm, dim3(p.threads_contig), lds_mid, st, nat, lde, k, p.k_lo, log_blowup, tb, lt);
+        return;
+    }
+    dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)nat.width);
+    {
+        ProfScope ps("k_lde_a", st, 2.0 * nw);
+        VK_LAUNCH(k_lde_a, gs, dim3(p.threads_strided), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
+    }
+    {
+        ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
+        VK_LAUNCH(k_lde_mid, gm, dim3(p.threads_contig), lds_mid, st, s1, s2, k, p.k_lo, log_blowup, tb, lt);
+    }
+    dim3 gc((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)nat.width, 1u << log_blowup);
+    ProfScope ps("k_lde_c", st, 2.0 * nw * b);
+    VK_LAUNCH(k_lde_c, gc, dim3(p.threads_strided), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb);
 }
 
 }  // namespace vk
