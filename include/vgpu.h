@@ -261,6 +261,15 @@ int64_t vgpu_proof_cbor(const uint32_t* proof_words, uint64_t n_words, uint32_t 
  * basic/tests/test_prover.rs:456-469): CBOR image -> proof words.  Accepts either setting of the two switches per value.  Returns the word
  * count (copies when out has room), or a negative status with the reason in vgpu_last_error. */
 int64_t vgpu_proof_from_cbor(const uint8_t* bytes, uint64_t n_bytes, uint32_t* out, uint64_t cap_words);
+/* The same for a first contact with a proof file of the real `valida prove` (every encoding convention of the absent crates is recall):
+ * flags & VGPU_CBOR_IN_BARE_IS_MONTGOMERY reads a BARE integer field element as the raw Montgomery word instead of the canonical value;
+ * *forms_seen (may be null) reports what the image contained: VGPU_CBOR_SAW_* bits. */
+#define VGPU_CBOR_IN_BARE_IS_MONTGOMERY 1u
+#define VGPU_CBOR_SAW_FIELD_STRUCT 1u    /* {"value": m} */
+#define VGPU_CBOR_SAW_FIELD_BARE 2u
+#define VGPU_CBOR_SAW_DIGEST_STRUCT 4u   /* Hash { value, _marker } */
+#define VGPU_CBOR_SAW_DIGEST_PLAIN 8u
+int64_t vgpu_proof_from_cbor_ex(const uint8_t* bytes, uint64_t n_bytes, uint32_t flags, uint32_t* out, uint64_t cap_words, uint32_t* forms_seen);
 uint64_t vgpu_proof_len(const vgpu_proof_t* pr);            /* u32 words of the flat "VPF1" encoding */
 const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr);
 /* 11 doubles, ms: ingest, commit_main, perm, commit_perm, quotient, commit_quotient, open_values, open_reduce, fri, queries, total */

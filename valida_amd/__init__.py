@@ -78,12 +78,20 @@ def _u32(a):
     return a, a.ctypes.data_as(c_u32p)
 
 
-def poseidon_round_constants(seed=0x56414C494441):
+def poseidon_round_constants(seed=0x56414C494441, source="splitmix", **cli_switches):
     """480 Poseidon-16 round constants from SplitMix64(seed), rejection-sampled 31-bit values < p.
 
     The reference draws them from thread_rng (basic/tests/test_prover.rs:422); they are configuration
     input here — the same array must be given to the prover and the verifier.
+    source="cli": the constants of the reference's CLI instead — Pcg64 seeded by Seeder::from("validia seed")
+    (basic/src/bin/valida.rs:364-365), restated in valida_amd/cli_constants.py (switches: raw_monty, sip_adj0).
     """
+    if source == "cli":
+        from .cli_constants import cli_poseidon_round_constants
+
+        return cli_poseidon_round_constants(**cli_switches)
+    if source != "splitmix":
+        raise ValueError("source must be 'splitmix' or 'cli'")
     out = []
     x = seed & 0xFFFFFFFFFFFFFFFF
     while len(out) < 480:
@@ -481,6 +489,23 @@ def proof_from_cbor(data):
     out = np.zeros(int(n), dtype=np.uint32)
     L.vgpu_proof_from_cbor(buf, ctypes.c_uint64(len(b)), out.ctypes.data_as(c_u32p), ctypes.c_uint64(int(n)))
     return out
+
+
+def proof_from_cbor_ex(data, bare_is_montgomery=False):
+    """(proof words, forms seen) — vgpu_proof_from_cbor_ex: the decoder with the one reading the image itself cannot decide (a bare integer as
+    the Montgomery word) selectable, and a report of the encodings met: bit 1 field as {"value": m}, 2 field bare, 4 digest as Hash struct, 8 plain."""
+    b = bytes(data)
+    buf = (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(b if b else b"\0")
+    L = lib()
+    L.vgpu_proof_from_cbor_ex.restype = ctypes.c_int64
+    seen = ctypes.c_uint32(0)
+    fl = ctypes.c_uint32(1 if bare_is_montgomery else 0)
+    n = L.vgpu_proof_from_cbor_ex(buf, ctypes.c_uint64(len(b)), fl, None, ctypes.c_uint64(0), ctypes.byref(seen))
+    if n < 0:
+        _check(int(n))
+    out = np.zeros(int(n), dtype=np.uint32)
+    L.vgpu_proof_from_cbor_ex(buf, ctypes.c_uint64(len(b)), fl, out.ctypes.data_as(c_u32p), ctypes.c_uint64(int(n)), ctypes.byref(seen))
+    return out, int(seen.value)
 
 
 class Comm:

@@ -746,6 +746,16 @@ int64_t vgpu_proof_from_cbor(const uint8_t* bytes, uint64_t n_bytes, uint32_t* o
         return (int64_t)w.size();
     } catch (const std::exception& e) { return (int64_t)fail(VGPU_ERR_INVALID_ARG, e.what()); }
 }
+int64_t vgpu_proof_from_cbor_ex(const uint8_t* bytes, uint64_t n_bytes, uint32_t flags, uint32_t* out, uint64_t cap_words, uint32_t* forms_seen) {
+    try {
+        if (!bytes) throw std::invalid_argument("null argument");
+        ProofCborDecoder dec(bytes, (size_t)n_bytes, (flags & 1u) != 0);
+        std::vector<uint32_t> w = dec.decode();
+        if (forms_seen) *forms_seen = dec.seen();
+        if (out && cap_words >= w.size()) memcpy(out, w.data(), w.size() * 4);
+        return (int64_t)w.size();
+    } catch (const std::exception& e) { return (int64_t)fail(VGPU_ERR_INVALID_ARG, e.what()); }
+}
 uint64_t vgpu_proof_len(const vgpu_proof_t* pr) { return pr->words.size(); }
 const uint32_t* vgpu_proof_words(const vgpu_proof_t* pr) { return pr->words.data(); }
 void vgpu_proof_phase_ms(const vgpu_proof_t* pr, double out[11]) {

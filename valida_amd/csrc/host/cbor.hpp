@@ -162,7 +162,11 @@ inline std::vector<uint8_t> proof_to_cbor(const uint32_t* words, size_t n, uint3
 // per value (a field element is a bare integer or {"value": <Montgomery word>}; a digest a bare array or {value, _marker}).
 class ProofCborDecoder {
   public:
-    ProofCborDecoder(const uint8_t* bytes, size_t n) : b_(bytes), n_(n) {}
+    // bare_is_montgomery: read a bare integer field element as the raw Montgomery word (a serializer that writes `value` without the struct
+    // wrapper) instead of the canonical value.  seen(): which forms occurred — 1 field as {"value": m}, 2 field as a bare integer,
+    // 4 digest as {value, _marker}, 8 digest as a bare array — so a first contact with a real proof file can say what it met.
+    ProofCborDecoder(const uint8_t* bytes, size_t n, bool bare_is_montgomery = false) : b_(bytes), n_(n), bare_monty_(bare_is_montgomery) {}
+    unsigned seen() const { return seen_; }
     std::vector<uint32_t> decode() {
         std::vector<uint32_t> roots, chips, pcs;
         map(3);
@@ -190,6 +194,8 @@ class ProofCborDecoder {
   private:
     const uint8_t* b_;
     size_t n_, pos_ = 0;
+    bool bare_monty_ = false;
+    unsigned seen_ = 0;
     [[noreturn]] static void bad(const char* why) { throw std::invalid_argument(std::string("cbor: ") + why); }
     uint8_t byte() { if (pos_ >= n_) bad("truncated input"); return b_[pos_++]; }
     // (major type, argument) of the next item; only the definite-length forms a serde / ciborium writer produces
@@ -223,11 +229,13 @@ class ProofCborDecoder {
             map(1); key("value");
             const uint32_t m = word("expected a field element");
             if (m >= vg::P) bad("field element out of range");
+            seen_ |= 1u;
             return vg::Fp::raw(m).canonical();
         }
         const uint32_t c = word("expected a field element");
         if (c >= vg::P) bad("field element out of range");
-        return c;
+        seen_ |= 2u;
+        return bare_monty_ ? vg::Fp::raw(c).canonical() : c;
     }
     void ext(std::vector<uint32_t>& out) {
         if (pos_ < n_ && (b_[pos_] >> 5) == 5) { map(1); key("value"); }
@@ -237,6 +245,7 @@ class ProofCborDecoder {
     void digest(std::vector<uint32_t>& out) {
         const bool wrapped = pos_ < n_ && (b_[pos_] >> 5) == 5;
         if (wrapped) { map(2); key("value"); }
+        seen_ |= wrapped ? 4u : 8u;
         array(8);
         for (int k = 0; k < 8; k++) out.push_back(val());
         if (wrapped) { key("_marker"); if (byte() != 0xf6) bad("expected null for PhantomData"); }
