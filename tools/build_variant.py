@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""A/B builds of ONE kernel file: compile it with extra -D flags and link it with the current objects of everything else into
+build/variants/<name>/libvgpu.so (picked up through VGPU_LIB_PATH; tools/gpu_ab*.sh alternate libraries inside one GPU session).
+
+    python tools/build_variant.py <name> kernels/ntt.hip -DVGPU_MID12_WAVES=4 [-D...]
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from valida_amd import build as b  # noqa: E402
+
+
+def main():
+    name, src, flags = sys.argv[1], sys.argv[2], sys.argv[3:]
+    b.build_vgpu()  # the baseline objects
+    out_dir = os.path.join(b.BUILD, "variants", name)
+    os.makedirs(out_dir, exist_ok=True)
+    obj = os.path.join(out_dir, src.replace("/", "_") + ".o")
+    subprocess.run(["hipcc"] + b.FLAGS + flags + ["-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj], check=True)
+    objs = [obj if s == src else os.path.join(b.BUILD, s.replace("/", "_") + ".o") for s in b.SOURCES]
+    lib = os.path.join(out_dir, "libvgpu.so")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"], check=True)
+    print(lib)
+
+
+if __name__ == "__main__":
+    main()

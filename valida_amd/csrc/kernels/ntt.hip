@@ -30,6 +30,38 @@ template <bool PAD> __device__ __forceinline__ int tile_addr(int i, int c, int L
 // tw: compact tables in LDS, stage s at offset 2^(s-1) - 1: tw[off + j] = w_{2^s}^{+-j}, j < 2^(s-1).
 // LB >= 0 fixes s_lo - 1 at compile time (the 2^12-point contiguous tile: every LDS address of the 16
 // points and 15 twiddles becomes base + immediate offset, no per-access address arithmetic).
+// The R stages of one round on the 2^R points a work item holds in registers.  `low` = the item's low index bits (below the round's
+// stages), lowbits their count: stage s = lowbits + 1 + st pairs the points differing in bit st with the twiddle w_{2^s}^(low + (k << lowbits)).
+// LB0 (lowbits == 0, i.e. stages 1 .. R: the first DIT / last DIF round): the twiddle of butterfly p is w^(p & (half - 1)) with a compile-time
+// exponent, and exponent 0 is the factor 1 — 15 of a radix-16 round's 32 butterflies need no multiplication at all.
+template <int R, bool DIT, bool LB0>
+__device__ __forceinline__ void butterflies(Fp (&x)[1 << R], const uint32_t* tw, int low, int lowbits) {
+    constexpr int G = 1 << R;
+#pragma unroll
+    for (int step = 0; step < R; step++) {
+        const int st = DIT ? step : R - 1 - step;  // stage s = s_lo + st pairs g differing in bit st
+        const int half = 1 << st;
+        const uint32_t* t = tw + ((1 << (lowbits + st)) - 1) + low;
+        Fp wv[G / 2];
+#pragma unroll
+        for (int k = 0; k < G / 2; k++)
+            if (k < half && !(LB0 && k == 0)) wv[k] = Fp::raw(t[k << lowbits]);
+#pragma unroll
+        for (int p = 0; p < G / 2; p++) {
+            const int g0 = ((p >> st) << (st + 1)) | (p & (half - 1)), g1 = g0 | half;
+            if (LB0 && (p & (half - 1)) == 0) { Fp u = x[g0], v = x[g1]; x[g0] = u + v; x[g1] = u - v; continue; }
+            const Fp wk = wv[p & (half - 1)];
+            if (DIT) { Fp u = x[g0], v = x[g1] * wk; x[g0] = u + v; x[g1] = u - v; }
+            else {
+                // (u - v) * w with the difference left unreduced in (0, 2p): the Montgomery product only needs a * b < p * 2^32
+                Fp u = x[g0], v = x[g1];
+                x[g0] = u + v;
+                x[g1] = Fp::raw(vg::monty_reduce((uint64_t)(u.v + (vg::P - v.v)) * wk.v));
+            }
+        }
+    }
+}
+
 template <int R, bool DIT, bool PAD, int LB>
 __device__ __forceinline__ void ntt_round(uint32_t* buf, const uint32_t* tw, int logn, int s_lo, int logT, int LD) {
     constexpr int G = 1 << R;
@@ -51,31 +83,7 @@ __device__ __forceinline__ void ntt_round(uint32_t* buf, const uint32_t* tw, int
 #pragma unroll
             for (int g = 0; g < G; g++) x[g] = Fp::raw(buf[tile_addr<PAD>(base | (g << lowbits), c, LD)]);
         }
-#pragma unroll
-        for (int step = 0; step < R; step++) {
-            const int st = DIT ? step : R - 1 - step;  // stage s = s_lo + st pairs g differing in bit st
-            const int half = 1 << st;
-            const uint32_t* t = tw + ((1 << (lowbits + st)) - 1) + low;
-            // LB == 0 (stages 1 .. R: the first DIT / last DIF round): the twiddle of butterfly p is w^(p & (half - 1)) with a compile-time
-            // exponent, and exponent 0 is the factor 1 — 15 of a radix-16 round's 32 butterflies need no multiplication at all
-            Fp wv[G / 2];
-#pragma unroll
-            for (int k = 0; k < G / 2; k++)
-                if (k < half && !(LB == 0 && k == 0)) wv[k] = Fp::raw(t[k << lowbits]);
-#pragma unroll
-            for (int p = 0; p < G / 2; p++) {
-                const int g0 = ((p >> st) << (st + 1)) | (p & (half - 1)), g1 = g0 | half;
-                if (LB == 0 && (p & (half - 1)) == 0) { Fp u = x[g0], v = x[g1]; x[g0] = u + v; x[g1] = u - v; continue; }
-                const Fp wk = wv[p & (half - 1)];
-                if (DIT) { Fp u = x[g0], v = x[g1] * wk; x[g0] = u + v; x[g1] = u - v; }
-                else {
-                    // (u - v) * w with the difference left unreduced in (0, 2p): the Montgomery product only needs a * b < p * 2^32
-                    Fp u = x[g0], v = x[g1];
-                    x[g0] = u + v;
-                    x[g1] = Fp::raw(vg::monty_reduce((uint64_t)(u.v + (vg::P - v.v)) * wk.v));
-                }
-            }
-        }
+        butterflies<R, DIT, LB == 0>(x, tw, low, lowbits);
         if (linear) {
 #pragma unroll
             for (int g = 0; g < G; g++) p0[g * gs] = x[g].v;
@@ -419,6 +427,101 @@ __global__ void k_lde_mid(DMatView src, DMatView dst, int k, int k_lo, int lb, D
     }
 }
 
+// ---- pass B for 2^12-point tiles (every height from 2^13 to 2^22): the same computation with the first round of the inverse transform
+// fed straight from the global loads, its last round and the first round of every forward transform joined in registers (both work on the
+// thread's own 16 consecutive positions: the coefficients never leave the register file), the last forward round stored straight to
+// HBM: ONE LDS tile instead of two, 2 + 3 b barriers per tile instead of 4 + 5 b, half the LDS traffic.  256 threads x 16 points.
+#ifndef VGPU_MID12_WAVES
+#define VGPU_MID12_WAVES 0  // > 0: occupancy the register allocator must reach (waves per SIMD); A/B builds: tools/build_variant.py
+#endif
+#ifndef VGPU_MID12_PREFETCH
+#define VGPU_MID12_PREFETCH 1
+#endif
+#if VGPU_MID12_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(VGPU_MID12_WAVES, VGPU_MID12_WAVES)))
+#endif
+__global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, int k, int lb, DeviceTables tb, LdeTables lt) {
+    extern __shared__ uint32_t lds[];
+    constexpr int K_LO = 12, N_LO = 1 << K_LO;
+    const int k_hi = k - K_LO, n_hi = 1 << k_hi, b = 1 << lb, tid = threadIdx.x;
+    const uint64_t N = 1ull << k, tiles_per_col = (uint64_t)n_hi, total = tiles_per_col * src.width;
+    const uint32_t nmask = (uint32_t)(N - 1);
+    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return src.col(cidx) + (t - cidx * tiles_per_col) * N_LO; };
+#if VGPU_MID12_PREFETCH
+    uint32_t pre[16];
+    if (blockIdx.x < total) {
+        const uint32_t* sp = tile_ptr(blockIdx.x);
+#pragma unroll
+        for (int g = 0; g < 16; g++) pre[g] = sp[tid + 256 * g];
+    }
+#endif
+    for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint64_t cidx = t / tiles_per_col, p = t - cidx * tiles_per_col;
+        Fp x[16];
+#if VGPU_MID12_PREFETCH
+#pragma unroll
+        for (int g = 0; g < 16; g++) x[g] = Fp::raw(pre[g]);
+        if (t + gridDim.x < total) {  // the next tile's loads land while this one computes
+            const uint32_t* sp = tile_ptr(t + gridDim.x);
+#pragma unroll
+            for (int g = 0; g < 16; g++) pre[g] = sp[tid + 256 * g];
+        }
+#else
+        {
+            const uint32_t* sp = tile_ptr(t);
+#pragma unroll
+            for (int g = 0; g < 16; g++) x[g] = Fp::raw(sp[tid + 256 * g]);
+        }
+#endif
+        // inverse, stages 12 .. 9 on the points tid + 256 g (DIF, inverse roots)
+        butterflies<4, false, false>(x, tb.itwc, tid, 8);
+        {
+            uint32_t* p0 = lds + tile_addr<true>(tid, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 16; g++) p0[g * 272] = x[g].v;  // tile_addr(tid + 256 g) = tile_addr(tid) + 272 g
+        }
+        __syncthreads();
+        ntt_round<4, false, true, 4>(lds, tb.itwc, 12, 5, 0, 0);  // stages 8 .. 5 (ends with a barrier)
+        {
+            const uint32_t* p0 = lds + 17 * tid;  // positions 16 tid + g
+#pragma unroll
+            for (int g = 0; g < 16; g++) x[g] = Fp::raw(p0[g]);
+        }
+        butterflies<4, false, true>(x, tb.itwc, 0, 0);  // stages 4 .. 1: x[g] = N times the coefficient with c_b = bitrev(16 tid + g)
+        const uint32_t ca = __brev((uint32_t)p) >> (32 - k_hi);
+        const Fp step = root_pow(tb, k, (ca * 256u) & nmask), tw0 = root_pow(tb, k, (ca * (uint32_t)tid) & nmask);
+        for (int tc = 0; tc < b; tc++) {
+            Fp y[16];
+            {
+                const uint32_t* fac = lt.fac + (size_t)tc * N_LO + 16 * tid;
+#pragma unroll
+                for (int g = 0; g < 16; g++) y[g] = x[g] * Fp::raw(fac[g]);
+            }
+            butterflies<4, true, true>(y, tb.twc, 0, 0);  // forward, stages 1 .. 4 (DIT, forward roots)
+            {
+                // the thread's own 16 positions: no one else reads or writes them between the inverse transform's last round and here;
+                // other threads' reads of them by the PREVIOUS coset's last round are behind that coset's closing barrier
+                uint32_t* p0 = lds + 17 * tid;
+#pragma unroll
+                for (int g = 0; g < 16; g++) p0[g] = y[g].v;
+            }
+            __syncthreads();
+            ntt_round<4, true, true, 4>(lds, tb.twc, 12, 5, 0, 0);  // stages 5 .. 8
+            {
+                const uint32_t* p0 = lds + tile_addr<true>(tid, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 16; g++) y[g] = Fp::raw(p0[g * 272]);
+            }
+            butterflies<4, true, false>(y, tb.twc, tid, 8);  // stages 9 .. 12: y[g] = the evaluation f_b = tid + 256 g of this block
+            uint32_t* out = dst.col(cidx) + (uint64_t)tc * N + p * N_LO + tid;
+            Fp cur = Fp::raw(lt.sig[(size_t)tc * n_hi + ca]) * tw0;  // sigma_t^c_a w_N^(c_a q), q = tid + 256 g
+#pragma unroll
+            for (int g = 0; g < 16; g++) { out[256 * g] = (y[g] * cur).v; cur *= step; }
+            __syncthreads();  // the tile is free for the next coset / the next tile
+        }
+    }
+}
+
 // ---- pass C: forward, strided, transposing store: grid = (n_lo / T, columns, cosets) --------------------
 __global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int logT, DeviceTables tb) {
     extern __shared__ uint32_t lds[];
@@ -492,6 +595,7 @@ static void set_lds_limit() {
     (void)hipFuncSetAttribute((const void*)k_lde_a, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_mid, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_c, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_mid12, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     done = true;
 }
 
@@ -567,7 +671,11 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
         ProfScope ps("k_lde_a", st, 2.0 * nw);
         VK_LAUNCH(k_lde_a, gs, dim3(p.threads_strided), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
     }
-    {
+    static const bool mid12 = [] { const char* e = getenv("VGPU_LDE_MID12"); return !(e && e[0] == '0'); }();
+    if (p.k_lo == 12 && mid12) {
+        ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
+        VK_LAUNCH(k_lde_mid12, gm, dim3(256), (size_t)padded_words(4096) * 4, st, s1, s2, k, log_blowup, tb, lt);
+    } else {
         ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
         VK_LAUNCH(k_lde_mid, gm, dim3(p.threads_contig), lds_mid, st, s1, s2, k, p.k_lo, log_blowup, tb, lt);
     }
