@@ -198,7 +198,20 @@ template <int RFKIND, int CHIP = -1>
 __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables tb) {
     extern __shared__ uint32_t regs[];
     const uint64_t n = 1ull << a.log_n;
-    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Which pair a thread owns.  The successor x g of a point is natural index + 2, i.e. in terms of the pair index m (bit b of m = natural
+    // bit log_n - 1 - b) an increment at bit log_n - 2 with the carry running DOWN: the set {all 8 values of bits log_n - 2 .. log_n - 4}
+    // x {32 consecutive low values} is closed under it except when those three bits are all ones.  A workgroup takes such a set (8 groups of
+    // 32 pairs = 64 consecutive storage rows each): 7 of 8 `next` rows it reads are `local` rows of its own threads, read at about the same
+    // time (the chip code touches a column's local and next value together) — they come from L1 / the XCD's L2 instead of HBM a second
+    // time.  Work is only permuted: results are position for position the same.  Heights below 2^9 keep the linear map.
+    uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#ifndef VGPU_QUOT_TILE
+#define VGPU_QUOT_TILE 1  // 0: the linear map (A/B builds, tools/build_variant.py)
+#endif
+    if (VGPU_QUOT_TILE && a.log_n >= 9 && blockDim.x == 256) {
+        const uint32_t B = blockIdx.x, top = B >> (a.log_n - 9), mid = B & ((1u << (a.log_n - 9)) - 1u);
+        m = ((uint64_t)top << (a.log_n - 1)) | ((uint64_t)(threadIdx.x >> 5) << (a.log_n - 4)) | ((uint64_t)mid << 5) | (threadIdx.x & 31u);
+    }
     if (m >= n) return;  // no block-level synchronisation below: LDS slots are thread-private
     const int kq = a.log_n + 1;
     const uint32_t Qmask = (uint32_t)(2 * n - 1);
