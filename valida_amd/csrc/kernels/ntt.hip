@@ -673,6 +673,8 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
     }
     static const bool mid12 = [] { const char* e = getenv("VGPU_LDE_MID12"); return !(e && e[0] == '0'); }();
     if (p.k_lo == 12 && mid12) {
+        static const unsigned cap = [] { const char* e = getenv("VGPU_MID12_GRID"); return e ? (unsigned)atoi(e) : 4096u; }();  // persistent blocks (A/B)
+        if (cap && gm.x > cap) gm.x = cap;
         ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
         VK_LAUNCH(k_lde_mid12, gm, dim3(256), (size_t)padded_words(4096) * 4, st, s1, s2, k, log_blowup, tb, lt);
     } else {
