@@ -408,13 +408,13 @@ def main():
         # ONE proof over W prover contexts of this GPU standing in for W ranks (vgpu_prove_sharded_local).  All the work
         # still runs on this one device, so the figures show what sharding COSTS (exchanges as device-to-device copies, the small chips and
         # the permutation traces computed by every rank, the host steps between the phases) — not a speed-up.
-        if world == 1 and prover.log_blowup == 1 and os.environ.get("VGPU_BENCH_SHARDED", "1") == "1":
+        if world == 1 and os.environ.get("VGPU_BENCH_SHARDED", "1") == "1":
             sharded_local = {}
             ref_words = provers[0].prove(*inputs[0]).words
             extra = []
             for wn in (1, 2, 4, 8):
                 while len(provers) + len(extra) < wn:
-                    extra.append(va.Prover(machine, rc, log_blowup=1, device=local_rank, hash_kind=hash_kind))
+                    extra.append(va.Prover(machine, rc, log_blowup=prover.log_blowup, device=local_rank, hash_kind=hash_kind))
                 ps = (provers + extra)[:wn]
                 up = va.upload_replicated(ps, mt, prep)
                 pr = va.prove_sharded_local(ps, mt, prep, uploaded=up)  # sizes the pools
@@ -594,7 +594,7 @@ def main():
                 out["vs_baseline"] = value / cb["value"]
                 out["vs_baseline_is"] = "value / cpu_baseline.value of this run (kind: %s; BASELINE.md section 2 target >= 20x; no published number exists)" % cb["kind"]
         print(json.dumps(out), flush=True)
-    if world > 1 and lib_comm is not None and not comm_stuck and prover.log_blowup == 1 and os.environ.get("VGPU_BENCH_SHARDED", "1") == "1":
+    if world > 1 and lib_comm is not None and not comm_stuck and os.environ.get("VGPU_BENCH_SHARDED", "1") == "1":
         # After the contract line (nothing below can change it): ONE proof — rank 0's segment — over ALL the ranks (vgpu_prove_sharded over
         # RCCL / xGMI: row-range shards), reported on stderr.  The first run of this path on real multi-GPU hardware:
         # a watchdog bounds it and every rank leaves without further collectives.

@@ -310,7 +310,8 @@ int32_t vgpu_commit_batches_sharded_local(vgpu_prover_t* const* provers, uint32_
  * an all-gather of partial opened values, a roots all-gather per sharded FRI layer, an all-gather of the proof tail.  Every rank
  * passes the SAME traces (they are replicated; what a proof's memory goes into — LDEs, trees, FRI layers — is sharded) and
  * receives the SAME proof words vgpu_prove gives on one GPU.  Matrices whose LDE has fewer than max(4 world, 2^log_min_sharded) rows
- * are computed whole by every rank.  Needs log_blowup = 1 and chips of log_quotient_degree 1; world must be a power of two.  The call
+ * are computed whole by every rank.  Any log_blowup (the quotient domain, machine/src/quotient.rs:41-47, is the first world >> (log_blowup - 1)
+ * ranks' row ranges: those ranks evaluate the quotient); chips of log_quotient_degree 1; world must be a power of two.  The call
  * owns the prover context and the communicator until it returns: no other proof on `p`, no vgpu_comm_* call on `comm` from another thread
  * meanwhile (RCCL serialises the operations of one communicator), and every rank must make the same call with traces of the same shapes. */
 int32_t vgpu_prove_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,

@@ -144,11 +144,41 @@ def test_sharded_proof_over_the_rccl_fabric_world_of_one(machine, rc, fib25):
     assert_oracle_proof(sharded.words, mt, prep, rc)
 
 
+@pytest.mark.parametrize("world,log_blowup,log_min", [(1, 2, 2), (2, 2, 2), (4, 2, 3), (8, 2, 2), (4, 3, 2), (2, 3, 2), (8, 3, 3)])
+def test_sharded_proof_with_a_larger_blowup(machine, rc, fib25, world, log_blowup, log_min):
+    """C3's configuration (4x blowup) and 8x: the quotient domain is the first L >> (log_blowup - 1) storage rows of every LDE (machine/src/quotient.rs:41-47
+    takes it as a strided view), i.e. the row ranges of the first world >> (log_blowup - 1) ranks: they evaluate the quotient (halo among
+    themselves once there are more than two), every rank receives its columns of the chunks.  Also world < 2^(log_blowup - 1): one rank, part of its range."""
+    p0, mt, prep, single = single_and_inputs(machine, rc, fib25, log_blowup=log_blowup)
+    provers = [p0] + [va.Prover(machine, rc, log_blowup=log_blowup) for _ in range(world - 1)]
+    sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=log_min)
+    assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc, log_blowup=log_blowup)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_proof_of_c3s_configuration_at_2_16(machine, rc, world):
+    """fib(9359): cpu 2^16 / mem 2^18 rows with the 4x blowup of C3 (LDEs of 2^18 .. 2^20 rows sharded, strided NTT passes, matrix-core opened values)."""
+    w = va.Workload.fib(9359)
+    p0, mt, prep, single = single_and_inputs(machine, rc, w, log_blowup=2)
+    provers = [p0] + [va.Prover(machine, rc, log_blowup=2) for _ in range(world - 1)]
+    sharded = va.prove_sharded_local(provers, mt, prep)
+    assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc, log_blowup=2)
+
+
+def test_sharded_proof_of_c3_at_full_size(machine, rc):
+    """C3 itself (fib 599 183: cpu 2^22, mem 2^24 rows, 4x blowup — the proof whose 116 GB of algorithmic traffic is the reason to shard) over 8
+    ranks: the oracle's proof of these traces, by the committed fixture."""
+    w = va.Workload.fib(599183)
+    mt, prep = w.main_traces(), w.preprocessed()
+    provers = [va.Prover(machine, rc, log_blowup=2) for _ in range(8)]
+    sharded = va.prove_sharded_local(provers, mt, prep)
+    assert_fixture(sharded, mt, "full_c3_fib599183_blowup4.json")
+
+
 def test_sharded_proof_refuses_what_it_does_not_implement(machine, rc, fib25):
     mt, prep = fib25.main_traces(), fib25.preprocessed()
-    provers = [va.Prover(machine, rc, log_blowup=2) for _ in range(2)]
-    with pytest.raises(va.VgpuError, match="log_blowup"):
-        va.prove_sharded_local(provers, mt, prep)
     provers = [va.Prover(machine, rc) for _ in range(3)]
     with pytest.raises(va.VgpuError, match="power of two"):
         va.prove_sharded_local(provers, mt, prep)

@@ -23,7 +23,8 @@
 //               the local one times w^-e: folded into beta), its tree built like a commitment round; once a layer is shorter than the
 //               threshold it is gathered and the remaining layers run on every rank.  The transcript is replicated.
 //   queries     every rank lays out the same proof tail and fills in the rows / digests it holds; the tails are OR-ed (ALL-GATHER).
-// Restrictions: log_blowup = 1 and log_quotient_degree = 1 (the quotient domain is the whole LDE; every chip of the reference).
+// Any log_blowup >= 1 (the quotient domain is the first L >> (log_blowup - 1) storage rows: the first W >> (log_blowup - 1) ranks' row ranges);
+// log_quotient_degree = 1 (every chip of the reference); W a power of two.
 #include "sharded_prover.hpp"
 #include <algorithm>
 #include <array>
@@ -125,11 +126,12 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
     const MachineDesc& md = provers[0]->machine_;
     const FriParams fri = provers[0]->fri_;
     const size_t NC = md.airs.size();
-    if (fri.log_blowup != 1) throw std::invalid_argument("sharded prove: log_blowup must be 1 (the quotient domain has to be the whole LDE)");
+    if (fri.log_blowup < 1) throw std::invalid_argument("sharded prove: log_blowup must be at least 1 (= the chips' log_quotient_degree)");
     for (auto& a : md.airs) if (a.log_quotient_degree != 1) throw std::invalid_argument("sharded prove: chip " + a.name + ": log_quotient_degree must be 1");
     if (log_min_sharded > 27) throw std::invalid_argument("sharded prove: log_min_sharded out of range");
-    const uint64_t min_big = std::max<uint64_t>(4ull * (uint64_t)W, 1ull << log_min_sharded);
     const unsigned lb = fri.log_blowup;
+    // a sharded object has at least 4 rows per rank, and more rows than the final FRI layer (2^lb values, held whole by every rank)
+    const uint64_t min_big = std::max<uint64_t>(std::max<uint64_t>(4ull * (uint64_t)W, 1ull << log_min_sharded), 2ull << lb);
     const Fp s = Fp::from_canonical(vg::GENERATOR);  // pcs.coset_shift()
 
     std::vector<Rank> rk((size_t)NH);
@@ -466,29 +468,42 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
     // quotients (lib.rs:263-599)
     // ---------------------------------------------------------------------------------------------------------------------------
     for (auto& R : rk) R.alpha = R.ch->sample_ext();
-    // the rank holding the successors of rank r's points: sub-coset e + 2 (the trace generator is w_L^2 for blowup 2)
-    auto next_rank = [&](const Rank& R) { return logW ? (int)vg::reverse_bits_len((R.e + 2u) % (uint32_t)W, logW) : 0; };
-    auto pred_rank = [&](const Rank& R) { return logW ? (int)vg::reverse_bits_len((R.e + (uint32_t)W - (2u % (uint32_t)W)) % (uint32_t)W, logW) : 0; };
+    // The quotient domain s H_{2n} is the first L >> dq storage rows of an LDE of L = n 2^lb rows (dq = lb - 1; machine/src/quotient.rs:41-47
+    // takes the same rows as a strided view of the natural-order LDE): the row ranges of the first Wq = max(1, W >> dq) ranks.  Those ranks
+    // evaluate the quotient, the others only receive their columns of the chunks afterwards.  Inside the quotient domain rank r < Wq holds the
+    // sub-coset s w_Q^eq H_{Q / Wq}, eq = bitrev_Wq(r) = e >> dq, and everything below is the blowup-2 picture with (W, e) -> (Wq, eq).
+    const unsigned dq = lb - 1;
+    const int Wq = std::max(1, W >> dq);
+    const unsigned logWq = vg::log2_strict_u64((uint64_t)Wq);
+    auto quot_rank = [&](const Rank& R) { return R.rank < Wq; };
+    auto eq_of = [&](const Rank& R) { return R.e >> std::min(dq, logW); };
+    // rows of chip i's LDE shard that lie in the quotient domain (ranks below Wq): the whole shard once W >= 2^dq
+    auto quot_rows = [&](uint64_t L) { return (L >> dq) / (uint64_t)Wq; };
+    // the rank holding the successors of rank r's points: sub-coset eq + 2 (the trace generator is w_Q^2)
+    auto next_rank = [&](const Rank& R) { return logWq ? (int)vg::reverse_bits_len((eq_of(R) + 2u) % (uint32_t)Wq, logWq) : 0; };
+    auto pred_rank = [&](const Rank& R) { return logWq ? (int)vg::reverse_bits_len((eq_of(R) + (uint32_t)Wq - (2u % (uint32_t)Wq)) % (uint32_t)Wq, logWq) : 0; };
     std::vector<size_t> big_chips;
     for (size_t i = 0; i < NC; i++) if (rk[0].main_rs.mats[i].big) big_chips.push_back(i);
-    const bool need_halo = W > 2 && !big_chips.empty();
+    const bool need_halo = Wq > 2 && !big_chips.empty();
     // halo layout (the same on every rank): per big chip [preprocessed shard][main shard][permutation shard], each a contiguous column-major block
     std::vector<size_t> halo_off(NC, 0);
     size_t halo_words = 0;
     for (size_t i : big_chips) {
         const ShMat& mm = rk[0].main_rs.mats[i];
         const ShMat& pm = rk[0].perm_rs.mats[i];
-        const uint64_t rows = mm.L / W;
+        const uint64_t rows = quot_rows(mm.L);
         halo_off[i] = halo_words;
         if (prep_slot[i] >= 0) halo_words += rows * rk[0].prep_rs.mats[prep_slot[i]].width;
         halo_words += rows * mm.width + rows * pm.width;
     }
-    if (need_halo) {
+    if (need_halo) {  // Wq > 2 implies W >= 4 * 2^dq: a quotient rank's shard lies in the quotient domain with all its rows
         std::vector<Fabric::A2A> plan((size_t)NH);
         for (int k = 0; k < NH; k++) {
             Rank& R = rk[k];
             DeviceCtx& c = *R.c;
             c.activate();
+            plan[k] = Fabric::A2A(&c, W);
+            if (!quot_rank(R)) continue;
             R.halo_send = DBuf(&c, halo_words + 4);
             R.halo_recv = DBuf(&c, halo_words + 4);
             for (size_t i : big_chips) {
@@ -501,7 +516,6 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 put(R.main_rs.mats[i].shard);
                 put(R.perm_rs.mats[i].shard);
             }
-            plan[k] = Fabric::A2A(&c, W);
             const int to = pred_rank(R), from = next_rank(R);
             plan[k].send[to] = R.halo_send.data; plan[k].send_words[to] = halo_words;
             plan[k].recv[from] = R.halo_recv.data; plan[k].recv_words[from] = halo_words;
@@ -531,7 +545,8 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         DBuf pool_dev(&c, pool);
         R.quot_full.clear(); R.quot_full.resize(NC);
         R.quot_shard.clear(); R.quot_shard.resize(NC);
-        const uint32_t d = (R.e + 2u) / (uint32_t)W;  // the successor's natural index inside its shard: same (0) or following (1); 2 on one rank
+        const uint32_t eq = eq_of(R);
+        const uint32_t d = (eq + 2u) / (uint32_t)Wq;  // the successor's natural index inside its shard: same (0) or following (1); 2 on one rank
         for (size_t i = 0; i < NC; i++) {
             const ShMat& mm = R.main_rs.mats[i];
             const ShMat& pm = R.perm_rs.mats[i];
@@ -545,19 +560,21 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 vk::launch_quotient(c.stream, a, c.tables);
                 continue;
             }
-            const uint64_t rows = mm.L / W;               // this rank's storage rows of the LDE = its part of the quotient domain
+            if (!quot_rank(R)) continue;  // this rank's row range lies outside the quotient domain
+            const uint64_t rows = quot_rows(mm.L);        // this rank's storage rows inside the quotient domain (the first rows of its shard)
             const unsigned log_rows = vg::log2_strict_u64(rows);
-            R.p->fill_quotient_args(a, (int)i, mm.shard.view(), pm.shard.view(), qm ? qm->shard.view() : vk::DMatView{nullptr, 0, 0, 0}, log_rows - 1, pool_dev.data + off[i]);
+            auto qview = [&](const DMat& sh) { return vk::DMatView{sh.data, rows, sh.width, sh.height}; };
+            R.p->fill_quotient_args(a, (int)i, qview(mm.shard), qview(pm.shard), qm ? qview(qm->shard) : vk::DMatView{nullptr, 0, 0, 0}, log_rows - 1, pool_dev.data + off[i]);
             a.K = Ks[i];
-            if (W > 1) {
-                // the shard is the LDE on s' H_rows, s' = s w_L^e: x, 1/x, the decomposition pairs (x, -x) follow from the shift; the
-                // selectors and Z_H belong to the TRACE domain H_n (n = L / 2): x^n = s^n (-1)^(natural index), and the natural index
-                // e + W m of every point of this shard has the parity of e
+            if (Wq > 1) {
+                // the rows are the LDE on s' H_rows, s' = s w_L^e = s w_Q^eq: x, 1/x, the decomposition pairs (x, -x) follow from the shift; the
+                // selectors and Z_H belong to the TRACE domain H_n (n = Q / 2): x^n = s^n (-1)^(natural index), and the natural index
+                // eq + Wq m of every point of this range has the parity of eq
                 const unsigned logL = vg::log2_strict_u64(mm.L);
                 const Fp sp = s * rho_of(R, logL);
                 a.coset_shift = sp.v; a.coset_shift_inv = sp.inv().v;
                 Fp sn = s.exp_power_of_2(log_deg[i]);
-                if (R.e & 1u) sn = -sn;
+                if (eq & 1u) sn = -sn;
                 const Fp z = sn - Fp::one();
                 a.zh[0] = a.zh[1] = z.v;
                 a.zh_inv[0] = a.zh_inv[1] = z.inv().v;
@@ -583,6 +600,9 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
     {
         std::vector<std::vector<CommitIn>> cin((size_t)NH);
         if (!big_chips.empty()) {
+            // senders: the Wq ranks that evaluated the quotient (chunk rows [r rows, (r + 1) rows) of every big chip); receivers: all W ranks
+            // (global chunk column g -> rank g mod W, as in every commitment round)
+            auto chunk_rows = [&](size_t i) { return quot_rows(rk[0].main_rs.mats[i].L) / 2; };
             std::vector<Fabric::A2A> plan((size_t)NH);
             std::vector<std::vector<DBuf>> sb((size_t)NH), rb((size_t)NH);
             for (int k = 0; k < NH; k++) {
@@ -593,24 +613,25 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 for (int t = 0; t < W; t++) {
                     size_t sw = 0, rw = 0;
                     for (size_t i : big_chips) {
-                        const uint64_t rows = R.quot_shard[i].height;
+                        const uint64_t rows = chunk_rows(i);
                         for (uint64_t col = 0; col < 10; col++) {
                             const int o = owner_of(10 * (uint64_t)i + col, W);
-                            if (o == t) sw += rows;
-                            if (o == R.rank) rw += rows;
+                            if (o == t && quot_rank(R)) sw += rows;
+                            if (o == R.rank && t < Wq) rw += rows;
                         }
                     }
                     sb[k].emplace_back(&c, sw + 4);
                     rb[k].emplace_back(&c, rw + 4);
                     size_t pos = 0;
-                    for (size_t i : big_chips) {
-                        const DMat& q = R.quot_shard[i];
-                        for (uint64_t col = 0; col < 10; col++)
-                            if (owner_of(10 * (uint64_t)i + col, W) == t) {
-                                VG_HIP_CHECK(hipMemcpyAsync(sb[k][t].data + pos, q.data + col * q.height, q.height * 4, hipMemcpyDeviceToDevice, c.stream));
-                                pos += q.height;
-                            }
-                    }
+                    if (quot_rank(R))
+                        for (size_t i : big_chips) {
+                            const DMat& q = R.quot_shard[i];
+                            for (uint64_t col = 0; col < 10; col++)
+                                if (owner_of(10 * (uint64_t)i + col, W) == t) {
+                                    VG_HIP_CHECK(hipMemcpyAsync(sb[k][t].data + pos, q.data + col * q.height, q.height * 4, hipMemcpyDeviceToDevice, c.stream));
+                                    pos += q.height;
+                                }
+                        }
                     plan[k].send[t] = sb[k][t].data; plan[k].send_words[t] = sw;
                     plan[k].recv[t] = rb[k][t].data; plan[k].recv_words[t] = rw;
                 }
@@ -623,13 +644,13 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 R.quot_own.clear(); R.quot_own.resize(NC);
                 std::vector<size_t> pos((size_t)W, 0);
                 for (size_t i : big_chips) {
-                    const uint64_t rows = R.quot_shard[i].height, n = rows * (uint64_t)W;
+                    const uint64_t rows = chunk_rows(i), n = rows * (uint64_t)Wq;
                     std::vector<uint64_t> own;
                     for (uint64_t col = 0; col < 10; col++) if (owner_of(10 * (uint64_t)i + col, W) == R.rank) own.push_back(col);
                     if (own.empty()) continue;
                     R.quot_own[i] = DMat(&c, n, own.size());
                     for (size_t q = 0; q < own.size(); q++)
-                        for (int src = 0; src < W; src++) {
+                        for (int src = 0; src < Wq; src++) {
                             // sender `src` packed, for this rank, (chip, column) segments in ascending order: its chunk rows [src rows, (src+1) rows)
                             VG_HIP_CHECK(hipMemcpyAsync(R.quot_own[i].data + q * n + (uint64_t)src * rows, rb[k][src].data + pos[src], rows * 4, hipMemcpyDeviceToDevice, c.stream));
                             pos[src] += rows;
