@@ -901,14 +901,62 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
     if (log_max < lb) throw std::invalid_argument("sharded open: nothing to open");
 
     // ---- FRI commit phase (App. B10): a layer of at least min_big elements lives in row ranges
+    // A layer that lives in row ranges needs the ranks' subtree roots on the host (an exchange per layer); from the first layer every
+    // rank holds WHOLE — with one rank: from the first layer — the transcript moves to the device as in the single-GPU prover
+    // (k_fri_challenge observes each root where the tree kernel left it and samples beta for the fold): the dependent chain of the
+    // remaining layers is enqueued without a host round trip, and roots, sponge state and final values come back in one go.
+    const bool multi = W > 1;
     for (auto& O : op) {
         O.cur = std::move(O.ro[log_max]);
         O.ro.erase(log_max);
-        O.cur_sharded = (1ull << log_max) >= min_big;
+        O.cur_sharded = multi && (1ull << log_max) >= min_big;
     }
+    struct DevFri { bool on = false; unsigned count = 0; size_t first_layer = 0; DBuf ch_dev, betas_dev, commits_dev; };
+    std::vector<DevFri> dev((size_t)NH);
     for (unsigned lf = log_max; lf-- > lb;) {
         const uint64_t len = 2ull << lf, half = len >> 1;  // current length 2^(lf+1)
-        const bool sharded = len >= min_big, next_sharded = half >= min_big;
+        const bool sharded = multi && len >= min_big, next_sharded = multi && half >= min_big;
+        if (!sharded) {
+            for (int k = 0; k < NH; k++) {
+                Rank& R = rk[k];
+                DeviceCtx& c = *R.c;
+                c.activate();
+                Opening& O = op[k];
+                DevFri& D = dev[(size_t)k];
+                if (O.cur_sharded) throw std::logic_error("sharded fri: layer state out of step");
+                if (!D.on) {
+                    const unsigned remaining = lf - lb + 1;
+                    std::vector<uint32_t> chw(vk::DEV_CHALLENGER_WORDS, 0);
+                    const Challenger& ch = *R.ch;
+                    for (int i = 0; i < 16; i++) chw[i] = ch.state[i].v;
+                    for (size_t i = 0; i < ch.in.size(); i++) chw[16 + i] = ch.in[i].v;
+                    chw[32] = (uint32_t)ch.in.size();
+                    for (size_t i = 0; i < ch.out.size(); i++) chw[33 + i] = ch.out[i].v;
+                    chw[49] = (uint32_t)ch.out.size();
+                    D.ch_dev = DBuf(&c, chw);
+                    D.betas_dev = DBuf(&c, (size_t)(5 * remaining + 8));
+                    D.commits_dev = DBuf(&c, (size_t)(8 * remaining + 8));
+                    D.first_layer = O.layers.size();
+                    D.on = true;
+                }
+                O.layers.emplace_back();
+                FriLayer& ly = O.layers.back();
+                ly.sharded = false; ly.len = len;
+                ly.t.sharded = false;
+                ly.t.log_total = ly.t.log_local = vg::log2_strict_u64(half);
+                ly.t.tree.build(&c, {vk::DMatView{O.cur.data, half, 10, half}}, false);
+                vk::launch_fri_challenge(c.stream, R.p->pow_pos_.data, D.ch_dev.data, ly.t.tree.layers.back().data, D.betas_dev.data + 5 * D.count, D.commits_dev.data + 8 * D.count);
+                DBuf next(&c, (size_t)(5 * half));
+                auto it = O.ro.find(lf);
+                vk::launch_fri_fold(c.stream, O.cur.data, len, D.betas_dev.data + 5 * D.count, it != O.ro.end() ? it->second.data : nullptr, c.tables, next.data);
+                c.check_launch("fri fold");
+                D.count++;
+                ly.buf = std::move(O.cur);
+                O.cur = std::move(next);
+                O.cur_sharded = false;
+            }
+            continue;
+        }
         // the layer's tree
         for (int k = 0; k < NH; k++) {
             Rank& R = rk[k];
@@ -990,6 +1038,40 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 O.cur = DBuf(&c, full);
             }
         }
+    }
+    for (int k = 0; k < NH; k++) {
+        DevFri& D = dev[(size_t)k];
+        if (!D.on) continue;
+        Rank& R = rk[k];
+        DeviceCtx& c = *R.c;
+        c.activate();
+        Opening& O = op[k];
+        std::vector<uint32_t> chw(vk::DEV_CHALLENGER_WORDS), commits((size_t)(8 * D.count + 8));
+        {   // sponge state and roots: two copies into one pinned area, one synchronisation
+            const size_t n0 = chw.size(), n1 = 8 * (size_t)D.count;
+            std::lock_guard<std::recursive_mutex> lk(c.host_mu);
+            uint32_t* pin = (uint32_t*)c.pinned_buffer((n0 + n1 + 8) * 4);
+            VG_HIP_CHECK(hipMemcpyAsync(pin, D.ch_dev.data, n0 * 4, hipMemcpyDeviceToHost, c.stream));
+            if (n1) VG_HIP_CHECK(hipMemcpyAsync(pin + n0, D.commits_dev.data, n1 * 4, hipMemcpyDeviceToHost, c.stream));
+            c.sync();
+            memcpy(chw.data(), pin, n0 * 4);
+            memcpy(commits.data(), pin + n0, n1 * 4);
+        }
+        Challenger& ch = *R.ch;
+        for (int i = 0; i < 16; i++) ch.state[i] = Fp::raw(chw[i]);
+        ch.in.clear();
+        for (uint32_t i = 0; i < chw[32]; i++) ch.in.push_back(Fp::raw(chw[16 + i]));
+        ch.out.clear();
+        for (uint32_t i = 0; i < chw[49]; i++) ch.out.push_back(Fp::raw(chw[33 + i]));
+        for (unsigned i = 0; i < D.count; i++) {
+            std::array<uint32_t, 8> root;
+            memcpy(root.data(), commits.data() + 8 * i, 32);
+            FriLayer& ly = O.layers[D.first_layer + i];
+            memcpy(ly.t.root, root.data(), 32);
+            memcpy(ly.t.tree.root, root.data(), 32);
+            O.commits.push_back(root);
+        }
+        D = DevFri();
     }
     // `cur` now holds 2^lb values that must all be equal (a constant polynomial)
     for (int k = 0; k < NH; k++) {
