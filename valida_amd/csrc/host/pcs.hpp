@@ -7,6 +7,7 @@
 // interleaved with the host transcript.
 #pragma once
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include "runtime.hpp"
 
@@ -37,17 +38,23 @@ struct DeviceTree {
 
     // mats: views in commit order.  Enqueues all kernels; root is read back (sync) at the end.
     // fetch_root = false leaves the root on the device only (layers.back()): the FRI commit phase consumes it there.
-    void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats, bool fetch_root = true) {
+    // before_injection: called once, just before the first kernel that reads a matrix SHORTER than the tallest ones is enqueued (a layer
+    // that injects rows) — commit_batches joins the stream that extends those matrices there, so the leaves and the first layers of the
+    // tree (Keccak: integer-VALU work) run beside the remaining LDEs (half memory phases) instead of after them.
+    void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats, bool fetch_root = true, const std::function<void()>* before_injection = nullptr) {
+        before_injection_ = before_injection;
         std::vector<ColMat> cms(mats.size());
         for (size_t i = 0; i < mats.size(); i++) {
             cms[i].height = mats[i].height;
             for (uint64_t col = 0; col < mats[i].width; col++) cms[i].cols.push_back(mats[i].data + col * mats[i].stride);
         }
         build_impl(c, cms, mats.size() == 1 ? &mats[0] : nullptr, fetch_root);
+        before_injection_ = nullptr;
     }
     void build_cols(DeviceCtx* c, const std::vector<ColMat>& mats) { build_impl(c, mats, nullptr, true); }
 
   private:
+    const std::function<void()>* before_injection_ = nullptr;
     // single_view: the tree is over ONE strided matrix (every FRI layer tree): no pointer table, columns are base + k * stride
     void build_impl(DeviceCtx* c, const std::vector<ColMat>& cms, const vk::DMatView* single_view, bool fetch_root) {
         ctx = c;
@@ -93,6 +100,7 @@ struct DeviceTree {
             layers.emplace_back(c, (size_t)len * 8);
             layer_len.push_back(len);
             const Group* inj = (gi < groups.size() && groups[gi].height == len) ? &groups[gi] : nullptr;
+            if (inj && before_injection_) { (*before_injection_)(); before_injection_ = nullptr; }
             // Layers of more than TOP_FIRST_LEN parents are their own launches (spread over the whole GPU); the rest of the tree is one
             // single-workgroup launch.  256, not the 1024 a workgroup could take: inside one workgroup a 1024-parent layer puts four
             // waves on each SIMD of ONE CU and costs 27 us (512 parents: 15 us), as a launch of its own across the CUs 9 + 2 us.
@@ -180,15 +188,32 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
                                                   const FriParams& fri) {
     auto pd = std::make_unique<ProverData>();
     Fp g = Fp::from_canonical(vg::GENERATOR);
-    Section lde_section(c);  // per-matrix LDE pipelines are independent: small ones run on the aux streams
-    for (size_t i = 0; i < mats.size(); i++) {
-        Fp shift = coset_shifts ? g * (*coset_shifts)[i].inv() : g;
-        pd->ldes.push_back(coset_lde(c, c->stream_for(i, mats[i].mat->height), mats[i], fri.log_blowup, shift));
-    }
-    lde_section.join();
+    // Per-matrix LDE pipelines are independent.  The tallest matrices are extended first, on the main stream; everything else goes to the
+    // auxiliary stream and is only joined when the tree reaches the first layer that injects shorter rows: the leaf hashes and the first
+    // compression layers (pure integer-VALU work) overlap the remaining LDEs.  VGPU_COMMIT_OVERLAP=0: all LDEs first, then the tree (A/B).
+    static const bool overlap = [] { const char* e = getenv("VGPU_COMMIT_OVERLAP"); return !(e && e[0] == '0'); }();
+    uint64_t maxh = 0;
+    for (auto& m : mats) maxh = std::max<uint64_t>(maxh, m.mat->height);
+    Section lde_section(c);
+    pd->ldes.resize(mats.size());
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t i = 0; i < mats.size(); i++) {
+            const bool tallest = mats[i].mat->height == maxh;
+            if (tallest != (pass == 0)) continue;
+            Fp shift = coset_shifts ? g * (*coset_shifts)[i].inv() : g;
+            hipStream_t st = overlap ? (tallest ? c->stream : c->aux[0]) : c->stream_for(i, mats[i].mat->height);
+            pd->ldes[i] = coset_lde(c, st, mats[i], fri.log_blowup, shift);
+        }
     std::vector<vk::DMatView> views;
     for (auto& l : pd->ldes) views.push_back(l.view());
-    pd->tree.build(c, views);
+    if (overlap) {
+        const std::function<void()> join = [&] { lde_section.join(); };
+        pd->tree.build(c, views, true, &join);
+        lde_section.join();  // a round of one height never injects
+    } else {
+        lde_section.join();
+        pd->tree.build(c, views);
+    }
     return pd;
 }
 
