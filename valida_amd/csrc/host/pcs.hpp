@@ -190,8 +190,11 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
     Fp g = Fp::from_canonical(vg::GENERATOR);
     // Per-matrix LDE pipelines are independent.  The tallest matrices are extended first, on the main stream; everything else goes to the
     // auxiliary stream and is only joined when the tree reaches the first layer that injects shorter rows: the leaf hashes and the first
-    // compression layers (pure integer-VALU work) overlap the remaining LDEs.  VGPU_COMMIT_OVERLAP=0: all LDEs first, then the tree (A/B).
-    static const bool overlap = [] { const char* e = getenv("VGPU_COMMIT_OVERLAP"); return !(e && e[0] == '0'); }();
+    // compression layers (pure integer-VALU work) overlap the remaining LDEs.  MEASURED (profiles/r03_ab_commit_overlap.json, one session):
+    // no gain — a lone proof 21.99 vs 22.03 ms (the overlapped kernels just stretch: both sides are issue-bound), three in flight
+    // 56.5 / 57.6 vs 57.8 proofs/s — so it stays OFF (VGPU_COMMIT_OVERLAP=1 turns it on); the default keeps the small matrices on the
+    // auxiliary stream and joins before the tree.
+    static const bool overlap = [] { const char* e = getenv("VGPU_COMMIT_OVERLAP"); return e && e[0] == '1'; }();
     uint64_t maxh = 0;
     for (auto& m : mats) maxh = std::max<uint64_t>(maxh, m.mat->height);
     Section lde_section(c);
