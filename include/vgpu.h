@@ -362,20 +362,28 @@ typedef struct vgpu_cpu_op {
 } vgpu_cpu_op_t;
 typedef struct vgpu_mem_op { uint32_t clk, addr, value, is_write; } vgpu_mem_op_t;   /* memory Operation::{Read,Write}(addr, value) at clk */
 typedef struct vgpu_alu_op { uint32_t opcode, a, b, c; } vgpu_alu_op_t;              /* e.g. Operation::Add32(a, b, c): a = result */
+typedef struct vgpu_out_op { uint32_t clk, byte; } vgpu_out_op_t;                    /* OutputChip::values entry (clk, byte) (output/src/lib.rs:21-23) */
 typedef struct vgpu_oplog_desc {
     const vgpu_cpu_op_t* cpu; uint64_t n_cpu;
     const vgpu_mem_op_t* mem; uint64_t n_mem;
     const vgpu_alu_op_t* alu[4]; uint64_t n_alu[4];   /* add, sub, lt, bitwise */
     const uint32_t* static_cells; uint64_t n_static;  /* MemoryChip::static_data as (addr, value) pairs, ascending address (may be null / 0) */
     uint32_t rom_len;                                 /* ProgramROM length (program chip rows before padding) */
+    /* the five remaining chips, each as the reference's chip holds it after Machine::run: Mul32Chip / Div32Chip / Shift32Chip / Com32Chip
+     * ::operations (opcode = the Operation variant: MUL32 | MULHS32 | MULHU32, DIV32 | SDIV32, SHL32 | SHR32 | SRA32, NE32 | EQ32 — a shift
+     * instruction also leaves a Mul32 / Div32 / SDiv32 with the power of two in the mul / div log, alu_u32/src/shift/mod.rs:207-212) and
+     * OutputChip::values.  All may be null / 0. */
+    const vgpu_alu_op_t* alu2[4]; uint64_t n_alu2[4];  /* mul, div, shift, com */
+    const vgpu_out_op_t* output; uint64_t n_output;
 } vgpu_oplog_desc_t;
 typedef struct vgpu_oplog vgpu_oplog_t;
 int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_oplog_t** out);
 void vgpu_oplog_free(vgpu_oplog_t* log);
-/* Any chip of the BasicMachine: cpu, program, mem, add, sub, lt, bitwise, range from their logs; static_data from the
- * initialised cells; mul, div, shift, com, output as the padding-only trace of a chip that received no operation (the log
- * format carries none for them — a program that uses them generates those traces on the host and vgpu_trace_upload's them).
- * The returned trace is already in the prover's working layout (no ingest pass). */
+/* Any chip of the BasicMachine — all fourteen Chip::generate_trace as kernels: cpu, program, mem, add, sub, lt, bitwise, mul, div, shift,
+ * com, output from their logs (the last five exactly as incomplete as the reference fills them: div / com rows carry only the opcode
+ * flag, mul leaves r / s zero, output never writes counter / counter_mult / opcode), range from the result words of the instructions
+ * that range-check them (add, sub, mul*, div*: the cpu log's bus operations and the cycle's memory write), static_data from the
+ * initialised cells.  The returned trace is already in the prover's working layout (no ingest pass). */
 int32_t vgpu_generate_trace(vgpu_prover_t* p, const vgpu_oplog_t* log, uint32_t chip, vgpu_trace_t** out);
 void vgpu_trace_shape(const vgpu_trace_t* t, uint64_t* height, uint64_t* width);
 /* canonical row-major copy of a device trace (what the reference's generate_trace would have returned) */

@@ -326,7 +326,7 @@ def test_interpreted_air_path_matches_oracle(machine, rc, make):
 
 # ---- device trace generation: Chip::generate_trace as kernels, from the VM's operation logs -----
 @pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(100), lambda: va.Workload.fib(582), lambda: va.Workload.alu(1),
-                                  lambda: va.Workload.named("static_data")])
+                                  lambda: va.Workload.named("static_data"), lambda: va.Workload.named("mixed_ops:40"), lambda: va.Workload.named("mixed_ops:700")])
 def test_generated_traces_match_host_generate_trace(prover, make):
     w = make()
     log = prover.upload_oplog(w.oplog())
@@ -348,6 +348,48 @@ def test_proof_from_generated_traces_is_the_same_proof(prover, rc):
     a = prover.prove(dmain, dprep)
     ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc)
     assert first_mismatch(a.words, ref.words) is None
+
+
+def test_all_fourteen_generators_feed_a_proof_that_is_the_oracles(prover, rc):
+    """mixed_ops keeps EVERY chip busy (mul / mulhs / mulhu, div / sdiv, shl / shr / sra, ne / eq, write beside add, sub, xor, lt): all fourteen
+    traces generated on the device from the operation logs, and the proof of them word for word the oracle's proof of the host-generated traces.
+    (The reference's mul / div / shift / com chips are stubs, SURVEY.md 0.6: such a proof is well-formed but no verifier accepts it — in the
+    reference either; what is pinned here is that the device reproduces the reference's generate_trace for them, incomplete as it is.)"""
+    w = va.Workload.named("mixed_ops:300")
+    mt, prep = w.main_traces(), w.preprocessed()
+    assert [m.shape[0] for m in mt][5:8] == [2048, 2048, 2048] and mt[9].shape[0] == 1024 and mt[11].shape[0] == 512  # mul, div, shift, com, output all busy
+    log = prover.upload_oplog(w.oplog())
+    dmain = [prover.generate_trace(log, i) for i in range(va.NUM_CHIPS)]
+    a = prover.prove(dmain, [(c, prover.upload(m)) for c, m in prep])
+    ref = po.prove_basic(mt, prep[0][1], prep[1][1], rc)
+    assert first_mismatch(a.words, ref.words) is None
+    assert po.verify_basic(prep[0][1], prep[1][1], a.words, rc) is not None  # stub chips: rejected, as the reference's own verifier would
+
+
+def test_operation_logs_are_validated_at_upload(prover):
+    import ctypes
+
+    w = va.Workload.named("mixed_ops:8")
+    d = w.oplog()
+    n = int(d.n_alu2[2])
+    ops = np.ctypeslib.as_array(ctypes.cast(d.alu2[2], ctypes.POINTER(ctypes.c_uint32)), shape=(n, 4)).copy()
+    bad = va.OplogDesc()
+    ctypes.memmove(ctypes.byref(bad), ctypes.byref(d), ctypes.sizeof(d))
+    ops[3, 0] = 100  # an ADD32 in the shift chip's log
+    bad.alu2[2] = ops.ctypes.data
+    with pytest.raises(va.VgpuError, match="not an operation of that chip"):
+        prover.upload_oplog(bad)
+    ops[3, 0], ops[3, 3] = 105, 40  # SHL32 by 40
+    with pytest.raises(va.VgpuError, match="shift amount"):
+        prover.upload_oplog(bad)
+    cpu = np.ctypeslib.as_array(ctypes.cast(d.cpu, ctypes.POINTER(ctypes.c_uint32)), shape=(int(d.n_cpu), 12)).copy()
+    bus = int(np.nonzero(cpu[:, 8] == 7)[0][0])  # first bus operation
+    cpu[bus, 2] = 9  # READ_ADVICE: no chip of this machine receives it
+    bad2 = va.OplogDesc()
+    ctypes.memmove(ctypes.byref(bad2), ctypes.byref(d), ctypes.sizeof(d))
+    bad2.cpu = cpu.ctypes.data
+    with pytest.raises(va.VgpuError, match="no bus operation"):
+        prover.upload_oplog(bad2)
 
 
 def test_generated_traces_full_size(prover, rc):

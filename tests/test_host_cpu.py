@@ -214,6 +214,50 @@ def test_workload_oplog_shape():
     assert cpu[-1, 8] == 9  # last record is STOP
 
 
+def test_the_five_remaining_chips_generate_trace_restatement():
+    """mul / div / shift / com / output rows of the workload VM against rows written out by hand from the reference's rules
+    (alu_u32/src/mul/mod.rs:38-66,125-132; div/mod.rs:84-103; shift/mod.rs:143-162; com/mod.rs:87-103; output/src/lib.rs:37-100)."""
+    w = va.Workload.named("mixed_ops:3")
+    mt = w.main_traces()
+    d = w.oplog()
+    assert [int(x) for x in d.n_alu2] == [18, 12, 12, 6] and int(d.n_output) == 4  # per iteration: 4 mul + 2 shl | 2 div + shr + sra | 4 shifts | ne, eq | 1 write (+ 1 final)
+    x, y = 0x12345678, 0x9ABCDEF1
+    be = lambda v: [(v >> 24) & 255, (v >> 16) & 255, (v >> 8) & 255, v & 255]
+    mul = mt[5]
+    assert mul.shape == (1024, 18) and mul[:, 17].tolist() == list(range(1, 1025))  # counter = row + 1 on every row, 1024 rows at least
+    assert mul[0].tolist() == be(x) + be(y) + be((x * y) & 0xFFFFFFFF) + [0, 0, 1, 0, 0, 1]            # Mul32: inputs, output, r = s = 0, is_mul
+    assert mul[1].tolist() == be(x) + be(y) + be((x * y) >> 32) + [0, 0, 0, 0, 1, 2]                    # Mulhu32
+    assert mul[2].tolist() == be(y) + be(x) + be((x * y) >> 32) + [0, 0, 0, 1, 0, 3]                    # Mulhs32: zero-extended operands (core.rs:146-158)
+    assert mul[4].tolist() == be(x) + be(32) + be((x << 5) & 0xFFFFFFFF) + [0, 0, 1, 0, 0, 5]          # the Mul32 a SHL leaves: times 2^5
+    assert mul[18:, :17].max() == 0
+    div = mt[6]
+    assert div.shape == (16, 14) and div[:12, :12].max() == 0                                            # flags only ("TODO: Fill in other columns")
+    assert div[:4, 12:].tolist() == [[1, 0], [0, 1], [1, 0], [0, 1]]                                     # div, sdiv, Div32 of SHR, SDiv32 of SRA
+    sh = mt[7]
+    assert sh.shape == (16, 28)
+    assert sh[0].tolist() == be(x) + be(5) + be((x << 5) & 0xFFFFFFFF) + [1, 0, 1, 0, 0, 0, 0, 0] + [5] + be(32) + [1, 0, 0]   # bits of 5, temp_1 = 5 (the exponent), 2^5
+    sra = ((y - (1 << 32)) >> 5) & 0xFFFFFFFF
+    assert sh[2].tolist() == be(y) + be(5) + be(sra) + [1, 0, 1, 0, 0, 0, 0, 0] + [5] + be(32) + [0, 1, 0]                      # SRA is logged as Shr32 (shift/mod.rs:325-328)
+    com = mt[9]
+    assert com.shape == (8, 14) and com[:6, :12].max() == 0 and com[:2, 12:].tolist() == [[1, 0], [0, 1]]
+    out = mt[11]
+    clk = [int(v) for v in np.ctypeslib.as_array(ctypes.cast(d.output, ctypes.POINTER(ctypes.c_uint32)), shape=(4, 2))[:, 0]]
+    rows = []
+    for i in range(3):
+        num = (clk[i + 1] - clk[i]) // 4 + 1
+        cl = [clk[i]] + [clk[i] + 4 * (k + 1) for k in range(1, num)]
+        for k in range(num):
+            rows.append([cl[k], 0, 0, (cl[k + 1] if k + 1 < num else clk[i + 1]) - cl[k]])
+        rows[-num][1:3] = [None, 1]
+    assert out.shape[1] == 7 and out[:, 4:].max() == 0                                                   # counter, counter_mult, opcode: never written
+    assert out.shape[0] == 1 << (len(rows)).bit_length()
+    for r, want in zip(out[: len(rows)], rows):
+        assert int(r[0]) == want[0] and int(r[3]) == want[3] % va.P and int(r[2]) == want[2] and (want[1] is None or int(r[1]) == 0)
+    assert out[len(rows), :3].tolist()[0] == clk[3] and out[len(rows), 2] == 1 and out[len(rows) + 1:].max() == 0
+    # range checks come from the INSTRUCTIONS add, sub, mul*, div* (not from the Mul32 / Div32 a shift leaves): 4 bytes each
+    assert int(mt[12][:, 0].sum()) == 4 * 3 * (4 + 2 + 3 + 1)  # per iteration: mul, mulhu, mulhs, muli | div, sdiv | add, add (y), add (i) | sub
+
+
 def test_ffi_captured_machine_equals_in_tree_machine():
     # every chip's eval forwarded call by call through vgpu_air_* compiles to the same program as the in-tree capture,
     # and evaluates to the same constraint values on random rows

@@ -113,6 +113,8 @@ class OplogDesc(ctypes.Structure):  # vgpu_oplog_desc_t
         ("alu", ctypes.c_void_p * 4), ("n_alu", ctypes.c_uint64 * 4),
         ("static_cells", ctypes.c_void_p), ("n_static", ctypes.c_uint64),
         ("rom_len", ctypes.c_uint32),
+        ("alu2", ctypes.c_void_p * 4), ("n_alu2", ctypes.c_uint64 * 4),  # mul, div, shift, com
+        ("output", ctypes.c_void_p), ("n_output", ctypes.c_uint64),      # OutputChip::values as (clk, byte)
     ]
 
 
@@ -141,7 +143,7 @@ def decode_interaction_words(w):
     return out
 
 
-GENERATED_CHIPS = tuple(range(14))  # every BasicMachine chip has a device trace generator (mul, div, shift, com, output: no-operation traces)
+GENERATED_CHIPS = tuple(range(14))  # every BasicMachine chip has a log-driven device trace generator
 
 
 class Workload:
@@ -168,7 +170,8 @@ class Workload:
 
     @classmethod
     def named(cls, name):
-        """One of the reference's other pinned prover programs: left_imm_ops, signed_inequality, loadfp."""
+        """One of the reference's other pinned prover programs: left_imm_ops, signed_inequality, loadfp, static_data; or "mixed_ops[:iters]", the
+        synthetic program that keeps every chip busy (mul, div, shift, com, output included)."""
         h = ctypes.c_void_p()
         _check(lib().vgpu_workload_named(name.encode(), ctypes.byref(h)))
         return cls(h)

@@ -45,10 +45,12 @@ struct vgpu_comm { std::shared_ptr<Prover> owner; std::unique_ptr<Comm> comm; };
 static_assert(sizeof(vgpu_cpu_op_t) == sizeof(vk::TgCpuOp) && sizeof(vgpu_mem_op_t) == sizeof(vk::TgMemOp) && sizeof(vgpu_alu_op_t) == sizeof(vk::TgAluOp),
               "C ABI log records and their device images must match");
 static_assert((int)VGPU_CPU_LOADFP == (int)vk::TG_CPU_LOADFP, "cpu op kinds");
+static_assert(sizeof(vgpu_out_op_t) == sizeof(vk::TgOutOp), "C ABI log records and their device images must match");
 struct vgpu_workload {
     std::vector<vgpu_cpu_op_t> log_cpu;
     std::vector<vgpu_mem_op_t> log_mem;
-    std::vector<vgpu_alu_op_t> log_alu[4];
+    std::vector<vgpu_alu_op_t> log_alu[4], log_alu2[4];
+    std::vector<vgpu_out_op_t> log_output;
     std::vector<uint32_t> log_static;  // (addr, value) pairs, ascending address
     std::unique_ptr<vwork::BasicVm> vm;
     std::vector<vwork::RowMajor> main;
@@ -362,6 +364,24 @@ int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_o
         for (int k = 0; k < 4; k++) { h.alu[k] = (const vk::TgAluOp*)log->alu[k]; h.n_alu[k] = log->n_alu[k]; }
         h.static_cells = log->static_cells; h.n_static = log->n_static;
         h.rom_len = log->rom_len;
+        for (int k = 0; k < 4; k++) { h.alu2[k] = (const vk::TgAluOp*)log->alu2[k]; h.n_alu2[k] = log->n_alu2[k]; if (h.n_alu2[k] && !h.alu2[k]) throw std::invalid_argument("oplog: null ALU log with a nonzero length"); }
+        h.output = (const vk::TgOutOp*)log->output; h.n_output = log->n_output;
+        if (h.n_output && !h.output) throw std::invalid_argument("oplog: null output tape with a nonzero length");
+        {   // every logged operation must be a variant of its chip's Operation enum
+            using namespace vchips;
+            auto check = [&](int k, std::initializer_list<uint32_t> ok, const char* chip) {
+                for (uint64_t i = 0; i < h.n_alu2[k]; i++) {
+                    bool good = false;
+                    for (uint32_t o : ok) good |= h.alu2[k][i].opcode == o;
+                    if (!good) throw std::invalid_argument(std::string("oplog: ") + chip + " log entry " + std::to_string(i) + " has an opcode that is not an operation of that chip");
+                    if (k == 2 && h.alu2[k][i].c >= 32) throw std::invalid_argument("oplog: shift log entry " + std::to_string(i) + ": shift amount >= 32");
+                }
+            };
+            check(0, {OP_MUL32, OP_MULHS32, OP_MULHU32}, "mul");
+            check(1, {OP_DIV32, OP_SDIV32}, "div");
+            check(2, {OP_SHL32, OP_SHR32, OP_SRA32}, "shift");
+            check(3, {OP_NE32, OP_EQ32}, "com");
+        }
         for (uint64_t i = 1; i < h.n_static; i++)
             if (log->static_cells[2 * i] <= log->static_cells[2 * i - 2]) throw std::invalid_argument("oplog: static cells must be in ascending address order");
         if (!h.n_cpu || !log->cpu) throw std::invalid_argument("oplog: empty cpu log");
@@ -373,17 +393,13 @@ int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_o
                 throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + " is malformed");
             // the program chip's multiplicity histogram indexes the ROM by pc
             if (h.rom_len && o.pc >= h.rom_len) throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + ": pc beyond the ROM length");
-            // Bus operations must target a chip whose device generator is fed by these logs (add, sub, lt, bitwise): the log format
-            // carries no mul / div / shift / com / output operations, and a proof built from their padding-only traces would leave
-            // the general bus unbalanced (an invalid proof with no prover-side error).
+            // Bus operations must target a chip of the BasicMachine (every one of them has a log-driven generator now); anything else —
+            // an advice read, an opcode of another machine — has no chip to receive it here
             if (o.kind == VGPU_CPU_BUS || o.kind == VGPU_CPU_BUS_LEFT_IMM) {
                 using namespace vchips;
                 const uint32_t op = o.opcode;
-                const bool fed = op == OP_ADD32 || op == OP_SUB32 || op == OP_LT32 || op == OP_LTE32 || op == OP_SLT32 || op == OP_SLE32 || op == OP_AND32 ||
-                                 op == OP_OR32 || op == OP_XOR32;
-                if (!fed)
-                    throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + ": opcode " + std::to_string(op) +
-                                                " belongs to a chip without a log-driven device trace generator (generate that chip's trace on the host and upload it)");
+                const bool known = (op >= OP_ADD32 && op <= OP_SLE32) || op == OP_WRITE;
+                if (!known) throw std::invalid_argument("oplog: cpu record " + std::to_string(i) + ": opcode " + std::to_string(op) + " is no bus operation of the BasicMachine's chips");
             }
         }
         // the memory chip's stable by-address radix sort reproduces the reference's (addr, clk) order only for clk-ordered logs
@@ -1001,6 +1017,12 @@ static void fill_logs(vgpu_workload& w) {
         w.log_alu[k].resize(src[k]->size());
         for (size_t i = 0; i < src[k]->size(); i++) { const auto& a = (*src[k])[i]; w.log_alu[k][i] = {a.opcode, vwork::u32_of(a.a), vwork::u32_of(a.b), vwork::u32_of(a.c)}; }
     }
+    const std::vector<vwork::AluOp>* src2[4] = {&vm.mul_ops, &vm.div_ops, &vm.shift_ops, &vm.com_ops};
+    for (int k = 0; k < 4; k++) {
+        w.log_alu2[k].resize(src2[k]->size());
+        for (size_t i = 0; i < src2[k]->size(); i++) { const auto& a = (*src2[k])[i]; w.log_alu2[k][i] = {a.opcode, vwork::u32_of(a.a), vwork::u32_of(a.b), vwork::u32_of(a.c)}; }
+    }
+    for (auto& v : vm.output_values) w.log_output.push_back({v.first, v.second});
 }
 int32_t vgpu_workload_named(const char* name, vgpu_workload_t** out) {
     VG_TRY({
@@ -1011,6 +1033,7 @@ int32_t vgpu_workload_named(const char* name, vgpu_workload_t** out) {
         else if (n == "signed_inequality") prog = vwork::signed_inequality_program();
         else if (n == "loadfp") prog = vwork::loadfp_program();
         else if (n == "static_data") prog = vwork::static_data_program();
+        else if (n.rfind("mixed_ops", 0) == 0) prog = vwork::mixed_ops_program(n.size() > 10 ? (uint32_t)std::stoul(n.substr(10)) : 40u);  // "mixed_ops" or "mixed_ops:<iters>"
         else throw std::invalid_argument("unknown program: " + n);
         auto w = std::make_unique<vgpu_workload>();
         w->vm.reset(new vwork::BasicVm(prog));
@@ -1040,6 +1063,8 @@ void vgpu_workload_oplog(const vgpu_workload_t* w, vgpu_oplog_desc_t* out) {
     for (int k = 0; k < 4; k++) { out->alu[k] = w->log_alu[k].data(); out->n_alu[k] = w->log_alu[k].size(); }
     out->static_cells = w->log_static.data(); out->n_static = w->log_static.size() / 2;
     out->rom_len = (uint32_t)w->vm->rom.size();
+    for (int k = 0; k < 4; k++) { out->alu2[k] = w->log_alu2[k].data(); out->n_alu2[k] = w->log_alu2[k].size(); }
+    out->output = w->log_output.data(); out->n_output = w->log_output.size();
 }
 void vgpu_workload_free(vgpu_workload_t* w) { delete w; }
 void vgpu_workload_stats(const vgpu_workload_t* w, uint64_t out[8]) {

@@ -103,14 +103,30 @@ std::unique_ptr<DeviceOplog> Prover::upload_oplog(const HostOplog& log) {
     d->rom_len = log.rom_len;
     d->n_static = log.n_static;
     d->static_cells = upload_bytes(c, log.static_cells, log.n_static * 8);
+    for (int k = 0; k < 4; k++) { d->n_alu2[k] = log.n_alu2[k]; d->alu2[k] = upload_bytes(c, log.alu2[k], log.n_alu2[k] * sizeof(vk::TgAluOp)); }
+    d->n_output = log.n_output;
+    d->output = upload_bytes(c, log.output, log.n_output * sizeof(vk::TgOutOp));
+    // first row of every window of the output tape (output/src/lib.rs:41-47: (clk_2 - clk_1) / table_len + 1 rows per window, one final
+    // row): a running sum over a handful of entries, done here where the log is in host memory; the rows themselves are filled on the device
+    std::vector<uint32_t> row0(log.n_output ? log.n_output : 1, 0);
+    uint64_t rows = 0;
+    for (uint64_t w = 0; w < log.n_output; w++) {
+        row0[w] = (uint32_t)rows;
+        if (w + 1 < log.n_output) {
+            if (log.output[w + 1].clk < log.output[w].clk) throw std::invalid_argument("oplog: output tape entry " + std::to_string(w + 1) + " is out of clock order");
+            rows += (uint64_t)((log.output[w + 1].clk - log.output[w].clk) / (uint32_t)log.n_output) + 1;
+        } else rows += 1;
+        if (rows > (1ull << 27)) throw std::invalid_argument("oplog: the output chip's trace would exceed 2^27 rows");
+    }
+    d->output_rows = rows;
+    d->output_row0 = upload_bytes(c, row0.data(), row0.size() * 4);
     c.sync();
     return d;
 }
 
 bool Prover::can_generate(int chip) {
     using namespace vchips;
-    // cpu, program, mem, add, sub, lt, bitwise, range from their logs; mul, div, shift, com, output as the padding-only traces of
-    // chips that received no operation (the log format carries none for them), static_data from the initialised cells
+    // every chip of the BasicMachine: from its log (static_data from the initialised cells, range from the range-checked result words)
     return chip >= 0 && chip < NUM_CHIPS;
 }
 
@@ -141,14 +157,23 @@ std::unique_ptr<DeviceTrace> Prover::generate_trace(const DeviceOplog& log, int 
         t->nat = DMat(&c, t->height, t->width);
         DBuf counts(&c, std::max<size_t>(256, log.rom_len) + 4);
         if (chip == CHIP_RANGE)
-            VG_HIP_CHECK(vk::launch_tracegen_range(c.stream, (const vk::TgAluOp*)log.alu[0].data, log.n_alu[0], (const vk::TgAluOp*)log.alu[1].data, log.n_alu[1], counts.data,
-                                                   t->nat.view()));
+            VG_HIP_CHECK(vk::launch_tracegen_range(c.stream, (const vk::TgCpuOp*)log.cpu.data, log.n_cpu, (const vk::TgMemOp*)log.mem.data, log.n_mem, counts.data, t->nat.view()));
         else
             VG_HIP_CHECK(vk::launch_tracegen_program(c.stream, (const vk::TgCpuOp*)log.cpu.data, log.n_cpu, next_pow2(log.n_cpu), log.rom_len, counts.data, t->nat.view()));
-    } else if (chip == CHIP_MUL || chip == CHIP_DIV || chip == CHIP_SHIFT || chip == CHIP_COM || chip == CHIP_OUTPUT || chip == CHIP_STATIC_DATA) {
-        t->height = chip == CHIP_MUL ? 1024 : chip == CHIP_STATIC_DATA ? next_pow2(log.n_static) : 1;
+    } else if (chip == CHIP_MUL || chip == CHIP_DIV || chip == CHIP_SHIFT || chip == CHIP_COM) {
+        const int k = chip == CHIP_MUL ? 0 : chip == CHIP_DIV ? 1 : chip == CHIP_SHIFT ? 2 : 3;
+        t->height = next_pow2(log.n_alu2[k]);
+        if (chip == CHIP_MUL && t->height < 1024) t->height = 1024;  // MIN_LENGTH, for the range-check counter (alu_u32/src/mul/mod.rs:39-42)
         t->nat = DMat(&c, t->height, t->width);
-        vk::launch_tracegen_idle(c.stream, chip == CHIP_MUL ? 1 : chip == CHIP_STATIC_DATA ? 2 : 0, log.static_cells.data, log.n_static, t->nat.view());
+        vk::launch_tracegen_alu2(c.stream, chip, (const vk::TgAluOp*)log.alu2[k].data, log.n_alu2[k], t->nat.view());
+    } else if (chip == CHIP_OUTPUT) {
+        t->height = next_pow2(log.output_rows);
+        t->nat = DMat(&c, t->height, t->width);
+        vk::launch_tracegen_output(c.stream, (const vk::TgOutOp*)log.output.data, log.output_row0.data, log.n_output, log.output_rows, t->nat.view());
+    } else if (chip == CHIP_STATIC_DATA) {
+        t->height = next_pow2(log.n_static);
+        t->nat = DMat(&c, t->height, t->width);
+        vk::launch_tracegen_idle(c.stream, 2, log.static_cells.data, log.n_static, t->nat.view());
     } else {
         const int k = chip == CHIP_ADD ? 0 : chip == CHIP_SUB ? 1 : chip == CHIP_LT ? 2 : 3;
         t->height = next_pow2(log.n_alu[k]);

@@ -36,10 +36,13 @@ struct HostOplog {
     const vk::TgAluOp* alu[4] = {nullptr, nullptr, nullptr, nullptr}; uint64_t n_alu[4] = {0, 0, 0, 0};  // add, sub, lt, bitwise
     const uint32_t* static_cells = nullptr; uint64_t n_static = 0;  // MemoryChip::static_data: (addr, value) pairs, ascending address
     uint32_t rom_len = 0;                                           // ProgramROM length (height of the program chip's trace before padding)
+    const vk::TgAluOp* alu2[4] = {nullptr, nullptr, nullptr, nullptr}; uint64_t n_alu2[4] = {0, 0, 0, 0};  // mul, div, shift, com
+    const vk::TgOutOp* output = nullptr; uint64_t n_output = 0;     // OutputChip::values
 };
 struct DeviceOplog {
-    DBuf cpu, mem, alu[4], static_cells;
-    uint64_t n_cpu = 0, n_mem = 0, n_alu[4] = {0, 0, 0, 0}, n_static = 0;
+    DBuf cpu, mem, alu[4], static_cells, alu2[4], output, output_row0;
+    uint64_t n_cpu = 0, n_mem = 0, n_alu[4] = {0, 0, 0, 0}, n_static = 0, n_alu2[4] = {0, 0, 0, 0}, n_output = 0;
+    uint64_t output_rows = 0;  // rows of the output chip's trace before padding (windows' rows + the final row)
     uint32_t rom_len = 0;
 };
 

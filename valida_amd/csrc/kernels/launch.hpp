@@ -87,6 +87,7 @@ void launch_check_constraints(hipStream_t st, const QuotientArgs& a, unsigned lo
 struct TgCpuOp { uint32_t pc, fp, opcode; int32_t operands[5]; uint32_t kind, has_imm, imm, mem_first; };
 struct TgMemOp { uint32_t clk, addr, value, is_write; };
 struct TgAluOp { uint32_t opcode, a, b, c; };  // a = result, b / c = inputs, as u32 values of the big-endian Words
+struct TgOutOp { uint32_t clk, byte; };          // OutputChip::values entry
 enum { TG_CPU_STORE32 = 0, TG_CPU_LOAD32, TG_CPU_JAL, TG_CPU_JALV, TG_CPU_BEQ, TG_CPU_BNE, TG_CPU_IMM32, TG_CPU_BUS, TG_CPU_BUS_LEFT_IMM, TG_CPU_STOP,
        TG_CPU_LOADFP };
 void launch_tracegen_cpu(hipStream_t st, const TgCpuOp* ops, uint64_t n, const TgMemOp* mem, uint64_t n_mem, DMatView t);
@@ -95,7 +96,12 @@ hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, c
                                void* sort_tmp, size_t sort_tmp_bytes, DMatView t);
 void launch_tracegen_alu(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t);
 void launch_tracegen_idle(hipStream_t st, int mode, const uint32_t* static_cells, uint64_t n_static, DMatView t);  // 0 zeros, 1 mul counter, 2 static data
-hipError_t launch_tracegen_range(hipStream_t st, const TgAluOp* add_ops, uint64_t n_add, const TgAluOp* sub_ops, uint64_t n_sub, uint32_t* counts, DMatView t);
+// range: the byte histogram of the words range_check()'ed on execute — the results of add, sub, mul, mulhs, mulhu, div, sdiv instructions
+// (alu_u32/src/{add,sub,mul,div}/mod.rs), read from the cpu log's bus operations and the memory write of their cycle
+hipError_t launch_tracegen_range(hipStream_t st, const TgCpuOp* ops, uint64_t n, const TgMemOp* mem, uint64_t n_mem, uint32_t* counts, DMatView t);
+// mul / div / shift / com from their logs (chip = CHIP_MUL .. ); output from the tape and the host-computed first row of every window
+void launch_tracegen_alu2(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t);
+void launch_tracegen_output(hipStream_t st, const TgOutOp* vals, const uint32_t* row0, uint64_t n, uint64_t n_rows, DMatView t);
 hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t n, uint64_t padded_n, uint32_t rom_len, uint32_t* counts, DMatView t);
 // open.hip
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* min_poly_dev, Fp shift, const DeviceTables& tb, uint32_t* w);

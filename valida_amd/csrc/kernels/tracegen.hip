@@ -188,14 +188,26 @@ template <int CHIP> __global__ void __launch_bounds__(256) k_tracegen_alu(const 
 // instructions issue on their result words (alu_u32/src/add/mod.rs, sub/mod.rs: `range_check(a)` on execute), so the
 // table is the byte histogram of the add and sub logs.  program/src/lib.rs:50-68: multiplicity of pc = number of
 // instruction fetches at pc — the histogram of the cpu log's pc column plus the padded STOP rows at the final pc.
-__global__ void __launch_bounds__(256) k_tg_byte_histogram(const TgAluOp* __restrict__ ops, uint64_t n, uint32_t* __restrict__ counts /* 256, zeroed */) {
+// Which words are range-checked is decided by the INSTRUCTION (its execute calls state.range_check(a)), not by the chip that logs the
+// operation — a shift leaves a Mul32 / Div32 in the mul / div log without a range check — so the histogram walks the cpu log: a bus
+// operation whose opcode is add, sub, mul, mulhs, mulhu, div or sdiv contributes the four bytes of the word its cycle wrote (the last
+// memory operation of the cycle).
+__global__ void __launch_bounds__(256) k_tg_range_histogram(const TgCpuOp* __restrict__ ops, uint64_t n, const TgMemOp* __restrict__ mem, uint64_t n_mem,
+                                                            uint32_t* __restrict__ counts /* 256, zeroed */) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t a = ops[i].a;
+        const TgCpuOp op = ops[i];
+        if (op.kind != TG_CPU_BUS && op.kind != TG_CPU_BUS_LEFT_IMM) continue;
+        const uint32_t oc = op.opcode;
+        if (!(oc == OP_ADD32 || oc == OP_SUB32 || oc == OP_MUL32 || oc == OP_MULHS32 || oc == OP_MULHU32 || oc == OP_DIV32 || oc == OP_SDIV32)) continue;
+        const uint64_t end = i + 1 < n ? ops[i + 1].mem_first : n_mem;
+        if (end == 0 || end <= op.mem_first) continue;
+        const TgMemOp w = mem[end - 1];
+        if (!w.is_write) continue;
 #pragma unroll
-        for (int k = 0; k < 4; k++) atomicAdd(&h[byte_of(a, k)], 1u);
+        for (int k = 0; k < 4; k++) atomicAdd(&h[byte_of(w.value, k)], 1u);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
@@ -226,6 +238,72 @@ __global__ void __launch_bounds__(256) k_tracegen_counts(const uint32_t* __restr
     if (i >= t.height) return;
     put(t, 0, i, i < n_counts ? counts[i] : 0u);
     if (with_counter) put(t, 1, i, (uint32_t)i);
+}
+
+// ---- mul / div / shift / com: rows exactly as the reference fills them (see workload/basic_vm.hpp for the file:line of every rule) ----
+template <int CHIP> __global__ void __launch_bounds__(256) k_tracegen_alu2(const TgAluOp* __restrict__ ops, uint64_t n, DMatView t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.height) return;
+    constexpr int W = CHIP == CHIP_MUL ? (int)mul::NUM_COLS : CHIP == CHIP_DIV ? (int)divc::NUM_COLS : CHIP == CHIP_SHIFT ? (int)shift::NUM_COLS : (int)com::NUM_COLS;
+    uint32_t r[W];
+#pragma unroll
+    for (int c = 0; c < W; c++) r[c] = 0;
+    if (CHIP == CHIP_MUL) r[mul::COUNTER] = (uint32_t)(i + 1);  // every row, padding included (alu_u32/src/mul/mod.rs:47-60)
+    if (i < n) {
+        const TgAluOp op = ops[i];
+        uint32_t a[4], b[4], c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = byte_of(op.a, k); b[k] = byte_of(op.b, k); c[k] = byte_of(op.c, k); }
+        if (CHIP == CHIP_MUL) {
+            r[mul::IS_MUL] = op.opcode == OP_MUL32; r[mul::IS_MULHS] = op.opcode == OP_MULHS32; r[mul::IS_MULHU] = op.opcode == OP_MULHU32;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { r[mul::INPUT_1 + k] = b[k]; r[mul::INPUT_2 + k] = c[k]; r[mul::OUTPUT + k] = a[k]; }
+        } else if (CHIP == CHIP_DIV) {
+            r[divc::IS_DIV] = op.opcode == OP_DIV32; r[divc::IS_SDIV] = op.opcode == OP_SDIV32;
+        } else if (CHIP == CHIP_SHIFT) {
+            r[shift::IS_SHL] = op.opcode == OP_SHL32; r[shift::IS_SHR] = op.opcode == OP_SHR32; r[shift::IS_SRA] = op.opcode == OP_SRA32;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { r[shift::INPUT_1 + k] = b[k]; r[shift::INPUT_2 + k] = c[k]; r[shift::OUTPUT + k] = a[k]; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[shift::BITS_2 + j] = (c[3] >> j) & 1;
+            r[shift::TEMP_1] = (c[3] & 1) + 2 * ((c[3] >> 1) & 1) + 4 * ((c[3] >> 2) & 1);
+            const uint32_t pw = 1u << (op.c & 31u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[shift::POWER_OF_TWO + k] = byte_of(pw, k);
+        } else {
+            r[com::IS_NE] = op.opcode == OP_NE32; r[com::IS_EQ] = op.opcode == OP_EQ32;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < W; c++) put(t, c, i, r[c]);
+}
+
+// ---- output (output/src/lib.rs:37-100): window w of the tape (entries w, w + 1) occupies rows [row0[w], row0[w + 1]): the real write, then
+// dummy rows clk_1 + table_len (i + 1); diff = next row's clk - this row's (the window's last row against clk_2); one final real row.
+// row0 (n entries: first row of every window, the last one = the final row) is computed by the host when the log is uploaded.
+__global__ void __launch_bounds__(256) k_tracegen_output(const TgOutOp* __restrict__ vals, const uint32_t* __restrict__ row0, uint64_t n, uint64_t n_rows, DMatView t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.height) return;
+    uint32_t r[output::NUM_COLS];
+#pragma unroll
+    for (int c = 0; c < (int)output::NUM_COLS; c++) r[c] = 0;
+    if (i < n_rows) {
+        // the window of row i: the last w with row0[w] <= i
+        uint64_t lo = 0, hi = n - 1;
+        while (lo < hi) { const uint64_t mid = (lo + hi + 1) >> 1; if (row0[mid] <= i) lo = mid; else hi = mid - 1; }
+        const uint64_t w = lo, k = i - row0[w];
+        const uint32_t table_len = (uint32_t)n, clk_1 = vals[w].clk;
+        auto clk_of = [&](uint64_t kk) { return kk == 0 ? clk_1 % vg::P : (uint32_t)(((uint64_t)clk_1 + (uint64_t)table_len * (kk + 1)) % vg::P); };
+        r[output::CLK] = clk_of(k);
+        if (k == 0) { r[output::IS_REAL] = 1; r[output::VALUE] = vals[w].byte & 255u; }
+        if (w + 1 < n) {
+            const uint64_t num = row0[w + 1] - row0[w];
+            const uint32_t next = k + 1 < num ? clk_of(k + 1) : vals[w + 1].clk % vg::P;
+            r[output::DIFF] = next >= r[output::CLK] ? next - r[output::CLK] : next + vg::P - r[output::CLK];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < (int)output::NUM_COLS; c++) put(t, c, i, r[c]);
 }
 
 // ---- chips that received no operations: padding-only traces ------------------------------------------------------------
@@ -361,12 +439,11 @@ hipError_t launch_tracegen_mem(hipStream_t st, const TgMemOp* mem, uint64_t n, c
 }
 
 // counts: scratch of max(256, rom_len) words
-hipError_t launch_tracegen_range(hipStream_t st, const TgAluOp* add_ops, uint64_t n_add, const TgAluOp* sub_ops, uint64_t n_sub, uint32_t* counts, DMatView t) {
+hipError_t launch_tracegen_range(hipStream_t st, const TgCpuOp* ops, uint64_t n, const TgMemOp* mem, uint64_t n_mem, uint32_t* counts, DMatView t) {
     hipError_t e = hipMemsetAsync(counts, 0, 256 * 4, st);
     if (e != hipSuccess) return e;
-    ProfScope ps("k_tracegen_tables", st, 16.0 * (n_add + n_sub) + 8.0 * t.height);
-    if (n_add) VK_LAUNCH(k_tg_byte_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n_add + 255) / 256)), dim3(256), 0, st, add_ops, n_add, counts);
-    if (n_sub) VK_LAUNCH(k_tg_byte_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n_sub + 255) / 256)), dim3(256), 0, st, sub_ops, n_sub, counts);
+    ProfScope ps("k_tracegen_tables", st, 48.0 * n + 8.0 * t.height);
+    if (n) VK_LAUNCH(k_tg_range_histogram, dim3((unsigned)std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, st, ops, n, mem, n_mem, counts);
     VK_LAUNCH(k_tracegen_counts, dim3(blocks_for(t.height)), dim3(256), 0, st, (const uint32_t*)counts, (uint64_t)256, 1, t);
     return hipSuccess;
 }
@@ -393,6 +470,21 @@ void launch_tracegen_alu(hipStream_t st, int chip, const TgAluOp* ops, uint64_t 
         case CHIP_LT: VK_LAUNCH(k_tracegen_alu<CHIP_LT>, g, b, 0, st, ops, n, t); break;
         default: VK_LAUNCH(k_tracegen_alu<CHIP_BITWISE>, g, b, 0, st, ops, n, t); break;
     }
+}
+
+void launch_tracegen_alu2(hipStream_t st, int chip, const TgAluOp* ops, uint64_t n, DMatView t) {
+    ProfScope ps("k_tracegen_alu", st, 16.0 * n + 4.0 * t.height * t.width);
+    const dim3 g(blocks_for(t.height)), b(256);
+    switch (chip) {
+        case CHIP_MUL: VK_LAUNCH(k_tracegen_alu2<CHIP_MUL>, g, b, 0, st, ops, n, t); break;
+        case CHIP_DIV: VK_LAUNCH(k_tracegen_alu2<CHIP_DIV>, g, b, 0, st, ops, n, t); break;
+        case CHIP_SHIFT: VK_LAUNCH(k_tracegen_alu2<CHIP_SHIFT>, g, b, 0, st, ops, n, t); break;
+        default: VK_LAUNCH(k_tracegen_alu2<CHIP_COM>, g, b, 0, st, ops, n, t); break;
+    }
+}
+void launch_tracegen_output(hipStream_t st, const TgOutOp* vals, const uint32_t* row0, uint64_t n, uint64_t n_rows, DMatView t) {
+    ProfScope ps("k_tracegen_tables", st, 12.0 * n + 4.0 * t.height * t.width);
+    VK_LAUNCH(k_tracegen_output, dim3(blocks_for(t.height)), dim3(256), 0, st, vals, row0, n, n_rows, t);
 }
 
 }  // namespace vk

@@ -10,12 +10,19 @@
 //   MemoryChip read/write/generate_trace memory/src/lib.rs:84-194, :236-262
 //   CpuChip generate_trace + padding     cpu/src/lib.rs:79-97, :163-373
 //   Add32/Sub32/Lt32/Bitwise32 rows      alu_u32/src/add/mod.rs:91-121, sub/mod.rs:91-117, lt/mod.rs:87-166, bitwise/mod.rs:84-129
-//   Mul32 min-length counter rows        alu_u32/src/mul/mod.rs:38-66
+//   Mul32 rows + min-length counter rows alu_u32/src/mul/mod.rs:38-66, :107-132; instructions :141-263
+//   Div32 / Com32 rows (flags only, as the reference fills them)   alu_u32/src/div/mod.rs:84-103, com/mod.rs:87-103; instructions div/mod.rs:112-189, com/mod.rs:110-196
+//   Shift32 rows                         alu_u32/src/shift/mod.rs:118-162; instructions :170-333 (SHL also logs a Mul32, SHR / SRA a Div32 / SDiv32
+//                                        with the power of two; SRA logs itself as Operation::Shr32, :325-328 — restated as written)
+//   Output rows                          output/src/lib.rs:37-100; WRITE :146-173
+//   Word arithmetic                      machine/src/core.rs:129-252 (mulhs zero-extends both operands, :146-158 — restated as written)
 //   Range / Program traces + preprocessed range/src/lib.rs:32-44, range/src/stark.rs:22-25,
 //                                        program/src/lib.rs:38-48, program/src/stark.rs:22-40
 // All values are canonical u32 < p.
 #pragma once
 #include <algorithm>
+#include <array>
+#include <climits>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -69,6 +76,8 @@ struct BasicVm {
     std::vector<MemOp> mem_ops;                    // in (clk, issue) order
     std::vector<CpuRecord> cpu_ops;
     std::vector<AluOp> add_ops, sub_ops, lt_ops, bitwise_ops;
+    std::vector<AluOp> mul_ops, div_ops, shift_ops, com_ops;       // Mul32Chip / Div32Chip / Shift32Chip / Com32Chip ::operations
+    std::vector<std::pair<uint32_t, uint8_t>> output_values;       // OutputChip::values: (clk, byte)
     std::vector<uint32_t> program_counts;
     uint32_t range_counts[256] = {0};
     std::map<uint32_t, Word> static_cells;  // StaticDataChip::cells, copied into memory by initialize_memory (static_data/src/lib.rs:28-32)
@@ -188,6 +197,65 @@ struct BasicVm {
                 write(at(o[0]), dst);
                 lt_ops.push_back({iw.opcode, dst, s1, s2});
                 pc += 1; push(left_imm ? CpuOp::BusLeftImm : CpuOp::Bus, iw, pc0, fp0, has_imm, imm);
+                break;
+            }
+            case OP_MUL32: case OP_MULHS32: case OP_MULHU32: case OP_DIV32: case OP_SDIV32: {  // alu_u32/src/mul/mod.rs:141-263, div/mod.rs:112-189
+                bool has_imm = false; Word imm{{0, 0, 0, 0}};
+                Word bw = read(at(o[1]));
+                Word cw = second_operand(has_imm, imm);
+                const uint32_t bv = u32_of(bw), cv = u32_of(cw);
+                uint32_t av;
+                switch (iw.opcode) {
+                    case OP_MUL32: av = bv * cv; break;
+                    case OP_MULHS32:  // core.rs:146-158: `bu32 as i64` ZERO-extends, so this is the unsigned high word
+                    case OP_MULHU32: av = (uint32_t)(((uint64_t)bv * cv) >> 32); break;
+                    case OP_DIV32:
+                        if (!cv) throw std::runtime_error("workload VM: division by zero (the reference panics)");
+                        av = bv / cv; break;
+                    default:
+                        if (!cv || ((int32_t)bv == INT32_MIN && (int32_t)cv == -1)) throw std::runtime_error("workload VM: signed division overflow (the reference panics)");
+                        av = (uint32_t)((int32_t)bv / (int32_t)cv); break;
+                }
+                Word aw = word_of(av);
+                write(at(o[0]), aw);
+                const bool is_mul = iw.opcode == OP_MUL32 || iw.opcode == OP_MULHS32 || iw.opcode == OP_MULHU32;
+                (is_mul ? mul_ops : div_ops).push_back({iw.opcode, aw, bw, cw});
+                pc += 1; push(CpuOp::Bus, iw, pc0, fp0, has_imm, imm);
+                range_check(aw);
+                break;
+            }
+            case OP_SHL32: case OP_SHR32: case OP_SRA32: {  // alu_u32/src/shift/mod.rs:170-333
+                bool has_imm = false; Word imm{{0, 0, 0, 0}};
+                Word bw = read(at(o[1]));
+                Word cw = second_operand(has_imm, imm);
+                const uint32_t bv = u32_of(bw), cv = u32_of(cw);
+                if (cv >= 32) throw std::runtime_error("workload VM: shift amount >= 32 (overflow in the reference's u32 shift)");
+                const uint32_t av = iw.opcode == OP_SHL32 ? bv << cv : iw.opcode == OP_SHR32 ? bv >> cv : (uint32_t)((int32_t)bv >> cv);
+                Word aw = word_of(av), dw = word_of(1u << cv);
+                write(at(o[0]), aw);
+                // the "receive" that matches the shift chip's send on the general bus
+                if (iw.opcode == OP_SHL32) mul_ops.push_back({OP_MUL32, aw, bw, dw});
+                else div_ops.push_back({iw.opcode == OP_SHR32 ? (uint32_t)OP_DIV32 : (uint32_t)OP_SDIV32, aw, bw, dw});
+                shift_ops.push_back({iw.opcode == OP_SHL32 ? (uint32_t)OP_SHL32 : (uint32_t)OP_SHR32, aw, bw, cw});  // SRA is logged as Shr32 (shift/mod.rs:325-328)
+                pc += 1; push(CpuOp::Bus, iw, pc0, fp0, has_imm, imm);
+                break;
+            }
+            case OP_NE32: case OP_EQ32: {  // alu_u32/src/com/mod.rs:110-196
+                bool has_imm = false; Word imm{{0, 0, 0, 0}};
+                Word s1 = read(at(o[1]));
+                Word s2 = second_operand(has_imm, imm);
+                const bool ne = u32_of(s1) != u32_of(s2);
+                Word dst = word_of((iw.opcode == OP_NE32 ? ne : !ne) ? 1 : 0);
+                write(at(o[0]), dst);
+                com_ops.push_back({iw.opcode, dst, s1, s2});
+                pc += 1; push(CpuOp::Bus, iw, pc0, fp0, has_imm, imm);
+                break;
+            }
+            case OP_WRITE: {  // output/src/lib.rs:146-173: one byte (the least significant of the word at fp + b) to the output tape
+                if (o[4] != 1 || o[2] != 0) throw std::runtime_error("workload VM: WRITE needs is_imm = 1 and c = 0 (asserted by the reference)");
+                Word bw = read(at(o[1]));
+                output_values.push_back({clock, bw.b[3]});
+                pc += 1; push(CpuOp::Bus, iw, pc0, fp0);
                 break;
             }
             default: throw std::runtime_error("workload VM: unsupported opcode " + std::to_string(iw.opcode));
@@ -356,9 +424,68 @@ struct BasicVm {
         }
         return t;
     }
-    static RowMajor mul_trace() {  // no MUL ops in these workloads: 1024 counter rows
-        RowMajor t(1024, mul::NUM_COLS);
-        for (size_t i = 0; i < 1024; i++) t.row(i)[mul::COUNTER] = (uint32_t)(i + 1);
+    RowMajor mul_trace() const {  // alu_u32/src/mul/mod.rs:38-62: at least 1024 rows (the range-check counter), counter = row + 1 on every row
+        RowMajor t(std::max<size_t>(next_pow2(mul_ops.size()), 1024), mul::NUM_COLS);
+        for (size_t i = 0; i < t.height; i++) t.row(i)[mul::COUNTER] = (uint32_t)(i + 1);
+        for (size_t i = 0; i < mul_ops.size(); i++) {
+            uint32_t* r = t.row(i); const AluOp& op = mul_ops[i];
+            r[op.opcode == OP_MUL32 ? mul::IS_MUL : op.opcode == OP_MULHS32 ? mul::IS_MULHS : mul::IS_MULHU] = 1;
+            for (int k = 0; k < 4; k++) { r[mul::INPUT_1 + k] = op.b.b[k]; r[mul::INPUT_2 + k] = op.c.b[k]; r[mul::OUTPUT + k] = op.a.b[k]; }  // r, s stay 0 (:125-132)
+        }
+        return t;
+    }
+    RowMajor div_trace() const {  // alu_u32/src/div/mod.rs:84-103: only the opcode flag ("TODO: Fill in other columns")
+        RowMajor t = alu_rows(div_ops, divc::NUM_COLS);
+        for (size_t i = 0; i < div_ops.size(); i++) t.row(i)[div_ops[i].opcode == OP_DIV32 ? divc::IS_DIV : divc::IS_SDIV] = 1;
+        return t;
+    }
+    RowMajor shift_trace() const {  // alu_u32/src/shift/mod.rs:118-162
+        RowMajor t = alu_rows(shift_ops, shift::NUM_COLS);
+        for (size_t i = 0; i < shift_ops.size(); i++) {
+            uint32_t* r = t.row(i); const AluOp& op = shift_ops[i];
+            r[op.opcode == OP_SHL32 ? shift::IS_SHL : op.opcode == OP_SHR32 ? shift::IS_SHR : shift::IS_SRA] = 1;
+            for (int k = 0; k < 4; k++) { r[shift::INPUT_1 + k] = op.b.b[k]; r[shift::INPUT_2 + k] = op.c.b[k]; r[shift::OUTPUT + k] = op.a.b[k]; }
+            const uint32_t c3 = op.c.b[3];
+            for (int j = 0; j < 8; j++) r[shift::BITS_2 + j] = (c3 >> j) & 1;
+            r[shift::TEMP_1] = (c3 & 1) + 2 * ((c3 >> 1) & 1) + 4 * ((c3 >> 2) & 1);  // the exponent, as written (:159-160)
+            const Word pw = word_of(1u << (u32_of(op.c) & 31u));
+            for (int k = 0; k < 4; k++) r[shift::POWER_OF_TWO + k] = pw.b[k];
+        }
+        return t;
+    }
+    RowMajor com_trace() const {  // alu_u32/src/com/mod.rs:87-103: only the opcode flag
+        RowMajor t = alu_rows(com_ops, com::NUM_COLS);
+        for (size_t i = 0; i < com_ops.size(); i++) t.row(i)[com_ops[i].opcode == OP_NE32 ? com::IS_NE : com::IS_EQ] = 1;
+        return t;
+    }
+    // rows of window i of the output tape (output/src/lib.rs:41-47): (clk_2 - clk_1) / table_len + 1
+    static uint64_t output_window_rows(uint32_t clk_1, uint32_t clk_2, uint32_t table_len) { return (uint64_t)((clk_2 - clk_1) / table_len) + 1; }
+    RowMajor output_trace() const {  // output/src/lib.rs:37-100
+        const size_t n = output_values.size();
+        const uint32_t table_len = (uint32_t)n;
+        std::vector<std::array<uint32_t, output::NUM_COLS>> rows;
+        for (size_t w = 0; w + 1 < n; w++) {
+            const uint32_t clk_1 = output_values[w].first, clk_2 = output_values[w + 1].first;
+            const uint64_t num = output_window_rows(clk_1, clk_2, table_len);
+            const size_t base = rows.size();
+            for (uint64_t i = 0; i < num; i++) {
+                std::array<uint32_t, output::NUM_COLS> r{};
+                if (i == 0) { r[output::IS_REAL] = 1; r[output::CLK] = clk_1 % P; r[output::VALUE] = output_values[w].second; }
+                else r[output::CLK] = (uint32_t)(((uint64_t)clk_1 + (uint64_t)table_len * (i + 1)) % P);  // "dummy output to satisfy range check"
+                rows.push_back(r);
+            }
+            for (uint64_t i = 0; i < num; i++) {  // clock diffs inside the window, the last one against clk_2
+                const uint32_t next = i + 1 < num ? rows[base + i + 1][output::CLK] : clk_2 % P;
+                rows[base + i][output::DIFF] = fsub(next, rows[base + i][output::CLK]);
+            }
+        }
+        if (n) {
+            std::array<uint32_t, output::NUM_COLS> r{};
+            r[output::IS_REAL] = 1; r[output::CLK] = output_values[n - 1].first % P; r[output::VALUE] = output_values[n - 1].second;
+            rows.push_back(r);
+        }
+        RowMajor t(next_pow2(rows.size()), output::NUM_COLS);  // counter, counter_mult, opcode: never written by the reference
+        for (size_t i = 0; i < rows.size(); i++) for (int c = 0; c < output::NUM_COLS; c++) t.row(i)[c] = rows[i][c];
         return t;
     }
     RowMajor range_trace() const {
@@ -404,12 +531,12 @@ struct BasicVm {
         out[CHIP_ADD] = add_trace();
         out[CHIP_SUB] = sub_trace();
         out[CHIP_MUL] = mul_trace();
-        out[CHIP_DIV] = RowMajor(1, divc::NUM_COLS);
-        out[CHIP_SHIFT] = RowMajor(1, shift::NUM_COLS);
+        out[CHIP_DIV] = div_trace();
+        out[CHIP_SHIFT] = shift_trace();
         out[CHIP_LT] = lt_trace();
-        out[CHIP_COM] = RowMajor(1, com::NUM_COLS);
+        out[CHIP_COM] = com_trace();
         out[CHIP_BITWISE] = bitwise_trace();
-        out[CHIP_OUTPUT] = RowMajor(1, output::NUM_COLS);
+        out[CHIP_OUTPUT] = output_trace();
         out[CHIP_RANGE] = range_trace();
         out[CHIP_STATIC_DATA] = static_data_trace();
         return out;
@@ -509,6 +636,46 @@ inline std::vector<InstructionWord> static_data_program() {
 }
 inline std::vector<InstructionWord> loadfp_program() {  // test_prover.rs:381-402
     return {{OP_LOADFP, {4, 0, 0, 0, 0}}, {OP_LOADFP, {8, 3, 0, 0, 0}}, {OP_STOP, {0, 0, 0, 0, 0}}};
+}
+
+// Every chip of the BasicMachine busy at once (no counterpart among the reference's tests, whose programs leave mul / div / shift / com / output
+// idle; SURVEY.md §0.6: several of these chips are stubs in the reference, so a proof of this program is well-formed but NOT accepted by a
+// verifier — it exists to exercise the five remaining trace generators).  Per iteration: mul, mulhu, mulhs, muli, div, sdiv, shl, shr,
+// sra, shli, ne, eq, add, sub, xor, lt, write, addi, addi, bne.
+inline std::vector<InstructionWord> mixed_ops_program(uint32_t iters) {
+    const int32_t B = BYTES_PER_INSTR, loop = 5 * B;
+    auto b = [](uint32_t v, int i) { return (int32_t)((v >> (24 - 8 * i)) & 255); };
+    const uint32_t x0 = 0x12345678u, y0 = 0x9ABCDEF1u;
+    return {
+        {OP_IMM32, {-4, b(x0, 0), b(x0, 1), b(x0, 2), b(x0, 3)}},   // x
+        {OP_IMM32, {-8, b(y0, 0), b(y0, 1), b(y0, 2), b(y0, 3)}},   // y
+        {OP_IMM32, {-12, 0, 0, 0, 0}},                              // i
+        {OP_IMM32, {-16, 0, 0, 0, 5}},                              // s = 5 (shift amount / small divisor)
+        {OP_IMM32, {-20, 255, 255, 255, 255}},                      // ones
+        // loop:
+        {OP_MUL32, {-24, -4, -8, 0, 0}},     // t1 = x * y
+        {OP_MULHU32, {-28, -4, -8, 0, 0}},   // t2 = hi(x * y)
+        {OP_MULHS32, {-32, -8, -4, 0, 0}},
+        {OP_MUL32, {-36, -4, 7, 0, 1}},      // t4 = x * 7
+        {OP_DIV32, {-40, -8, -16, 0, 0}},    // t5 = y / 5
+        {OP_SDIV32, {-44, -8, 3, 0, 1}},     // t6 = (i32)y / 3
+        {OP_SHL32, {-48, -4, -16, 0, 0}},    // t7 = x << 5
+        {OP_SHR32, {-52, -8, -16, 0, 0}},    // t8 = y >> 5
+        {OP_SRA32, {-56, -8, -16, 0, 0}},    // t9 = (i32)y >> 5
+        {OP_SHL32, {-60, -4, 3, 0, 1}},      // t10 = x << 3
+        {OP_NE32, {-64, -24, -28, 0, 0}},
+        {OP_EQ32, {-68, -4, -4, 0, 0}},
+        {OP_ADD32, {-72, -24, -28, 0, 0}},   // t13 = t1 + t2
+        {OP_SUB32, {-76, -20, -72, 0, 0}},   // ~t13 (borrow-free)
+        {OP_XOR32, {-4, -72, -4, 0, 0}},     // x ^= t13
+        {OP_LT32, {-80, -4, -8, 0, 0}},
+        {OP_WRITE, {0, -4, 0, 0, 1}},        // output the low byte of x
+        {OP_ADD32, {-8, -8, 0x01010101, 0, 1}},  // y += ..
+        {OP_ADD32, {-12, -12, 1, 0, 1}},     // i += 1
+        {OP_BNE, {loop, -12, (int32_t)iters, 0, 1}},
+        {OP_WRITE, {0, -8, 0, 0, 1}},
+        {OP_STOP, {0, 0, 0, 0, 0}},
+    };
 }
 
 }  // namespace vwork
