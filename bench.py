@@ -437,6 +437,8 @@ def main():
             if big:
                 for p_ in provers:
                     p_.trim()
+                run_steps(len(provers))  # the pools size themselves again (first-touch hipMalloc inside the table's steps would be timed as kernel time)
+                torch.cuda.synchronize()
     # Per-kernel table: a few steps with events on EVERY launch, outside the timed region.  Timed region: events on the launches
     # of the dominant kernel only — a timed launch carries a pair of events, and 1270 of them per proof cost ~4 % of the throughput
     # being measured; the roofline needs that kernel's live average, the table does not need the timed region.
