@@ -2,7 +2,7 @@
 """A/B builds of ONE kernel file: compile it with extra -D flags and link it with the current objects of everything else into
 build/variants/<name>/libvgpu.so (picked up through VGPU_LIB_PATH; tools/gpu_ab*.sh alternate libraries inside one GPU session).
 
-    python tools/build_variant.py <name> kernels/ntt.hip -DVGPU_MID12_WAVES=4 [-D...]
+    python tools/build_variant.py <name> kernels/ntt.hip|ALL -DVGPU_MID12_WAVES=4 [-D...]
 """
 import os
 import subprocess
@@ -18,9 +18,15 @@ def main():
     b.build_vgpu()  # the baseline objects
     out_dir = os.path.join(b.BUILD, "variants", name)
     os.makedirs(out_dir, exist_ok=True)
-    obj = os.path.join(out_dir, src.replace("/", "_") + ".o")
-    subprocess.run(["hipcc"] + b.FLAGS + flags + ["-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj], check=True)
-    objs = [obj if s == src else os.path.join(b.BUILD, s.replace("/", "_") + ".o") for s in b.SOURCES]
+    srcs = list(b.SOURCES) if src == "ALL" else [src]  # ALL: a switch in a shared header (field.hpp)
+    procs = []
+    for one in srcs:
+        obj = os.path.join(out_dir, one.replace("/", "_") + ".o")
+        procs.append(subprocess.Popen(["hipcc"] + b.FLAGS + flags + ["-x", "hip", "-c", os.path.join(b.CSRC, one), "-o", obj]))
+    for p in procs:
+        if p.wait() != 0:
+            raise SystemExit("hipcc failed")
+    objs = [os.path.join(out_dir if s in srcs else b.BUILD, s.replace("/", "_") + ".o") for s in b.SOURCES]
     lib = os.path.join(out_dir, "libvgpu.so")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"], check=True)
     print(lib)

@@ -1,0 +1,69 @@
+// Field-arithmetic microbenchmark (gfx950): the modular add / sub / Montgomery product of valida_amd/csrc/field.hpp as compiled (unsigned-min
+// reductions: v_min_u32 is a half-rate instruction) against a carry-out + v_cndmask form (three full-rate instructions), in long dependent
+// chains per lane with 8 independent chains, 8 waves per SIMD.  Prints ns per (add + sub) pair and per product, per wave64 — the ratio decides
+// whether field.hpp switches its reductions.   hipcc --offload-arch=gfx950 -O3 tools/microbench_fp.hip -o build/mb/microbench_fp
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+constexpr uint32_t P = 0x78000001u;
+__device__ __forceinline__ uint32_t add_min(uint32_t a, uint32_t b) { uint32_t s = a + b, t = s - P; return s < t ? s : t; }
+__device__ __forceinline__ uint32_t sub_min(uint32_t a, uint32_t b) { uint32_t d = a - b, t = d + P; return d < t ? d : t; }
+__device__ __forceinline__ uint32_t add_c(uint32_t a, uint32_t b) {
+    uint32_t s = a + b, t, r; unsigned long long vc;
+    asm("v_subrev_co_u32_e64 %0, %1, %4, %3\n\tv_cndmask_b32_e64 %2, %0, %3, %1" : "=&v"(t), "=&s"(vc), "=v"(r) : "v"(s), "v"(P));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub_c(uint32_t a, uint32_t b) {
+    uint32_t d, t, r; unsigned long long vc;
+    asm("v_sub_co_u32_e64 %0, %1, %4, %5\n\tv_add_u32_e32 %2, %6, %0\n\tv_cndmask_b32_e64 %3, %0, %2, %1" : "=&v"(d), "=&s"(vc), "=&v"(t), "=v"(r) : "v"(a), "v"(b), "v"(P));
+    return r;
+}
+__device__ __forceinline__ uint32_t mont_min(uint32_t a, uint32_t b) {
+    uint64_t t = (uint64_t)a * b; uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo * 0x88000001u, u = __umulhi(m, P), r = hi - u, r2 = r + P; return r < r2 ? r : r2;
+}
+__device__ __forceinline__ uint32_t mont_c(uint32_t a, uint32_t b) {
+    uint64_t t = (uint64_t)a * b; uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo * 0x88000001u, u = __umulhi(m, P);
+    return sub_c(hi, u);
+}
+template <int MODE> __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
+    uint32_t x[8], y = 123456789u + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = (threadIdx.x * 2654435761u + i * 40503u) % P;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (MODE == 0) { x[i] = add_min(x[i], y); x[i] = sub_min(x[i], x[(i + 1) & 7]); }
+            if (MODE == 1) { x[i] = add_c(x[i], y); x[i] = sub_c(x[i], x[(i + 1) & 7]); }
+            if (MODE == 2) x[i] = mont_min(x[i], y);
+            if (MODE == 3) x[i] = mont_c(x[i], y);
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc ^= x[i];
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+template <int MODE> double run(uint32_t* d, int iters) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    k<MODE><<<2048, 256>>>(d, 16);
+    hipDeviceSynchronize();
+    hipEventRecord(a); k<MODE><<<2048, 256>>>(d, iters); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    // 2048 blocks x 4 waves = 8192 waves on 1024 SIMDs = 8 per SIMD; ops per wave = iters * 8
+    return ms * 1e6 / ((double)iters * 8.0) / 8.0;  // ns of SIMD time per op-group per wave
+}
+int main() {
+    uint32_t* d; hipMalloc(&d, 2048 * 256 * 4);
+    const int iters = 20000;
+    uint32_t h0[4] = {0}, v[4];
+    double t0 = run<0>(d, iters); hipMemcpy(&v[0], d, 4, hipMemcpyDeviceToHost);
+    double t1 = run<1>(d, iters); hipMemcpy(&v[1], d, 4, hipMemcpyDeviceToHost);
+    double t2 = run<2>(d, iters); hipMemcpy(&v[2], d, 4, hipMemcpyDeviceToHost);
+    double t3 = run<3>(d, iters); hipMemcpy(&v[3], d, 4, hipMemcpyDeviceToHost);
+    (void)h0;
+    printf("add+sub pair   min-form %.3f ns   carry-form %.3f ns   (ratio %.3f)  results %s\n", t0, t1, t1 / t0, v[0] == v[1] ? "equal" : "DIFFER");
+    printf("Montgomery mul min-form %.3f ns   carry-form %.3f ns   (ratio %.3f)  results %s\n", t2, t3, t3 / t2, v[2] == v[3] ? "equal" : "DIFFER");
+    return 0;
+}

@@ -39,26 +39,50 @@ VG_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
 // faster, but with three proofs in flight — the GPU full — the bench LOST 4.5 % (48.7 vs 51.0 proofs/s, A/B in one session,
 // tools/gpu_ab.sh): twice as many 64-bit multiply-adds per product; not a power effect (2.31 GHz, 1.13 of 1.4 kW under the full bench); cause
 // not established.  Measured, reverted.
+// The three conditional corrections of the field arithmetic (a + b, a - b and the last step of a Montgomery reduction).  As plain C++ they
+// compile to add / sub + v_min_u32, and v_min_u32 issues at HALF rate on gfx950 (profiles/r02_microbench.txt); on the device they are
+// written as carry-out + v_cndmask_b32 instead — three full-rate instructions, the borrow travelling in an SGPR pair the register
+// allocator picks (VOP3 encodings, so independent reductions do not serialise on VCC).  Measured (tools/microbench_fp.hip,
+// profiles/r03_microbench_fp.txt): add + sub pair 9.9 -> 7.1 ns per wave, Montgomery product 11.3 -> 9.8 ns, identical results.
+// VG_CARRY_REDUCE=0 restores the min form (A/B builds).
+#ifndef VG_CARRY_REDUCE
+#define VG_CARRY_REDUCE 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && VG_CARRY_REDUCE
+// s in [0, 2p) -> s mod p
+VG_HD uint32_t reduce_once(uint32_t s) {
+    uint32_t t, r;
+    unsigned long long borrow;
+    asm("v_subrev_co_u32_e64 %0, %1, %4, %3\n\tv_cndmask_b32_e64 %2, %0, %3, %1" : "=&v"(t), "=&s"(borrow), "=v"(r) : "v"(s), "v"(P));
+    return r;
+}
+// a, b in [0, p) (or any a >= 0, b with a - b > -p) -> (a - b) mod p
+VG_HD uint32_t sub_mod(uint32_t a, uint32_t b) {
+    uint32_t d, t, r;
+    unsigned long long borrow;
+    asm("v_sub_co_u32_e64 %0, %1, %4, %5\n\tv_add_u32_e32 %2, %6, %0\n\tv_cndmask_b32_e64 %3, %0, %2, %1" : "=&v"(d), "=&s"(borrow), "=&v"(t), "=v"(r) : "v"(a), "v"(b), "v"(P));
+    return r;
+}
+#else
+VG_HD uint32_t reduce_once(uint32_t s) { uint32_t t = s - P; return s < t ? s : t; }          // s - p wraps to a huge value when s < p
+VG_HD uint32_t sub_mod(uint32_t a, uint32_t b) { uint32_t d = a - b, t = d + P; return d < t ? d : t; }  // d wraps to a huge value when a < b
+#endif
+
 VG_HD uint32_t monty_reduce(uint64_t t) {
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t m = lo * 0x88000001u;         // lo * p^{-1} mod 2^32
     uint32_t u = mul_hi_u32(m, P);         // (m * p) >> 32 ; low word of m*p equals lo
-    uint32_t r = hi - u;  // in (-p, p): the wrapped value is huge when negative, so min picks the corrected one
-    uint32_t r2 = r + P;
-    return r < r2 ? r : r2;
+    return sub_mod(hi, u);                 // hi - u in (-p, p)
 }
 
 // Montgomery reduction of a lazily accumulated sum of up to FOUR products of values < p
 // (t < 4 p^2 < 2^64, high word < 2p): one conditional subtraction of p * 2^32 first, then as above.
 // 7 VALU instructions for 4 multiply-adds that each cost one v_mad_u64_u32.
 VG_HD uint32_t monty_reduce_wide(uint64_t t) {
-    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
-    uint32_t h2 = hi - P;
-    hi = hi < h2 ? hi : h2;
+    uint32_t lo = (uint32_t)t, hi = reduce_once((uint32_t)(t >> 32));
     uint32_t m = lo * 0x88000001u;
     uint32_t u = mul_hi_u32(m, P);
-    uint32_t r = hi - u, r2 = r + P;
-    return r < r2 ? r : r2;
+    return sub_mod(hi, u);
 }
 
 struct Fp {
@@ -71,9 +95,9 @@ struct Fp {
     VG_HD bool is_zero() const { return v == 0; }
     VG_HD bool operator==(const Fp& o) const { return v == o.v; }
     VG_HD bool operator!=(const Fp& o) const { return v != o.v; }
-    // branch-free via unsigned min (v_min_u32): 3 VALU instructions each
-    VG_HD Fp operator+(const Fp& o) const { uint32_t s = v + o.v, t = s - P; return raw(s < t ? s : t); }
-    VG_HD Fp operator-(const Fp& o) const { uint32_t d = v - o.v, t = d + P; return raw(d < t ? d : t); }
+    // branch-free, 3 VALU instructions each (reduce_once / sub_mod above)
+    VG_HD Fp operator+(const Fp& o) const { return raw(reduce_once(v + o.v)); }
+    VG_HD Fp operator-(const Fp& o) const { return raw(sub_mod(v, o.v)); }
     VG_HD Fp operator-() const { return raw(v ? P - v : 0); }
     VG_HD Fp operator*(const Fp& o) const { return raw(monty_reduce((uint64_t)v * o.v)); }
     VG_HD Fp& operator+=(const Fp& o) { *this = *this + o; return *this; }
