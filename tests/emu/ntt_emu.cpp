@@ -1,6 +1,7 @@
 // The NTT / LDE kernels of valida_amd/csrc/kernels/ntt.hip compiled for the HOST under tools/hipemu (fibers per workgroup thread,
 // __syncthreads() as a yield): the very kernel source, its index arithmetic and barrier structure, checked on the CPU against the oracle's
 // committed LDE before any GPU minute is spent (tests/test_ntt_emu_cpu.py).  Test infrastructure; nothing in the product links it.
+#define HIPEMU_CHECKS 1
 #include <hip/hip_runtime.h>  // tools/hipemu/hip/hip_runtime.h (first on the include path)
 
 #include "../../valida_amd/csrc/kernels/ntt.hip"

@@ -18,6 +18,22 @@ __device__ __forceinline__ uint32_t sub_c(uint32_t a, uint32_t b) {
     asm("v_sub_co_u32_e64 %0, %1, %4, %5\n\tv_add_u32_e32 %2, %6, %0\n\tv_cndmask_b32_e64 %3, %0, %2, %1" : "=&v"(d), "=&s"(vc), "=&v"(t), "=v"(r) : "v"(a), "v"(b), "v"(P));
     return r;
 }
+// the same through VCC (VOP2 encodings, half the code bytes; sequences serialise on VCC — in-order issue makes that free within a wave)
+__device__ __forceinline__ uint32_t add_v(uint32_t a, uint32_t b) {
+    uint32_t s = a + b, t, r;
+    asm("v_subrev_co_u32_e32 %0, vcc, %3, %2\n\tv_cndmask_b32_e32 %1, %0, %2, vcc" : "=&v"(t), "=v"(r) : "v"(s), "v"(P) : "vcc");
+    return r;
+}
+__device__ __forceinline__ uint32_t sub_v(uint32_t a, uint32_t b) {
+    uint32_t d, t, r;
+    asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\tv_add_u32_e32 %1, %5, %0\n\tv_cndmask_b32_e32 %2, %0, %1, vcc" : "=&v"(d), "=&v"(t), "=v"(r) : "v"(a), "v"(b), "v"(P) : "vcc");
+    return r;
+}
+__device__ __forceinline__ uint32_t mont_v(uint32_t a, uint32_t b) {
+    uint64_t t = (uint64_t)a * b; uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo * 0x88000001u, u = __umulhi(m, P);
+    return sub_v(hi, u);
+}
 __device__ __forceinline__ uint32_t mont_min(uint32_t a, uint32_t b) {
     uint64_t t = (uint64_t)a * b; uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t m = lo * 0x88000001u, u = __umulhi(m, P), r = hi - u, r2 = r + P; return r < r2 ? r : r2;
@@ -38,6 +54,8 @@ template <int MODE> __global__ void __launch_bounds__(256) k(uint32_t* out, int 
             if (MODE == 1) { x[i] = add_c(x[i], y); x[i] = sub_c(x[i], x[(i + 1) & 7]); }
             if (MODE == 2) x[i] = mont_min(x[i], y);
             if (MODE == 3) x[i] = mont_c(x[i], y);
+            if (MODE == 4) { x[i] = add_v(x[i], y); x[i] = sub_v(x[i], x[(i + 1) & 7]); }
+            if (MODE == 5) x[i] = mont_v(x[i], y);
         }
     }
     uint32_t acc = 0;
@@ -63,6 +81,10 @@ int main() {
     double t2 = run<2>(d, iters); hipMemcpy(&v[2], d, 4, hipMemcpyDeviceToHost);
     double t3 = run<3>(d, iters); hipMemcpy(&v[3], d, 4, hipMemcpyDeviceToHost);
     (void)h0;
+    uint32_t v4, v5;
+    double t4 = run<4>(d, iters); hipMemcpy(&v4, d, 4, hipMemcpyDeviceToHost);
+    double t5 = run<5>(d, iters); hipMemcpy(&v5, d, 4, hipMemcpyDeviceToHost);
+    printf("through VCC (VOP2): add+sub pair %.3f ns   Montgomery mul %.3f ns   results %s\n", t4, t5, (v4 == v[0] && v5 == v[2]) ? "equal" : "DIFFER");
     printf("add+sub pair   min-form %.3f ns   carry-form %.3f ns   (ratio %.3f)  results %s\n", t0, t1, t1 / t0, v[0] == v[1] ? "equal" : "DIFFER");
     printf("Montgomery mul min-form %.3f ns   carry-form %.3f ns   (ratio %.3f)  results %s\n", t2, t3, t3 / t2, v[2] == v[3] ? "equal" : "DIFFER");
     return 0;

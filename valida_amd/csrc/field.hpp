@@ -48,7 +48,19 @@ VG_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
 #ifndef VG_CARRY_REDUCE
 #define VG_CARRY_REDUCE 1
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && VG_CARRY_REDUCE
+#if defined(__HIP_DEVICE_COMPILE__) && VG_CARRY_REDUCE == 2
+// the same through VCC (VOP2 encodings: half the code bytes; measured 3 % faster on the add + sub pair, equal on the product)
+VG_HD uint32_t reduce_once(uint32_t s) {
+    uint32_t t, r;
+    asm("v_subrev_co_u32_e32 %0, vcc, %3, %2\n\tv_cndmask_b32_e32 %1, %0, %2, vcc" : "=&v"(t), "=v"(r) : "v"(s), "v"(P) : "vcc");
+    return r;
+}
+VG_HD uint32_t sub_mod(uint32_t a, uint32_t b) {
+    uint32_t d, t, r;
+    asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\tv_add_u32_e32 %1, %5, %0\n\tv_cndmask_b32_e32 %2, %0, %1, vcc" : "=&v"(d), "=&v"(t), "=v"(r) : "v"(a), "v"(b), "v"(P) : "vcc");
+    return r;
+}
+#elif defined(__HIP_DEVICE_COMPILE__) && VG_CARRY_REDUCE
 // s in [0, 2p) -> s mod p
 VG_HD uint32_t reduce_once(uint32_t s) {
     uint32_t t, r;
