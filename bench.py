@@ -115,14 +115,14 @@ def segment_loop_bound(log_rows, rank):
     return n
 
 
-def exchange_roots(dist, torch, commitments, device):
+def exchange_roots(dist, torch, commitments, device, group=None):
     """The one collective of the path: all-gather of each segment's three 8-word Merkle roots (96 B per proof
     per rank; RCCL over xGMI with the nccl backend, gloo in the CPU tests).  `commitments` holds 24 words per
     proof this rank produced; returns a [world, len(commitments)] int64 array."""
     world = dist.get_world_size()
     local = torch.from_numpy(np.ascontiguousarray(commitments, dtype=np.int64).reshape(-1)).to(device)
     out = torch.zeros(local.numel() * world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, local)
+    dist.all_gather_into_tensor(out, local, group=group)
     return out.reshape(world, local.numel())
 
 
@@ -222,6 +222,12 @@ def main():
             dist.init_process_group(backend="nccl", device_id=coll_device)
         else:
             dist.init_process_group(backend=backend)
+    # Control plane (the communicator id, the agreement on the route) on a gloo group of its own: if the library's RCCL rendezvous gets
+    # stuck, nothing the job still has to say to itself may travel through RCCL on the same device — the abandoned rendezvous could
+    # interfere with it or deadlock it — so after a stuck bring-up EVERY collective of the job (roots, barriers, the final MAX) uses this
+    # group and host tensors, and the line says so ("comm_stuck").
+    ctl = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
+    coll_group = None
 
     rc = va.poseidon_round_constants()
     machine = va.Machine.basic()
@@ -278,7 +284,7 @@ def main():
 
         try:
             ids = [va.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
+            dist.broadcast_object_list(ids, src=0, group=ctl)
             th = threading.Thread(target=bring_up, daemon=True)
             th.start()
             th.join(float(os.environ.get("VGPU_BENCH_COMM_TIMEOUT", "90")))
@@ -291,10 +297,12 @@ def main():
             comm_note = "vgpu_comm_allgather_roots (RCCL driven by libvgpu.so)"
         except Exception as e:  # noqa: BLE001
             lib_comm, comm_note = None, "torch.distributed all_gather_into_tensor (library communicator failed: %s)" % e
-        flags = [lib_comm is not None]
         gathered = [None] * world
-        dist.all_gather_object(gathered, flags[0])
-        if not all(gathered):  # all ranks take the same route
+        dist.all_gather_object(gathered, (lib_comm is not None, comm_stuck), group=ctl)
+        if any(g[1] for g in gathered):  # some rank left a thread inside the rendezvous: no RCCL traffic of any kind from here on
+            comm_stuck = True
+            coll_group, coll_device = ctl, torch.device("cpu")
+        if not all(g[0] for g in gathered):  # all ranks take the same route
             lib_comm = None
             if "failed" not in comm_note:
                 comm_note = "torch.distributed all_gather_into_tensor (library communicator failed on another rank)"
@@ -332,7 +340,7 @@ def main():
                 if lib_comm is not None:
                     all_roots[0] = lib_comm.allgather_roots(done[j].words[2:26])
                 else:
-                    all_roots[0] = exchange_roots(dist, torch, done[j].words[2:26], coll_device)
+                    all_roots[0] = exchange_roots(dist, torch, done[j].words[2:26], coll_device, coll_group)
 
         for i in range(k):
             slot = i % len(provers)
@@ -355,7 +363,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=coll_group)
         torch.cuda.synchronize()
 
     # context initialisation (not a step): every prover context sizes its memory pool and loads its kernels once, so the W
@@ -484,7 +492,7 @@ def main():
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=coll_group)
         elapsed = float(tmax.item())
 
     if rank == 0:
@@ -549,6 +557,7 @@ def main():
                 "log_blowup": prover.log_blowup, "num_queries": prover.num_queries, "pow_bits": prover.pow_bits,
                 "parallelism": ("segments: one independent proof per GPU + all-gather of 3 roots per proof via " + comm_note) if world > 1 else "single GPU",
                 "proofs_in_flight_per_gpu": len(provers),
+                "comm_stuck": bool(comm_stuck),  # true: the library's RCCL bring-up timed out somewhere and the job's collectives ran over gloo
             },
             "roofline": roofline_object(name, prof[name], achieved, traffic, traffic_src, keccak_roofline(prof[name]) if valu_ops > 0 else None, args.steps),
             # The dominant kernel is Keccak-f[1600] over Merkle nodes: 32-bit integer VALU work, ~4200 instructions per 96 B moved, so
@@ -641,7 +650,7 @@ def main():
         os._exit(0)
     if world > 1:
         if comm_stuck:  # a thread is still inside the abandoned rendezvous: leave without waiting for it
-            dist.barrier()
+            dist.barrier(group=coll_group)
             sys.stdout.flush()
             os._exit(0)
         dist.destroy_process_group()
