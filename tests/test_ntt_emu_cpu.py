@@ -40,7 +40,7 @@ def run(fn, m, log_blowup, shift):
 # one-tile columns (every height up to 2^12, height 1 included), the four-step split with 2^12-point tiles (k_hi = 1 .. 8: every round
 # split of the strided tile), several widths (the persistent blocks' tile -> column map), both blowups, a shifted coset (the quotient round's)
 CASES = [(0, 3, 1, 31), (1, 1, 1, 31), (2, 2, 2, 31), (3, 5, 1, 31), (4, 1, 1, 31), (5, 3, 2, 31), (6, 2, 1, 31), (7, 1, 1, 31), (8, 2, 1, 961), (9, 1, 2, 31),
-         (10, 2, 1, 31), (11, 1, 1, 31), (12, 3, 1, 31), (13, 2, 1, 31), (14, 1, 2, 31), (15, 3, 1, 961), (16, 2, 1, 31), (17, 1, 1, 31), (18, 1, 2, 31), (20, 2, 1, 31)]
+         (10, 2, 1, 31), (11, 1, 1, 31), (12, 3, 1, 31), (13, 2, 1, 31), (14, 1, 2, 31), (15, 3, 1, 961), (16, 2, 1, 31), (17, 1, 1, 31), (18, 1, 2, 31), (20, 2, 1, 31), (22, 1, 1, 31)]  # 2^20 / 2^22: the strided rounds with compile-time shapes
 
 
 @pytest.mark.parametrize("k,w,log_blowup,shift", CASES)
@@ -52,7 +52,7 @@ def test_fused_lde_kernels_under_emulation_match_the_oracle(emu, k, w, log_blowu
     assert np.array_equal(got, want), "first mismatch at %s" % (np.argwhere(got != want)[0],)
 
 
-@pytest.mark.parametrize("k,w,log_blowup,shift", [(0, 2, 1, 31), (5, 3, 2, 31), (11, 2, 1, 31), (12, 1, 1, 31), (13, 2, 1, 31), (16, 1, 2, 961)])
+@pytest.mark.parametrize("k,w,log_blowup,shift", [(0, 2, 1, 31), (5, 3, 2, 31), (11, 2, 1, 31), (12, 1, 1, 31), (13, 2, 1, 31), (16, 1, 2, 961), (20, 1, 1, 31), (22, 1, 1, 961)])
 def test_unfused_passes_under_emulation_match_the_oracle(emu, k, w, log_blowup, shift):
     """The emulator's own credentials: the passes whose DEVICE results the -m gpu suite has matched to the oracle since round 1 give the
     same LDE when their source runs under it."""

@@ -171,6 +171,50 @@ __device__ __forceinline__ void tile_transform(uint32_t* buf, const uint32_t* tw
     }
 }
 
+// Strided tiles of the two hot shapes with everything the address arithmetic needs at compile time: heights 2^20 (2^8 rows x 64 columns) and
+// 2^22 / 2^24 (2^10 rows x 16 columns).  The generic rounds compute every LDS address (row x LD + column) and twiddle offset at run time —
+// about as many instructions again as the butterflies themselves; here a work item's 2^R points are base + immediate offsets.
+template <int R, bool DIT, int LB, int LOGT>
+__device__ __forceinline__ void ntt_round_strided(uint32_t* buf, const uint32_t* tw, int logn) {
+    constexpr int G = 1 << R, T = 1 << LOGT, LD = T + 1, gs = LD << LB;
+    const int n_items = (1 << (logn - R)) << LOGT;
+    for (int w = threadIdx.x; w < n_items; w += blockDim.x) {
+        const int c = w & (T - 1), q = w >> LOGT;
+        const int low = q & ((1 << LB) - 1), base = ((q >> LB) << (LB + R)) | low;
+        uint32_t* p0 = buf + base * LD + c;
+        Fp x[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) x[g] = Fp::raw(p0[g * gs]);
+        butterflies<R, DIT, LB == 0>(x, tw, low, LB);
+#pragma unroll
+        for (int g = 0; g < G; g++) p0[g * gs] = x[g].v;
+    }
+    __syncthreads();
+}
+// K_HI = 8: two radix-16 rounds; K_HI = 10: radix-4 on the top two stages + two radix-16 rounds
+template <bool DIT, int K_HI, int LOGT>
+__device__ __forceinline__ void strided_transform(uint32_t* buf, const uint32_t* tw) {
+    static_assert(K_HI == 8 || K_HI == 10, "hot shapes only");
+    if (DIT) {
+        ntt_round_strided<4, true, 0, LOGT>(buf, tw, K_HI);
+        ntt_round_strided<4, true, 4, LOGT>(buf, tw, K_HI);
+        if (K_HI == 10) ntt_round_strided<2, true, 8, LOGT>(buf, tw, K_HI);
+    } else {
+        if (K_HI == 10) ntt_round_strided<2, false, 8, LOGT>(buf, tw, K_HI);
+        ntt_round_strided<4, false, 4, LOGT>(buf, tw, K_HI);
+        ntt_round_strided<4, false, 0, LOGT>(buf, tw, K_HI);
+    }
+}
+#ifndef VGPU_STRIDED_FIXED
+#define VGPU_STRIDED_FIXED 1  // 0: the generic rounds for every shape (A/B builds)
+#endif
+template <bool DIT>
+__device__ __forceinline__ void strided_tile_transform(uint32_t* buf, const uint32_t* tw, int k_hi, int logT, int LD) {
+    if (VGPU_STRIDED_FIXED && k_hi == 8 && logT == 6) strided_transform<DIT, 8, 6>(buf, tw);
+    else if (VGPU_STRIDED_FIXED && k_hi == 10 && logT == 4) strided_transform<DIT, 10, 4>(buf, tw);
+    else tile_transform<DIT, false>(buf, tw, k_hi, logT, LD);
+}
+
 __device__ __forceinline__ void stage_twiddles(uint32_t* dst, const uint32_t* __restrict__ compact, int logn) {
     const int count = (1 << logn) - 1;
     for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = compact[i];
@@ -267,7 +311,7 @@ __global__ void k_intt_strided(DMatView m, int k, int k_lo, int logT, DeviceTabl
     }
     stage_twiddles(tw, tb.itwc, k_hi);
     __syncthreads();
-    tile_transform<true, false>(lds, tw, k_hi, logT, LD);
+    strided_tile_transform<true>(lds, tw, k_hi, logT, LD);
     Fp ninv = Fp::raw(n_inv_mont);
     for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; col[h * n_lo + c] = (Fp::raw(lds[h * LD + c]) * ninv).v; }
 }
@@ -305,7 +349,7 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
     }
     stage_twiddles(tw, tb.twc, k_hi);
     __syncthreads();
-    tile_transform<false, false>(lds, tw, k_hi, logT, LD);
+    strided_tile_transform<false>(lds, tw, k_hi, logT, LD);
     // twiddle: thread per row h', running product over the T consecutive r
     for (int h = threadIdx.x; h < n_hi; h += blockDim.x) {
         const uint32_t e = __brev((uint32_t)h) >> (32 - k_hi);  // k_hi >= 1 in this kernel
@@ -387,7 +431,7 @@ __global__ void k_lde_a(DMatView src, DMatView dst, int k, int k_lo, int logT, D
     }
     stage_twiddles(tw, tb.itwc, k_hi);
     __syncthreads();
-    tile_transform<false, false>(lds, tw, k_hi, logT, LD);  // DIF with inverse roots: row p holds c_a = bitrev(p)
+    strided_tile_transform<false>(lds, tw, k_hi, logT, LD);  // DIF with inverse roots: row p holds c_a = bitrev(p)
     for (int p = threadIdx.x; p < n_hi; p += blockDim.x) {  // times w_N^-(c_a i_lo): thread per row, running product over the T consecutive i_lo
         const uint32_t ca = __brev((uint32_t)p) >> (32 - k_hi);  // k_hi >= 1 in this kernel
         const Fp base = inv_root_pow(tb, k, ca);
@@ -570,7 +614,7 @@ __global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int
     }
     stage_twiddles(tw, tb.twc, k_hi);
     __syncthreads();
-    tile_transform<false, false>(lds, tw, k_hi, logT, LD);  // DIF with forward roots: row p'' holds f_a = bitrev(p'')
+    strided_tile_transform<false>(lds, tw, k_hi, logT, LD);  // DIF with forward roots: row p'' holds f_a = bitrev(p'')
     // element (p'', q0 + c) -> out[bitrev_{k_lo}(q0 + c) n_hi + p'']: n_hi consecutive words per c (LDS read with the odd stride LD: conflict-free)
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int p2 = e & (n_hi - 1), c = e >> k_hi;
