@@ -515,6 +515,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     t0 = Clock::now();
     const Ext5 alpha = ch.sample_ext();
     std::vector<DMat> quot(NC);
+    std::vector<char> quot_is_natural(NC, 0);
     std::vector<Fp> quot_shifts(NC);
     {
         std::vector<uint32_t> pool;
@@ -535,6 +536,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         }
         DBuf pool_dev(&c, pool);
         Section quotient_section(&c);
+        static const bool quot_natural = [] { const char* e = getenv("VGPU_QUOT_NATURAL"); return !(e && e[0] == '0'); }();
         for (size_t i = 0; i < NC; i++) {
             auto& air = machine_.airs[i];
             vk::QuotientArgs a{};
@@ -543,6 +545,10 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             a.K = Ks[i];
             quot[i] = DMat(&c, 1ull << log_deg[i], 5ull << air.log_quotient_degree);
             a.out = quot[i].view();
+            // chunk rows in natural order (staged through LDS into 64-byte runs): the quotient round then takes the fused LDE like the other
+            // two; higher quotient degrees (k_quotient_general) keep the bit-reversed positions.  VGPU_QUOT_NATURAL=0: bit-reversed everywhere.
+            a.out_natural = quot_natural && air.log_quotient_degree == 1 ? 1 : 0;
+            quot_is_natural[i] = a.out_natural != 0;
             vk::launch_quotient(c.stream_for(i, 1ull << log_deg[i]), a, c.tables);
             quot_shifts[i] = s.exp_power_of_2(air.log_quotient_degree);  // lib.rs:593-596
         }
@@ -555,8 +561,8 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         for (size_t i = 0; i < NC; i++) {
             auto& q = quot[i];
             DMat nat(&c, q.height, q.width);
-            if (q.height > 1) vk::launch_bitrev_rows(c.stream, q.view(), nat.view());
-            else VG_HIP_CHECK(hipMemcpyAsync(nat.data, q.data, q.width * 4, hipMemcpyDeviceToDevice, c.stream));
+            if (q.height > 1 && !quot_is_natural[i]) vk::launch_bitrev_rows(c.stream, q.view(), nat.view());
+            else VG_HIP_CHECK(hipMemcpyAsync(nat.data, q.data, q.height * q.width * 4, hipMemcpyDeviceToDevice, c.stream));
             DBuf tmp(&c, (size_t)(q.height * q.width));
             vk::launch_export_rows(c.stream, nat.view(), 0, q.height, tmp.data);
             dbg->quotient_chunks[i].resize(q.height * q.width);
@@ -567,7 +573,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     std::unique_ptr<ProverData> quot_pd;
     {
         std::vector<CommitInput> in;
-        for (auto& m : quot) in.push_back({&m, true, true});
+        for (size_t i = 0; i < quot.size(); i++) in.push_back({&quot[i], !quot_is_natural[i], !quot_is_natural[i]});
         quot_pd = commit_batches(&c, in, &quot_shifts, fri_);
     }
     ch.observe_digest(quot_pd->tree.root);

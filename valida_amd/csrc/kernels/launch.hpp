@@ -19,7 +19,8 @@ struct QuotientArgs {
     uint32_t zh_inv[8];          // 1 / zh[r]
     uint32_t zh[8];              // Z_H on the 2^lqd cosets of the quotient domain: zh[r] = s^n w_Q^r - 1 for natural index = r mod 2^lqd
     uint32_t g_inv;              // g_n^{-1}  (subgroup_last)
-    DMatView out;                // n x (5 << lqd), row for natural i stored at position bitrev_k(i)
+    DMatView out;                // n x (5 << lqd), row for natural i stored at position bitrev_k(i) — or, out_natural (log_quotient_degree 1 only), at position i
+    int out_natural;             // the chunk matrix in NATURAL row order: the following commitment round extends it through the fused LDE (no bit-reversed input path)
     // BasicMachine chip whose eval template is compiled into a native kernel (vchips::ChipId), or INTERPRET for
     // the register-program interpreter (AIRs captured at run time through vgpu_air_*)
     static constexpr int INTERPRET = -2;

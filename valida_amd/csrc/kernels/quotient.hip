@@ -208,11 +208,18 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
 #ifndef VGPU_QUOT_TILE
 #define VGPU_QUOT_TILE 1  // 0: the linear map (A/B builds, tools/build_variant.py)
 #endif
-    if (VGPU_QUOT_TILE && a.log_n >= 9 && blockDim.x == 256) {
+    const bool tiled = VGPU_QUOT_TILE && a.log_n >= 9 && blockDim.x == 256;
+    // Natural-order output (out_natural): the tile is 16 groups (pair-index bits log_n-1 .. log_n-4: the same carry chain, closed 7 times of 8)
+    // x 16 consecutive low values, so that for a fixed low value the 16 groups are 16 CONSECUTIVE natural chunk rows
+    // (natural index = bitrev(m): its low four bits are the group bits): after an LDS transpose the rows leave in 64-byte runs.
+    const bool nat_tile = tiled && a.out_natural;
+    if (nat_tile) {
+        m = ((uint64_t)(threadIdx.x >> 4) << (a.log_n - 4)) | ((uint64_t)blockIdx.x << 4) | (threadIdx.x & 15u);
+    } else if (tiled) {
         const uint32_t B = blockIdx.x, top = B >> (a.log_n - 9), mid = B & ((1u << (a.log_n - 9)) - 1u);
         m = ((uint64_t)top << (a.log_n - 1)) | ((uint64_t)(threadIdx.x >> 5) << (a.log_n - 4)) | ((uint64_t)mid << 5) | (threadIdx.x & 31u);
     }
-    if (m >= n) return;  // no block-level synchronisation below: LDS slots are thread-private
+    if (m >= n) return;  // never in a tiled launch (log_n >= 9: whole workgroups); the register-file LDS slots are thread-private
     const int kq = a.log_n + 1;
     const uint32_t Qmask = (uint32_t)(2 * n - 1);
     const uint32_t j0 = (uint32_t)(2 * m), j1 = j0 + 1;
@@ -250,10 +257,25 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
     // decompose (App. B11): even = (a+b)/2, odd = (a-b)/(2 x0)
     Fp x0_inv = Fp::raw(a.coset_shift_inv) * inv_domain_point(tb, j0);
     Ext5 sum = q0 + q1, diff = (q0 - q1) * x0_inv;
+    if (nat_tile) {
+        // thread (group A, low r) holds chunk row i0 = bitrev4(r) << (log_n - 4) | bitrev(block) << 4 | bitrev4(A); it stages it at slot
+        // (r << 4) | bitrev4(A), and thread t then stores slot t = the row bitrev4(t >> 4) << (log_n - 4) | bitrev(block) << 4 | (t & 15):
+        // sixteen neighbouring lanes, sixteen consecutive rows
+        __shared__ uint32_t tr[10 * 256];
+        const uint32_t A = threadIdx.x >> 4, r = threadIdx.x & 15u, slot = (r << 4) | (__brev(A) >> 28);
+#pragma unroll
+        for (int c = 0; c < 5; c++) { tr[c * 256 + slot] = sum.c[c].halve().v; tr[(5 + c) * 256 + slot] = diff.c[c].halve().v; }
+        __syncthreads();
+        const uint64_t row = ((uint64_t)(__brev(A) >> 28) << (a.log_n - 4)) | ((uint64_t)(a.log_n > 8 ? __brev((uint32_t)blockIdx.x) >> (32 - (a.log_n - 8)) : 0u) << 4) | r;
+#pragma unroll
+        for (int c = 0; c < 10; c++) a.out.data[(uint64_t)c * a.out.stride + row] = tr[c * 256 + threadIdx.x];
+        return;
+    }
+    const uint64_t pos = a.out_natural ? (uint64_t)i0 : m;  // small heights: natural position directly
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        a.out.data[(uint64_t)c * a.out.stride + m] = sum.c[c].halve().v;
-        a.out.data[(uint64_t)(5 + c) * a.out.stride + m] = diff.c[c].halve().v;
+        a.out.data[(uint64_t)c * a.out.stride + pos] = sum.c[c].halve().v;
+        a.out.data[(uint64_t)(5 + c) * a.out.stride + pos] = diff.c[c].halve().v;
     }
 }
 
