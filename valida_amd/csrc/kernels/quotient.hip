@@ -413,7 +413,7 @@ void launch_quotient(hipStream_t st, const QuotientArgs& a_in, const DeviceTable
     const QuotientArgs a = a_in.normalised();  // one GPU: next rows from the same LDEs, 2^lqd further in natural index
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_quotient<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);  // 160 KiB minus the 10 KiB static transpose tile of the natural-order store
         (void)hipFuncSetAttribute((const void*)k_quotient_general<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
