@@ -301,27 +301,34 @@ def test_proof_cbor_matches_independent_encoder(flags):
 
 
 def test_committed_bench_line_follows_the_contract():
-    # profiles/r02_bench_full.json is the line bench.py printed on the MI355X: every field the driver reads is there
+    # profiles/r03_bench_full.json is the line bench.py printed on the MI355X in the round's profile session: every field the driver reads is there
     import json
 
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_bench_full.json")) as f:
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_bench_full.json")) as f:
         d = json.load(f)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["unit"] == "proofs/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["n_gpus"] == 1
+    assert d["unit"] == "proofs/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["n_gpus"] == 1
     assert "workload" in d["config"] and "model" not in d["config"] and d["dtype"] == "u32" and d["data"].startswith("synthetic")
     assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
-    assert "profiles/" in r["traffic_source"] and "not measured in this run" in r["traffic_source"]
+    # the binding roofline first (the dominant kernel is Keccak: integer VALU), the HBM figures of the contract under `hbm`
+    assert r["bound"] == "valu" and r["kernel"] == "k_keccak_compress" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    h = r["hbm"]
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9 and h["traffic"] is not None
+    assert "profiles/r03_pmc.json" in h["traffic_source"] and "not measured in this run" in h["traffic_source"]
+    assert abs(h["traffic"] / h["algorithmic_bytes_per_launch"] - 1.0) < 0.02  # no wasted re-reads in the dominant kernel
     v = d["valu_roofline"]
-    assert r["kernel"] == "k_keccak_compress" and v["kernel"] == r["kernel"] and v["microbench"].startswith("profiles/")
-    assert 0 < v["frac"] < 1 and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9
+    assert v["kernel"] == r["kernel"] and v["microbench"].startswith("profiles/") and abs(v["frac"] - r["frac"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "proofs/s" and "sample" in c
     assert "2^20 cpu rows" in c["sample"] and "scaled" not in c["sample"]  # the headline segment itself, no extrapolation
-    assert d["value"] / c["value"] > 20  # north star: >= 20x the CPU baseline (a port, not Plonky3: see DESIGN.md)
+    # no published number exists: vs_baseline is the ratio to the CPU baseline of the SAME run and says so
+    assert abs(d["vs_baseline"] - d["value"] / c["value"]) < 1e-6 * d["vs_baseline"] and "kind: port" in d["vs_baseline_is"] and d["vs_baseline"] > 20
+    assert d["proof_checked_by_vgpu_verify"]["accepted"] is True
+    p = d["pcie_inclusive"]
+    assert p["value"] < d["value"] and p["from_pinned_host_memory"]["value"] < d["value"] * 1.02  # the host-resident readings, beside the headline
 
 
 def test_bench_reads_its_valu_peaks_from_the_committed_microbench_report():
