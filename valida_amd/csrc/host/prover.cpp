@@ -311,11 +311,13 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
                                     PhaseTimes* times, ProveDebugOut* dbg) {
     DeviceCtx& c = *ctx_;
     c.activate();
-    struct Running {  // one proof at a time per context: its streams, pool sections and pinned buffers are not shared
+    // one proof at a time per context: a second caller (another thread's vgpu_prove, the worker of a second vgpu_prove_async) waits here
+    // until the running proof has finished — the calls are served one after the other, none is refused
+    std::unique_lock<std::mutex> one_at_a_time(c.prove_mu);
+    c.activate();
+    struct Running {  // lets uploads of another thread know that the context's main stream is owned (DeviceCtx::upload_beside_proof)
         std::atomic<int>& n;
-        explicit Running(std::atomic<int>& a) : n(a) {
-            if (n.fetch_add(1) != 0) { n.fetch_sub(1); throw std::invalid_argument("prove: another proof is already running on this prover context (wait for its ticket first)"); }
-        }
+        explicit Running(std::atomic<int>& a) : n(a) { n.fetch_add(1); }
         ~Running() { n.fetch_sub(1); }
     } running(c.proofs_running);
     const size_t NC = machine_.airs.size();

@@ -59,6 +59,9 @@ struct DeviceCtx {
     // Uploads handed in by a caller thread WHILE a proof owns the main stream (a host that prepares segment i+1 during proof i):
     // a stream of their own, created on first use, so the copy neither queues behind the proof's kernels nor shares its waits.
     std::atomic<int> proofs_running{0};
+    // One proof at a time per context (its streams, pool sections and pinned buffers are not shared): callers QUEUE on this mutex — the
+    // reference's `Machine: Sync` (machine/src/machine.rs:13) lets several threads call prove on one machine, and so may a host here.
+    std::mutex prove_mu;
     std::mutex upload_mu;
     hipStream_t upload_stream = nullptr;
     hipEvent_t upload_ev = nullptr;

@@ -145,15 +145,18 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             throw std::invalid_argument("sharded prove: the ranks' prover contexts must share one configuration");
         if (in[k].main.size() != NC) throw std::invalid_argument("sharded prove: need one main trace per chip and rank");
     }
+    // every hosted context for the whole proof; a context that is busy with another proof is not waited for (a sharded proof holds several
+    // contexts at once: waiting in some order on each could deadlock two such calls) — the call is refused
     struct Running {
-        std::vector<std::atomic<int>*> held;
-        void take(std::atomic<int>& a) {
-            if (a.fetch_add(1) != 0) { a.fetch_sub(1); throw std::invalid_argument("sharded prove: another proof is already running on one of the prover contexts"); }
-            held.push_back(&a);
+        std::vector<DeviceCtx*> held;
+        void take(DeviceCtx& c) {
+            if (!c.prove_mu.try_lock()) throw std::invalid_argument("sharded prove: another proof is already running on one of the prover contexts");
+            c.proofs_running.fetch_add(1);
+            held.push_back(&c);
         }
-        ~Running() { for (auto* a : held) a->fetch_sub(1); }
+        ~Running() { for (auto* c : held) { c->proofs_running.fetch_sub(1); c->prove_mu.unlock(); } }
     } running;
-    for (auto& R : rk) running.take(R.c->proofs_running);
+    for (auto& R : rk) running.take(*R.c);
 
     // the sub-coset of rank `R` inside a domain of 2^logL points: generator power w_L^e
     auto rho_of = [&](const Rank& R, unsigned logL) { return vg::two_adic_generator(logL).pow((uint64_t)R.e); };
