@@ -88,9 +88,24 @@ def timeline(db_path, out_txt, header):
         f.write("largest gaps: gap_us  after_kernel -> before_kernel  (at_us from the start of the proof)\n")
         for g_, a_, b_, at_ in sorted(big, reverse=True)[:40]:
             f.write("  %8.1f  %-22s -> %-22s  (%.0f)\n" % (g_ / 1e3, a_, b_, at_))
-        f.write("kernel launches total_us avg_us\n")
+        # exclusive time: how long a kernel class ran with NO other kernel on the GPU — what shortening that class would take off the
+        # proof's latency (kernels on the auxiliary stream hidden behind a big launch have none)
+        ev = []
+        for n_, s_, e_ in seg:
+            ev.append((s_, 1, short(n_)))
+            ev.append((e_, -1, short(n_)))
+        ev.sort(key=lambda x: (x[0], x[1]))
+        active, excl, last = {}, {}, ev[0][0]
+        for t_, d_, n_ in ev:
+            if t_ > last:
+                live = [k for k, c in active.items() if c > 0]
+                if len(live) == 1 and active[live[0]] == 1:
+                    excl[live[0]] = excl.get(live[0], 0) + (t_ - last)
+                last = t_
+            active[n_] = active.get(n_, 0) + d_
+        f.write("kernel launches total_us avg_us exclusive_us\n")
         for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
-            f.write("%-28s %5d %10.1f %8.1f\n" % (k, n, t / 1e3, t / 1e3 / n))
+            f.write("%-28s %5d %10.1f %8.1f %10.1f\n" % (k, n, t / 1e3, t / 1e3 / n, excl.get(k, 0) / 1e3))
 
 
 def counters(db_path):
