@@ -226,7 +226,12 @@ def main():
     # stuck, nothing the job still has to say to itself may travel through RCCL on the same device — the abandoned rendezvous could
     # interfere with it or deadlock it — so after a stuck bring-up EVERY collective of the job (roots, barriers, the final MAX) uses this
     # group and host tensors, and the line says so ("comm_stuck").
-    ctl = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
+    ctl = None
+    if world > 1 and backend == "nccl":
+        try:
+            ctl = dist.new_group(backend="gloo")
+        except Exception as e:  # noqa: BLE001 - without it the control plane stays on the default group, as before round 3
+            print("bench: no gloo control group (%s: %s); control messages use the default group" % (type(e).__name__, e), file=sys.stderr, flush=True)
     coll_group = None
 
     rc = va.poseidon_round_constants()
@@ -301,7 +306,8 @@ def main():
         dist.all_gather_object(gathered, (lib_comm is not None, comm_stuck), group=ctl)
         if any(g[1] for g in gathered):  # some rank left a thread inside the rendezvous: no RCCL traffic of any kind from here on
             comm_stuck = True
-            coll_group, coll_device = ctl, torch.device("cpu")
+            if ctl is not None:
+                coll_group, coll_device = ctl, torch.device("cpu")
         if not all(g[0] for g in gathered):  # all ranks take the same route
             lib_comm = None
             if "failed" not in comm_note:
