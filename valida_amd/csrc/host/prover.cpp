@@ -721,10 +721,26 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         for (auto& w : wlist) { w.pool_off = pool.size(); put_min_poly(pool, w.z); }
         pool.push_back(0);
         DBuf pool_dev(&c, pool);
-        for (auto& w : wlist) {
-            uint64_t n = 1ull << w.log_n;
-            w.buf = DBuf(&c, (size_t)vk::bary_buffer_words(n));
-            vk::launch_bary_weights(c.stream, n, pool_dev.data + w.pool_off, s, c.tables, w.buf.data);
+        {   // every weight vector of the opening in one launch
+            std::vector<uint32_t> jobs;
+            uint32_t blocks = 0;
+            double rows = 0;
+            for (auto& w : wlist) {
+                const uint64_t n = 1ull << w.log_n;
+                w.buf = DBuf(&c, (size_t)vk::bary_buffer_words(n));
+                jobs.push_back(blocks); jobs.push_back(0);
+                put_u64(jobs, n);
+                put_ptr(jobs, pool_dev.data + w.pool_off);
+                put_ptr(jobs, w.buf.data);
+                put_ptr(jobs, vk::bary_weights_has_image(n) ? w.buf.data + 5 * n : nullptr);
+                blocks += vk::bary_weights_blocks(n);
+                rows += (double)n;
+            }
+            if (!wlist.empty()) {
+                DBuf jobs_dev(&c, jobs);
+                vk::launch_bary_weights_batch(c.stream, jobs_dev.data, (uint32_t)wlist.size(), blocks, rows, s, c.tables);
+                // jobs_dev returns to the pool while the launch is queued: safe, the pool hands a block only to work enqueued later on this stream
+            }
         }
         DBuf out_dev(&c, out_words + 4);
         std::vector<DBuf> partials;

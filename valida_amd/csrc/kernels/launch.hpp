@@ -106,6 +106,10 @@ void launch_tracegen_output(hipStream_t st, const TgOutOp* vals, const uint32_t*
 hipError_t launch_tracegen_program(hipStream_t st, const TgCpuOp* ops, uint64_t n, uint64_t padded_n, uint32_t rom_len, uint32_t* counts, DMatView t);
 // open.hip
 void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* min_poly_dev, Fp shift, const DeviceTables& tb, uint32_t* w);
+// the same for several (height, point) pairs in one launch: job = { first block (u32), pad, n (u64), min-poly pointer, weight buffer, digit-plane image (or null) }
+void launch_bary_weights_batch(hipStream_t st, const uint32_t* jobs_dev, uint32_t n_jobs, uint32_t total_blocks, double total_rows, Fp shift, const DeviceTables& tb);
+uint32_t bary_weights_blocks(uint64_t n);
+bool bary_weights_has_image(uint64_t n);
 uint64_t col_dot_slots(uint64_t n);
 uint64_t bary_buffer_words(uint64_t n);  // words of a weight vector launch_bary_weights fills (launch_col_dot takes such buffers)
 uint64_t col_dot_max_columns(int np);  // widest matrix (view) one k_col_dot launch takes for np points; wider ones are opened in column chunks

@@ -37,8 +37,10 @@ template <bool PAD> __device__ __forceinline__ int tile_addr(int i, int c, int L
 #ifndef VGPU_NTT_LAZY
 #define VGPU_NTT_LAZY 1  // 0: every butterfly output fully reduced (A/B builds)
 #endif
+// `held`: the round's 2^R - 1 twiddles already in registers, in load order (stage st at offset 2^st - 1) — a persistent block whose
+// work items sit at the same tile position for every tile loads them once (k_lde_mid12's outer rounds)
 template <int R, bool DIT, bool LB0>
-__device__ __forceinline__ void butterflies(Fp (&x)[1 << R], const uint32_t* tw, int low, int lowbits) {
+__device__ __forceinline__ void butterflies(Fp (&x)[1 << R], const uint32_t* tw, int low, int lowbits, const Fp* held = nullptr) {
     constexpr int G = 1 << R;
 #pragma unroll
     for (int step = 0; step < R; step++) {
@@ -48,7 +50,7 @@ __device__ __forceinline__ void butterflies(Fp (&x)[1 << R], const uint32_t* tw,
         Fp wv[G / 2];
 #pragma unroll
         for (int k = 0; k < G / 2; k++)
-            if (k < half && !(LB0 && k == 0)) wv[k] = Fp::raw(t[k << lowbits]);
+            if (k < half && !(LB0 && k == 0)) wv[k] = held ? held[half - 1 + k] : Fp::raw(t[k << lowbits]);
 #pragma unroll
         for (int p = 0; p < G / 2; p++) {
             const int g0 = ((p >> st) << (st + 1)) | (p & (half - 1)), g1 = g0 | half;
@@ -76,6 +78,16 @@ __device__ __forceinline__ void butterflies(Fp (&x)[1 << R], const uint32_t* tw,
 #pragma unroll
     for (int g = 0; g < G; g++) if (x[g].v >= vg::P) { fprintf(stderr, "butterflies: unreduced value leaves the round\n"); abort(); }
 #endif
+}
+
+template <int R>
+__device__ __forceinline__ void load_round_twiddles(Fp (&held)[(1 << R) - 1], const uint32_t* tw, int low, int lowbits) {
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const uint32_t* t = tw + ((1 << (lowbits + st)) - 1) + low;
+#pragma unroll
+        for (int k = 0; k < (1 << st); k++) held[(1 << st) - 1 + k] = Fp::raw(t[k << lowbits]);
+    }
 }
 
 template <int R, bool DIT, bool PAD, int LB>
@@ -507,6 +519,19 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
     const uint64_t N = 1ull << k, tiles_per_col = (uint64_t)n_hi, total = tiles_per_col * src.width;
     const uint32_t nmask = (uint32_t)(N - 1);
     auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return src.col(cidx) + (t - cidx * tiles_per_col) * N_LO; };
+#ifndef VGPU_MID12_TWREG
+#define VGPU_MID12_TWREG 1  // the twiddles of the two outer rounds (stages 9 .. 12: they depend on the thread, not on the tile) held in registers
+#endif
+#if VGPU_MID12_TWREG
+    Fp tw_in[15], tw_out[15];
+    load_round_twiddles<4>(tw_in, tb.itwc, tid, 8);
+    load_round_twiddles<4>(tw_out, tb.twc, tid, 8);
+    const Fp* const held_in = tw_in;
+    const Fp* const held_out = tw_out;
+#else
+    const Fp* const held_in = nullptr;
+    const Fp* const held_out = nullptr;
+#endif
 #if VGPU_MID12_PREFETCH
     uint32_t pre[16];
     if (blockIdx.x < total) {
@@ -534,7 +559,7 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
         }
 #endif
         // inverse, stages 12 .. 9 on the points tid + 256 g (DIF, inverse roots)
-        butterflies<4, false, false>(x, tb.itwc, tid, 8);
+        butterflies<4, false, false>(x, tb.itwc, tid, 8, held_in);
         {
             uint32_t* p0 = lds + tile_addr<true>(tid, 0, 0);
 #pragma unroll
@@ -572,7 +597,7 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
 #pragma unroll
                 for (int g = 0; g < 16; g++) y[g] = Fp::raw(p0[g * 272]);
             }
-            butterflies<4, true, false>(y, tb.twc, tid, 8);  // stages 9 .. 12: y[g] = the evaluation f_b = tid + 256 g of this block
+            butterflies<4, true, false>(y, tb.twc, tid, 8, held_out);  // stages 9 .. 12: y[g] = the evaluation f_b = tid + 256 g of this block
             uint32_t* out = dst.col(cidx) + (uint64_t)tc * N + p * N_LO + tid;
             Fp cur = Fp::raw(lt.sig[(size_t)tc * n_hi + ca]) * tw0;  // sigma_t^c_a w_N^(c_a q), q = tid + 256 g
 #pragma unroll

@@ -23,9 +23,9 @@ namespace vk {
 constexpr int BARY_ROWS = 4;
 // For n >= MFMA_DOT_MIN_ROWS the kernel also writes the weights as k_col_dot_mfma's A operand (`img`, see there): 7-bit digit planes, four rows
 // to a word, laid out so that a lane of that kernel fetches its four operand registers of a plane with one 16-byte load.
-__global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t* __restrict__ mg, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ w,
-                                                      uint32_t* __restrict__ img) {
-    const uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * BARY_ROWS;
+__device__ __forceinline__ void bary_weights_block(uint64_t block, uint64_t n, const uint32_t* __restrict__ mg, uint32_t shift, const DeviceTables& tb, uint32_t* __restrict__ w,
+                                                   uint32_t* __restrict__ img) {
+    const uint64_t j0 = (block * blockDim.x + threadIdx.x) * BARY_ROWS;
     if (j0 >= n) return;
     const uint32_t* g = mg + 5;
     Fp r[BARY_ROWS], mx[BARY_ROWS], pre[BARY_ROWS];
@@ -74,6 +74,21 @@ __global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t
 #pragma unroll
         for (int q = 0; q < BARY_ROWS; q++) if (j0 + q < n) store_ext(w, n, j0 + q, res[q]);
     }
+}
+
+__global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t* __restrict__ mg, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ w,
+                                                      uint32_t* __restrict__ img) {
+    bary_weights_block(blockIdx.x, n, mg, shift, tb, w, img);
+}
+// All weight vectors of an opening in ONE launch: a proof needs one per (height, point) — seventeen for the BasicMachine, most of them a handful
+// of blocks — and as launches of their own they sit one after the other at the head of the opening phase (0.27 ms of a lone proof with
+// nothing else on the GPU).  jobs: n_jobs x { first block, n (u64), mg pointer (u64), w pointer (u64), img pointer (u64) }, first blocks ascending.
+struct BaryJob { uint32_t first_block, pad; uint64_t n; const uint32_t* mg; uint32_t* w; uint32_t* img; };
+__global__ void __launch_bounds__(256) k_bary_weights_batch(const BaryJob* __restrict__ jobs, uint32_t n_jobs, uint32_t shift, DeviceTables tb) {
+    uint32_t lo = 0, hi = n_jobs - 1;  // the job of this block: the last one whose first block is <= blockIdx.x (block-uniform)
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (jobs[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1; }
+    const BaryJob j = jobs[lo];
+    bary_weights_block(blockIdx.x - j.first_block, j.n, j.mg, shift, tb, j.w, j.img);
 }
 
 // ---- column dot products --------------------------------------------------------------------------
@@ -561,6 +576,14 @@ void launch_bary_weights(hipStream_t st, uint64_t n, const uint32_t* min_poly_de
     const uint64_t threads = (n + BARY_ROWS - 1) / BARY_ROWS;
     VK_LAUNCH(k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n, min_poly_dev, shift.v, tb, w, n >= MFMA_DOT_MIN_ROWS ? w + 5 * n : (uint32_t*)nullptr);
 }
+// jobs_dev: the job table on the device (5 x u64 words per job as BaryJob lays them out); total_blocks = sum of the jobs' blocks
+void launch_bary_weights_batch(hipStream_t st, const uint32_t* jobs_dev, uint32_t n_jobs, uint32_t total_blocks, double total_rows, Fp shift, const DeviceTables& tb) {
+    if (!n_jobs) return;
+    ProfScope ps("k_bary_weights", st, 20.0 * total_rows);
+    VK_LAUNCH(k_bary_weights_batch, dim3(total_blocks), dim3(256), 0, st, (const BaryJob*)jobs_dev, n_jobs, shift.v, tb);
+}
+uint32_t bary_weights_blocks(uint64_t n) { return (uint32_t)(((n + BARY_ROWS - 1) / BARY_ROWS + 255) / 256); }
+bool bary_weights_has_image(uint64_t n) { return n >= MFMA_DOT_MIN_ROWS; }
 uint64_t col_dot_slots(uint64_t n) {
     if (n >= MFMA_DOT_MIN_ROWS) return n / mfma_dot_chunk_rows(n);
     uint64_t tiles = (n + DOT_TR - 1) / DOT_TR;
