@@ -62,7 +62,8 @@ def test_unfused_passes_under_emulation_match_the_oracle(emu, k, w, log_blowup, 
 
 
 def test_the_2_14_point_tiles_of_the_largest_heights(emu):
-    """Heights from 2^23 use 2^14-point contiguous tiles (1024 threads, 139 KiB of LDS in k_lde_mid): one column of 2^23 rows."""
+    """Heights from 2^23 use 2^14-point contiguous tiles (k_lde_mid14: 1024 threads x 16 points, the outer radix-4 rounds straight from / to HBM): one column of 2^23 rows."""
     rng = np.random.default_rng(323)
     m = np.ascontiguousarray(rng.integers(0, P, (1 << 23, 1), dtype=np.uint32))
     assert np.array_equal(run(emu.emu_lde_natural, m, 1, 31), po.committed_lde(m, 1, 31))
+    assert np.array_equal(run(emu.emu_lde_natural, m, 2, 961), po.committed_lde(m, 2, 961))  # four cosets (C3's blowup), a shifted coset

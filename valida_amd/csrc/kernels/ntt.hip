@@ -607,6 +607,75 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
     }
 }
 
+// ---- pass B for 2^14-point tiles (heights from 2^23: C3's memory chip): the same fusion with one more, radix-4, round at the outer end of each
+// transform (stages 14, 13).  1024 threads x 16 points; a thread's prefetched element tid + 1024 u is point g = u >> 2 of its outer-round
+// item j = u & 3 (points tid + 1024 j + 4096 g).  One LDS tile (70 KiB) instead of the generic kernel's two; 128 registers (one workgroup per CU).
+__global__ void __launch_bounds__(1024) k_lde_mid14(DMatView src, DMatView dst, int k, int lb, DeviceTables tb, LdeTables lt) {
+    extern __shared__ uint32_t lds[];
+    constexpr int K_LO = 14, N_LO = 1 << K_LO, NT = 1024;
+    const int k_hi = k - K_LO, n_hi = 1 << k_hi, b = 1 << lb, tid = threadIdx.x;
+    const uint64_t N = 1ull << k, tiles_per_col = (uint64_t)n_hi, total = tiles_per_col * src.width;
+    const uint32_t nmask = (uint32_t)(N - 1);
+    for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint64_t cidx = t / tiles_per_col, p = t - cidx * tiles_per_col;
+        const uint32_t* sp = src.col(cidx) + p * N_LO;
+        // inverse, stages 14 and 13 (DIF, inverse roots), straight from the global loads
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int w = tid + NT * j;
+            Fp x4[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) x4[g] = Fp::raw(sp[w + 4096 * g]);
+            butterflies<2, false, false>(x4, tb.itwc, w, 12);
+#pragma unroll
+            for (int g = 0; g < 4; g++) lds[tile_addr<true>(w + 4096 * g, 0, 0)] = x4[g].v;
+        }
+        __syncthreads();
+        ntt_round<4, false, true, 8>(lds, tb.itwc, 14, 9, 0, 0);  // stages 12 .. 9
+        ntt_round<4, false, true, 4>(lds, tb.itwc, 14, 5, 0, 0);  // stages 8 .. 5
+        Fp x[16];
+        {
+            const uint32_t* p0 = lds + 17 * tid;  // positions 16 tid + g
+#pragma unroll
+            for (int g = 0; g < 16; g++) x[g] = Fp::raw(p0[g]);
+        }
+        butterflies<4, false, true>(x, tb.itwc, 0, 0);  // stages 4 .. 1: N times the coefficient with c_b = bitrev(16 tid + g)
+        const uint32_t ca = k_hi ? __brev((uint32_t)p) >> (32 - k_hi) : 0u;
+        const Fp step = root_pow(tb, k, (ca * 4096u) & nmask);
+        for (int tc = 0; tc < b; tc++) {
+            Fp y[16];
+            {
+                const uint32_t* fac = lt.fac + (size_t)tc * N_LO + 16 * tid;
+#pragma unroll
+                for (int g = 0; g < 16; g++) y[g] = x[g] * Fp::raw(fac[g]);
+            }
+            butterflies<4, true, true>(y, tb.twc, 0, 0);  // forward, stages 1 .. 4
+            {
+                uint32_t* p0 = lds + 17 * tid;  // the thread's own positions (see k_lde_mid12)
+#pragma unroll
+                for (int g = 0; g < 16; g++) p0[g] = y[g].v;
+            }
+            __syncthreads();
+            ntt_round<4, true, true, 4>(lds, tb.twc, 14, 5, 0, 0);  // stages 5 .. 8
+            ntt_round<4, true, true, 8>(lds, tb.twc, 14, 9, 0, 0);  // stages 9 .. 12
+            uint32_t* out = dst.col(cidx) + (uint64_t)tc * N + p * N_LO;
+            const Fp sg = Fp::raw(lt.sig[(size_t)tc * n_hi + ca]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {  // stages 13 and 14, then sigma_t^c_a w_N^(c_a q) and out: q = w + 4096 g
+                const int w = tid + NT * j;
+                Fp y4[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) y4[g] = Fp::raw(lds[tile_addr<true>(w + 4096 * g, 0, 0)]);
+                butterflies<2, true, false>(y4, tb.twc, w, 12);
+                Fp cur = sg * root_pow(tb, k, (ca * (uint32_t)w) & nmask);
+#pragma unroll
+                for (int g = 0; g < 4; g++) { out[w + 4096 * g] = (y4[g] * cur).v; cur *= step; }
+            }
+            __syncthreads();  // the tile is free for the next coset / the next tile
+        }
+    }
+}
+
 // ---- pass C: forward, strided, transposing store: grid = (n_lo / T, columns, cosets) --------------------
 __global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int logT, DeviceTables tb) {
     extern __shared__ uint32_t lds[];
@@ -681,6 +750,7 @@ static void set_lds_limit() {
     (void)hipFuncSetAttribute((const void*)k_lde_mid, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_c, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_mid12, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_mid14, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     done = true;
 }
 
@@ -757,11 +827,15 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
         VK_LAUNCH(k_lde_a, gs, dim3(p.threads_strided), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
     }
     static const bool mid12 = [] { const char* e = getenv("VGPU_LDE_MID12"); return !(e && e[0] == '0'); }();
+    static const bool mid14 = [] { const char* e = getenv("VGPU_LDE_MID14"); return !(e && e[0] == '0'); }();
     if (p.k_lo == 12 && mid12) {
         static const unsigned cap = [] { const char* e = getenv("VGPU_MID12_GRID"); return e ? (unsigned)atoi(e) : 4096u; }();  // persistent blocks (A/B)
         if (cap && gm.x > cap) gm.x = cap;
         ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
         VK_LAUNCH(k_lde_mid12, gm, dim3(256), (size_t)padded_words(4096) * 4, st, s1, s2, k, log_blowup, tb, lt);
+    } else if (p.k_lo == 14 && mid12 && mid14) {
+        ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
+        VK_LAUNCH(k_lde_mid14, gm, dim3(1024), (size_t)padded_words(16384) * 4, st, s1, s2, k, log_blowup, tb, lt);
     } else {
         ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
         VK_LAUNCH(k_lde_mid, gm, dim3(p.threads_contig), lds_mid, st, s1, s2, k, p.k_lo, log_blowup, tb, lt);
