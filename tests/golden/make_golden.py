@@ -69,6 +69,8 @@ def make_full(out_dir, which):
         make(599183, "full_c3_fib599183_blowup4.json", 2, out_dir, debug_check=False)
     if "c2p" in which:  # the configuration `bench.py --mmcs poseidon` times
         make(149794, "full_c2_fib149794_poseidon.json", 1, out_dir, debug_check=False, hash_kind=1)
+    if "c4p" in which:  # BASELINE.json configs[3] to the letter: the ALU / range-check heavy program with the Poseidon Merkle tree (`--workload c4 --mmcs poseidon`)
+        make(("alu", 116507), "full_c4_alu116507_poseidon.json", 1, out_dir, debug_check=False, hash_kind=1)
 
 
 if __name__ == "__main__":

@@ -305,6 +305,14 @@ def test_full_size_c2_poseidon_mmcs(machine, rc, poseidon_oracle):
     _full_size_round_trip(va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16), w, rc, 1, golden="full_c2_fib149794_poseidon.json", oracle_words=False)
 
 
+def test_full_size_c4_alu_2_20_poseidon_mmcs(machine, rc, poseidon_oracle):
+    # BASELINE.json configs[3] to the letter: "alu_u32 + range-check heavy synthetic program, 2^20 rows (multi-chip quotient + Poseidon Merkle)":
+    # C4's program committed with the Poseidon-16 MMCS (`bench.py --workload c4 --mmcs poseidon`), every word pinned by the oracle's proof
+    w = va.Workload.alu(116507)
+    assert _golden_full("full_c4_alu116507_poseidon.json") is not None
+    _full_size_round_trip(va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16), w, rc, 1, golden="full_c4_alu116507_poseidon.json", oracle_words=False)
+
+
 def test_c3_shape_at_2_18_blowup4_every_word(machine, rc):
     # C3's configuration (4x blowup) at cpu 2^18 / mem 2^20 rows: every proof word against the oracle
     w = va.Workload.fib(37446)

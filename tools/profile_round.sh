@@ -28,6 +28,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o run -- $P > "$O
 python $ROOT/bench.py > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"
 for w in c3 c4; do $B --workload $w --steps 6 --warmup 2 > "$OUT/bench_$w.json" 2> /dev/null; done
 $B --mmcs poseidon --steps 4 --warmup 1 > "$OUT/bench_poseidon.json" 2> "$OUT/bench_poseidon.err"
+# BASELINE.json configs[3] to the letter: the ALU / range-check heavy program with the Poseidon Merkle tree
+$B --workload c4 --mmcs poseidon --steps 4 --warmup 1 > "$OUT/bench_c4_poseidon.json" 2> /dev/null
 # summarise here: the databases are too big to be copied back, the summaries are not
 cd "$ROOT" && python tools/summarize_prof.py "$TAG" "$OUT/summary" && rm -rf "$OUT"/stats1 "$OUT"/stats2 "$OUT"/pmc_valu "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_busy
 ls "$OUT/summary"

@@ -139,7 +139,7 @@ def main():
             timeline(p, os.path.join(dst, "%s_timeline_inflight1.txt" % tag), "rocprofv3 --kernel-trace -- python bench.py --no-cpu-baseline --no-extra-legs --inflight 1 --steps 10 --warmup 1   (MI355X)")
         except sqlite3.Error as e:
             print("timeline failed:", e)
-    for f in ("bench_default.json", "bench_inflight1.json", "bench_full.json", "bench_c3.json", "bench_c4.json", "bench_poseidon.json", "stats1.json", "stats2.json"):
+    for f in ("bench_default.json", "bench_inflight1.json", "bench_full.json", "bench_c3.json", "bench_c4.json", "bench_poseidon.json", "bench_c4_poseidon.json", "stats1.json", "stats2.json"):
         p = os.path.join(src, f)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, f)))
