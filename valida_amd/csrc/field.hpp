@@ -80,11 +80,19 @@ VG_HD uint32_t reduce_once(uint32_t s) { uint32_t t = s - P; return s < t ? s : 
 VG_HD uint32_t sub_mod(uint32_t a, uint32_t b) { uint32_t d = a - b, t = d + P; return d < t ? d : t; }  // d wraps to a huge value when a < b
 #endif
 
+#ifndef VG_MONTY_ADD
+#define VG_MONTY_ADD 0
+#endif
 VG_HD uint32_t monty_reduce(uint64_t t) {
+#if VG_MONTY_ADD == 1  // additive form (A/B builds, see above): t + m p has a zero low word and a high word in [0, 2p)
+    const uint32_t m = (uint32_t)t * P_INV_NEG;
+    return reduce_once((uint32_t)((t + (uint64_t)m * P) >> 32));
+#else
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
     uint32_t m = lo * 0x88000001u;         // lo * p^{-1} mod 2^32
     uint32_t u = mul_hi_u32(m, P);         // (m * p) >> 32 ; low word of m*p equals lo
     return sub_mod(hi, u);                 // hi - u in (-p, p)
+#endif
 }
 
 // Montgomery reduction of a lazily accumulated sum of up to FOUR products of values < p
@@ -111,7 +119,15 @@ struct Fp {
     VG_HD Fp operator+(const Fp& o) const { return raw(reduce_once(v + o.v)); }
     VG_HD Fp operator-(const Fp& o) const { return raw(sub_mod(v, o.v)); }
     VG_HD Fp operator-() const { return raw(v ? P - v : 0); }
+#if VG_MONTY_ADD == 2 && defined(__HIP_DEVICE_COMPILE__)  // A/B: the product through v_mul_lo_u32 + v_mul_hi_u32 instead of one v_mad_u64_u32
+    VG_HD Fp operator*(const Fp& o) const {
+        uint32_t lo, hi;
+        asm("v_mul_lo_u32 %0, %2, %3\n\tv_mul_hi_u32 %1, %2, %3" : "=&v"(lo), "=v"(hi) : "v"(v), "v"(o.v));
+        return raw(sub_mod(hi, mul_hi_u32(lo * 0x88000001u, P)));
+    }
+#else
     VG_HD Fp operator*(const Fp& o) const { return raw(monty_reduce((uint64_t)v * o.v)); }
+#endif
     VG_HD Fp& operator+=(const Fp& o) { *this = *this + o; return *this; }
     VG_HD Fp& operator-=(const Fp& o) { *this = *this - o; return *this; }
     VG_HD Fp& operator*=(const Fp& o) { *this = *this * o; return *this; }
