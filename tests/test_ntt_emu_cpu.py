@@ -23,7 +23,7 @@ def emu():
     out = os.path.join(ROOT, "build", "libnttemu.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     deps = [src, os.path.join(ROOT, "tools", "hipemu", "hip", "hip_runtime.h")] + [
-        os.path.join(ROOT, "valida_amd", "csrc", "kernels", f) for f in ("ntt.hip", "launch.hpp", "device_common.hpp", "profiler.hpp")] + [
+        os.path.join(ROOT, "valida_amd", "csrc", "kernels", f) for f in ("ntt.hip", "butterfly.hpp", "launch.hpp", "device_common.hpp", "profiler.hpp")] + [
         os.path.join(ROOT, "valida_amd", "csrc", "field.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", os.path.join(ROOT, "tools", "hipemu"), src, "-o", out], check=True)

@@ -126,6 +126,9 @@ inline unsigned __brev(unsigned x) {
     return (x >> 16) | (x << 16);
 }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+struct uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline void __threadfence_block() {}
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) hipemu::launch(grid, block, lds, [=]() { kernel(__VA_ARGS__); })
 #define hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, e0, e1, flags, ...) hipemu::launch(grid, block, lds, [=]() { kernel(__VA_ARGS__); })

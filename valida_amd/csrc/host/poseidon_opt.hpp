@@ -10,6 +10,7 @@
 // merged into the constants of the full round that follows.  Identical outputs by construction; the constructor checks it on
 // random states against the plain permutation and the kernels fall back to the plain form if a block D^ is singular.
 #pragma once
+#include <cstring>
 #include <vector>
 #include "challenger.hpp"
 
@@ -21,7 +22,12 @@ struct PoseidonOptTables {
     static constexpr int T_SCALARS = RC_FULL + 128;   // [22 (+2 pad)]: t_0 .. t_21
     static constexpr int SPARSE = T_SCALARS + 24;     // [21][32]: a, u[1..15], w[1..15], pad
     static constexpr int F_DENSE = SPARSE + 21 * 32;  // [16][16] row-major
-    static constexpr int WORDS = F_DENSE + 256;
+    // the MDS layer of the FULL rounds as a 16-point cyclic convolution (CosetMds<16> is circulant: y_j = sum_i c[(j - i) & 15] x_i):
+    // y = iDFT(lambda . DFT(x)), lambda = DFT(c) / 16 — 50 products and 128 additions instead of 256 products (butterfly.hpp)
+    static constexpr int FFT_FWD = F_DENSE + 256;     // [15 (+1 pad)]: stage s = 1..4 at offset 2^(s-1) - 1: w_{2^s}^j, j < 2^(s-1)
+    static constexpr int FFT_INV = FFT_FWD + 16;      // the same with w^-j
+    static constexpr int FFT_LAM = FFT_INV + 16;      // [16]: lambda in bit-reversed order (the order the DIF transform leaves)
+    static constexpr int WORDS = FFT_LAM + 16;
     std::vector<uint32_t> words;
     bool valid = false;
 
@@ -90,6 +96,20 @@ struct PoseidonOptTables {
             tau[0] = Fp::zero();
             for (int a = 1; a < 16; a++) tau[a] = mt[a];
         }
+        {   // the convolution form of the MDS layer
+            for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) if (M[j][i] != M[(j - i) & 15][0]) return;  // not circulant: plain rounds
+            const Fp w16 = vg::two_adic_generator(4), inv16 = Fp::from_canonical(16).inv();
+            for (int st = 0; st < 4; st++) {
+                const Fp ws = w16.pow((uint64_t)(16 >> (st + 1))), wsi = ws.inv();
+                for (int k = 0; k < (1 << st); k++) { words[FFT_FWD + (1 << st) - 1 + k] = ws.pow((uint64_t)k).v; words[FFT_INV + (1 << st) - 1 + k] = wsi.pow((uint64_t)k).v; }
+            }
+            for (int i = 0; i < 16; i++) {
+                const int k = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+                Fp acc = Fp::zero();
+                for (int d = 0; d < 16; d++) acc += M[d][0] * w16.pow((uint64_t)(d * k));
+                words[FFT_LAM + i] = (acc * inv16).v;
+            }
+        }
         valid = true;
         // self-check against the plain permutation
         uint64_t seed = 0x9E3779B97F4A7C15ull;
@@ -102,11 +122,23 @@ struct PoseidonOptTables {
         }
     }
 
+    // the MDS layer from the convolution tables, by the definition of the transforms (the kernels run the butterfly network of butterfly.hpp)
+    void mds_convolution(Fp* st) const {
+        const Fp w16 = vg::two_adic_generator(4), w16i = w16.inv();
+        Fp X[16];
+        for (int i = 0; i < 16; i++) {  // X[i] = lambda_k DFT(x)_k, k = bitrev(i)
+            const int k = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+            Fp acc = Fp::zero();
+            for (int j = 0; j < 16; j++) acc += st[j] * w16.pow((uint64_t)(j * k));
+            X[k] = acc * Fp::raw(words[FFT_LAM + i]);
+        }
+        for (int j = 0; j < 16; j++) { Fp acc = Fp::zero(); for (int k = 0; k < 16; k++) acc += X[k] * w16i.pow((uint64_t)(j * k)); st[j] = acc; }
+    }
     // the optimised schedule on the host (what the kernels do), for the self-check and the C-ABI test hook
     void permute(const Poseidon16& p, Fp* st) const {
         auto W = [&](int off) { return Fp::raw(words[off]); };
         auto sbox = [](Fp x) { Fp x2 = x * x; return x2 * x2 * x; };
-        for (int r = 0; r < 4; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); p.mds(st); }
+        for (int r = 0; r < 4; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); mds_convolution(st); }
         st[0] += W(T_SCALARS);
         for (int i = 0; i < 21; i++) {
             const int s = SPARSE + 32 * i;
@@ -120,8 +152,25 @@ struct PoseidonOptTables {
         Fp out[16];
         for (int a = 0; a < 16; a++) { Fp acc = Fp::zero(); for (int b = 0; b < 16; b++) acc += W(F_DENSE + 16 * a + b) * st[b]; out[a] = acc; }
         for (int a = 0; a < 16; a++) st[a] = out[a];
-        for (int r = 4; r < 8; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); p.mds(st); }
+        for (int r = 4; r < 8; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); mds_convolution(st); }
     }
 };
+
+// The Poseidon table a context keeps on the device: [480 round constants][16 circulant MDS coefficients][.. 1023: scratch of the device
+// challenger / proof-of-work search] and from word 1024 the PoseidonOptTables image.  sparse = those tables are valid.
+inline std::vector<uint32_t> poseidon_device_image(const uint32_t* rc480_canonical, const Poseidon16& p, bool& sparse) {
+    PoseidonOptTables popt(p);
+    std::vector<uint32_t> pos(1024 + PoseidonOptTables::WORDS, 0);
+    memcpy(pos.data() + 1024, popt.words.data(), popt.words.size() * 4);
+    for (int i = 0; i < 480; i++) pos[i] = Fp::from_canonical(rc480_canonical[i]).v;
+    const Fp w16 = vg::two_adic_generator(4), g = Fp::from_canonical(vg::GENERATOR);
+    for (int d = 0; d < 16; d++) {  // column 0 of CosetMds<16>: sum_k (31 w^d)^k
+        Fp base = g * w16.pow((uint64_t)d), acc = Fp::zero(), pw = Fp::one();
+        for (int k = 0; k < 16; k++) { acc += pw; pw *= base; }
+        pos[480 + d] = acc.v;
+    }
+    sparse = popt.valid;
+    return pos;
+}
 
 }  // namespace vhost

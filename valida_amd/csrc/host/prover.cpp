@@ -24,21 +24,13 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
         iw_dev_.emplace_back(ctx_.get(), a.interaction_words);
     }
     // Poseidon tables for the device PoW search: round constants + circulant CosetMds coefficients
-    PoseidonOptTables popt(perm16_);  // sparse form of the partial rounds for the Poseidon MMCS kernels (word 1024 on)
-    std::vector<uint32_t> pos(1024 + PoseidonOptTables::WORDS, 0);
-    memcpy(pos.data() + 1024, popt.words.data(), popt.words.size() * 4);
-    for (int i = 0; i < 480; i++) pos[i] = Fp::from_canonical(poseidon_rc480[i]).v;
-    Fp w16 = vg::two_adic_generator(4), g = Fp::from_canonical(vg::GENERATOR);
-    for (int d = 0; d < 16; d++) {
-        Fp base = g * w16.pow((uint64_t)d), acc = Fp::zero(), pw = Fp::one();
-        for (int k = 0; k < 16; k++) { acc += pw; pw *= base; }
-        pos[480 + d] = acc.v;
-    }
+    bool sparse = false;  // sparse form of the partial rounds + convolution form of the MDS layer for the Poseidon MMCS kernels (word 1024 on)
+    const std::vector<uint32_t> pos = poseidon_device_image(poseidon_rc480, perm16_, sparse);
     pow_pos_ = DBuf(ctx_.get(), pos);
     VG_HIP_CHECK(hipHostMalloc((void**)&cs_pinned_, CS_PINNED_WORDS * 4));
     ctx_->hash_kind = fri_.hash_kind;
     ctx_->poseidon_tab = pow_pos_.data;
-    ctx_->poseidon_sparse = popt.valid;
+    ctx_->poseidon_sparse = sparse;
 }
 
 // challenger.grind(bits) with the search on the device; canonical rule = smallest witness.
@@ -56,7 +48,7 @@ uint32_t Prover::grind(Challenger& ch) {
     for (uint64_t first = 0; first < vg::P; first += batch) {
         c.upload_async(pow_pos_.data + 496, st, 17 * 4);
         uint32_t count = (uint32_t)std::min<uint64_t>(batch, vg::P - first);
-        vk::launch_pow_grind(c.stream, pow_pos_.data, k_pending, (uint32_t)first, count, bits, best_dev);
+        vk::launch_pow_grind(c.stream, pow_pos_.data, c.poseidon_sparse, k_pending, (uint32_t)first, count, bits, best_dev);
         uint32_t best;
         c.download_small(&best, best_dev, 4);
         if (best != 0xffffffffu) {

@@ -126,7 +126,7 @@ void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint3
 // also copied to commit8_dev.  pos_dev: [480 Poseidon round constants][16 circulant MDS coefficients]; ch_dev: 50-word state.
 constexpr int DEV_CHALLENGER_WORDS = 50;
 void launch_fri_challenge(hipStream_t st, const uint32_t* pos_dev, uint32_t* ch_dev, const uint32_t* digest8_dev, uint32_t* beta5_dev, uint32_t* commit8_dev);
-void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev);
+void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, bool sparse, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev);
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst);
 
 }  // namespace vk

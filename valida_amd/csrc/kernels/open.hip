@@ -11,6 +11,7 @@
 #include <stdexcept>
 #include <string>
 #include "launch.hpp"
+#include "poseidon_perm.hpp"
 
 namespace vk {
 
@@ -525,12 +526,10 @@ void launch_fri_challenge(hipStream_t st, const uint32_t* pos_dev, uint32_t* ch_
 // duplexing overwrites state[0..k] with (pending, w), permutes, and the sample is state[15].  Thread t
 // tries w = first + t; the smallest passing witness is kept with atomicMin (canonical rule: smallest).
 // pos: [480 round constants][16 circulant MDS coefficients m[d] = sum_k (31 w16^d)^k][16 base state], Montgomery.
-__global__ void __launch_bounds__(256) k_pow_grind(const uint32_t* __restrict__ pos, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t mask,
+__global__ void __launch_bounds__(256) k_pow_grind(const uint32_t* __restrict__ pos, int sparse, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t mask,
                                                    uint32_t* __restrict__ best) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
-    const uint32_t* rc = pos;
-    const uint32_t* mds = pos + 480;
     const uint32_t* base = pos + 496;
     Fp st[16];
 #pragma unroll
@@ -538,34 +537,15 @@ __global__ void __launch_bounds__(256) k_pow_grind(const uint32_t* __restrict__ 
     const Fp wit = Fp::from_canonical(first + t);
 #pragma unroll
     for (int i = 0; i < 16; i++) if ((uint32_t)i == k_pending) st[i] = wit;
-#pragma unroll 1
-    for (int r = 0; r < 30; r++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) st[i] += Fp::raw(rc[r * 16 + i]);
-        if (r < 4 || r >= 26) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) { Fp x2 = st[i] * st[i]; st[i] = x2 * x2 * st[i]; }
-        } else {
-            Fp x2 = st[0] * st[0];
-            st[0] = x2 * x2 * st[0];
-        }
-        Fp out[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            Fp acc = Fp::zero();
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc += Fp::raw(mds[(j - i) & 15]) * st[i];
-            out[j] = acc;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) st[i] = out[i];
-    }
+    // the permutation of the Poseidon MMCS kernels (poseidon_perm.hpp: sparse partial rounds, convolution MDS — a fifth of the plain
+    // rounds' instructions; a batch is one wave per CU, i.e. latency-bound: the search costs what one permutation costs)
+    poseidon16_permute(st, tab_of(pos, sparse != 0));
     if ((st[15].canonical() & mask) == 0) atomicMin(best, first + t);
 }
 
-void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev) {
+void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, bool sparse, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev) {
     ProfScope ps("k_pow_grind", st, 0.0);
-    VK_LAUNCH(k_pow_grind, dim3((count + 255) / 256), dim3(256), 0, st, pos_dev, k_pending, first, count, (1u << bits) - 1u, best_dev);
+    VK_LAUNCH(k_pow_grind, dim3((count + 255) / 256), dim3(256), 0, st, pos_dev, sparse ? 1 : 0, k_pending, first, count, (1u << bits) - 1u, best_dev);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------

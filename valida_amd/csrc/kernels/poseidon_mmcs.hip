@@ -14,108 +14,9 @@
 // Integer-VALU-bound: ~0.8 k instructions per dense round (16 x 16 lazily accumulated products); the 22 partial rounds run in their
 // sparse-matrix form (31 products each, one dense round at the end), ~12 k instructions per permutation instead of ~26 k.
 #include "launch.hpp"
+#include "poseidon_perm.hpp"
 
 namespace vk {
-
-struct PoseidonTab {
-    const uint32_t* __restrict__ rc;   // [30][16] Montgomery
-    const uint32_t* __restrict__ mds;  // [16] circulant coefficients: M[j][i] = mds[(j - i) & 15]
-    const uint32_t* __restrict__ opt;  // sparse-partial-round tables (host/poseidon_opt.hpp layout), or null: plain rounds
-};
-// offsets into `opt` (words) — must match vhost::PoseidonOptTables
-constexpr int POPT_RC_FULL = 0, POPT_T = 128, POPT_SPARSE = 152, POPT_F = 152 + 21 * 32;
-
-// y = M x with M circulant; four products share one Montgomery reduction (4 p^2 < 2^64)
-__device__ __forceinline__ void poseidon_mds(Fp (&st)[16], const uint32_t (&m)[16]) {
-    Fp out[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        Fp acc = Fp::zero();
-#pragma unroll
-        for (int i0 = 0; i0 < 16; i0 += 4) {
-            uint64_t t = 0;
-#pragma unroll
-            for (int i = i0; i < i0 + 4; i++) t += (uint64_t)m[(j - i) & 15] * st[i].v;
-            acc += Fp::raw(vg::monty_reduce_wide(t));
-        }
-        out[j] = acc;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) st[i] = out[i];
-}
-__device__ __forceinline__ Fp poseidon_sbox(Fp x) { const Fp x2 = x * x; return x2 * x2 * x; }
-
-// row . state for one row of 16 wave-uniform coefficients
-__device__ __forceinline__ Fp poseidon_dot16(const uint32_t* __restrict__ row, const Fp (&st)[16]) {
-    Fp acc = Fp::zero();
-#pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += 4) {
-        uint64_t t = 0;
-#pragma unroll
-        for (int i = i0; i < i0 + 4; i++) t += (uint64_t)row[i] * st[i].v;
-        acc += Fp::raw(vg::monty_reduce_wide(t));
-    }
-    return acc;
-}
-
-__device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonTab& tab) {
-    uint32_t m[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
-    if (tab.opt == nullptr) {  // plain form: 30 rounds, dense MDS in every one
-#pragma unroll 1
-        for (int r = 0; r < 30; r++) {
-            const uint32_t* rc = tab.rc + 16 * r;
-#pragma unroll
-            for (int i = 0; i < 16; i++) st[i] += Fp::raw(rc[i]);
-            if (r < 4 || r >= 26) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) st[i] = poseidon_sbox(st[i]);
-            } else st[0] = poseidon_sbox(st[0]);
-            poseidon_mds(st, m);
-        }
-        return;
-    }
-    // 4 full rounds, 21 SPARSE partial rounds (31 products each instead of 256), one dense partial round, 4 full rounds — the same
-    // permutation (host/poseidon_opt.hpp derives the tables and checks them against the plain form)
-    const uint32_t* __restrict__ o = tab.opt;
-#pragma unroll 1
-    for (int r = 0; r < 4; r++) {
-        const uint32_t* rc = o + POPT_RC_FULL + 16 * r;
-#pragma unroll
-        for (int i = 0; i < 16; i++) st[i] = poseidon_sbox(st[i] + Fp::raw(rc[i]));
-        poseidon_mds(st, m);
-    }
-    st[0] += Fp::raw(o[POPT_T]);
-#pragma unroll 1
-    for (int i = 0; i < 21; i++) {
-        const uint32_t* __restrict__ s = o + POPT_SPARSE + 32 * i;
-        const Fp x0 = poseidon_sbox(st[0]);
-        Fp tmp[16];
-        tmp[0] = x0;
-#pragma unroll
-        for (int b = 1; b < 16; b++) tmp[b] = st[b];
-        const Fp n0 = poseidon_dot16(s, tmp);             // a x0 + u . x^
-#pragma unroll
-        for (int a = 1; a < 16; a++) st[a] += Fp::raw(s[15 + a]) * x0;  // x^ + w x0
-        st[0] = n0 + Fp::raw(o[POPT_T + 1 + i]);
-    }
-    {
-        st[0] = poseidon_sbox(st[0]);
-        Fp out[16];
-#pragma unroll
-        for (int a = 0; a < 16; a++) out[a] = poseidon_dot16(o + POPT_F + 16 * a, st);
-#pragma unroll
-        for (int a = 0; a < 16; a++) st[a] = out[a];
-    }
-#pragma unroll 1
-    for (int r = 4; r < 8; r++) {
-        const uint32_t* rc = o + POPT_RC_FULL + 16 * r;
-#pragma unroll
-        for (int i = 0; i < 16; i++) st[i] = poseidon_sbox(st[i] + Fp::raw(rc[i]));
-        poseidon_mds(st, m);
-    }
-}
 
 struct PPtrCols {
     const uint32_t* const* p;
@@ -212,10 +113,6 @@ __global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, Poseidon
 constexpr double POSEIDON_VALU_PER_PERM = 9.0 * (256.0 + 64.0 * 7.0 + 16.0 * 9.0 + 48.0) + 8.0 * 16.0 * 18.0 + 22.0 * 18.0 + 21.0 * (16.0 + 4 * 7.0 + 9.0 + 15.0 * 9.0);
 static double p_row_perms(int n_elems) { return (double)((n_elems + 7) / 8); }
 static double p_node_perms(int n_inject) { return n_inject > 0 ? 2.0 + p_row_perms(n_inject) : 1.0; }
-// pos_dev: [480 rc][16 mds][16 state][8 ..] as the device challenger uses, followed at word 1024 by the sparse-round tables when the
-// first of them (the validity word at 1023) is set
-static PoseidonTab tab_of(const uint32_t* pos_dev, bool sparse) { return PoseidonTab{pos_dev, pos_dev + 480, sparse ? pos_dev + 1024 : nullptr}; }
-
 void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     ProfScope ps("k_poseidon_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * p_row_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
     VK_LAUNCH(k_poseidon_leaves<PPtrCols>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, PPtrCols{cols_dev}, n_elems, n_rows, tab_of(pos_dev, sparse), digests);
