@@ -18,16 +18,19 @@ P = 2013265921
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
 
 
-@pytest.fixture(scope="module")
-def emu():
+# the MDS layer of the full rounds: 2 = CRT blocks (what the library is built with), 1 = transforms through the butterfly network (the A/B
+# alternative, kept buildable with -DVGPU_POSEIDON_MDS=1)
+@pytest.fixture(scope="module", params=[2, 1], ids=["mds_blocks", "mds_transforms"])
+def emu(request):
     src = os.path.join(ROOT, "tests", "emu", "poseidon_emu.cpp")
-    out = os.path.join(ROOT, "build", "libposeidonemu.so")
+    out = os.path.join(ROOT, "build", "libposeidonemu%d.so" % request.param)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     csrc = os.path.join(ROOT, "valida_amd", "csrc")
     deps = [src, os.path.join(ROOT, "tools", "hipemu", "hip", "hip_runtime.h"), os.path.join(csrc, "field.hpp"), os.path.join(csrc, "host", "poseidon_opt.hpp"),
             os.path.join(csrc, "host", "challenger.hpp")] + [os.path.join(csrc, "kernels", f) for f in ("poseidon_mmcs.hip", "poseidon_perm.hpp", "butterfly.hpp", "launch.hpp", "device_common.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", os.path.join(ROOT, "tools", "hipemu"), src, "-o", out], check=True)
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DVGPU_POSEIDON_MDS=%d" % request.param, "-x", "c++", "-I", os.path.join(ROOT, "tools", "hipemu"), src, "-o", out],
+                       check=True)
     return ctypes.CDLL(out)
 
 

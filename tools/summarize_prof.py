@@ -103,6 +103,15 @@ def timeline(db_path, out_txt, header):
                     excl[live[0]] = excl.get(live[0], 0) + (t_ - last)
                 last = t_
             active[n_] = active.get(n_, 0) + d_
+        # the FRI commit phase layer by layer: a layer = from one k_fri_fold to the next (its tree, the challenger step, the fold)
+        folds = [(s_ - t0) / 1e3 for n_, s_, e_ in seg if "k_fri_fold" in n_]
+        if len(folds) > 2:
+            first_ro = min(((s_ - t0) / 1e3 for n_, s_, e_ in seg if "k_reduce_openings" in n_), default=folds[0])
+            grind = min(((s_ - t0) / 1e3 for n_, s_, e_ in seg if "k_pow_grind" in n_), default=(t1 - t0) / 1e3)
+            f.write("phases_us: up to the reduced openings %.0f, reduced openings .. first fold %.0f, FRI layers %.0f, proof of work .. end %.0f\n"
+                    % (first_ro, folds[0] - first_ro, grind - folds[0], (t1 - t0) / 1e3 - grind))
+            f.write("fri_layer_us (first fold -> next fold, ..., last fold -> proof of work): %s\n"
+                    % " ".join("%.0f" % (b_ - a_) for a_, b_ in zip(folds, folds[1:] + [grind])))
         f.write("kernel launches total_us avg_us exclusive_us\n")
         for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             f.write("%-28s %5d %10.1f %8.1f %10.1f\n" % (k, n, t / 1e3, t / 1e3 / n, excl.get(k, 0) / 1e3))

@@ -27,7 +27,14 @@ struct PoseidonOptTables {
     static constexpr int FFT_FWD = F_DENSE + 256;     // [15 (+1 pad)]: stage s = 1..4 at offset 2^(s-1) - 1: w_{2^s}^j, j < 2^(s-1)
     static constexpr int FFT_INV = FFT_FWD + 16;      // the same with w^-j
     static constexpr int FFT_LAM = FFT_INV + 16;      // [16]: lambda in bit-reversed order (the order the DIF transform leaves)
-    static constexpr int WORDS = FFT_LAM + 16;
+    // ... and as the CRT split of that convolution, x^16 - 1 = (x^8 + 1)(x^4 + 1)(x^4 - 1): two stages of additions / subtractions, three
+    // SMALL dense products with lazily accumulated terms (negacyclic 8 x 8, negacyclic 4 x 4, cyclic 4 x 4: 96 terms instead of 256, no
+    // twiddle products at all), two stages back.  On gfx950 a multiply-add into a 64-bit accumulator is ONE half-rate instruction and a
+    // modular addition three full-rate ones: this form (~430 instructions) beats both the dense product (~900) and the transforms (~650).
+    static constexpr int BLK_N8 = FFT_LAM + 16;       // [8][8]  y-[k] = sum_j N8[k][j] (a[j] - a[j + 8])
+    static constexpr int BLK_C4 = BLK_N8 + 64;        // [4][4]  on a++[j] = (a[j] + a[j + 8]) + (a[j + 4] + a[j + 12])
+    static constexpr int BLK_N4 = BLK_C4 + 16;        // [4][4]  on a+-[j] = (a[j] + a[j + 8]) - (a[j + 4] + a[j + 12])
+    static constexpr int WORDS = BLK_N4 + 16;
     std::vector<uint32_t> words;
     bool valid = false;
 
@@ -109,6 +116,17 @@ struct PoseidonOptTables {
                 for (int d = 0; d < 16; d++) acc += M[d][0] * w16.pow((uint64_t)(d * k));
                 words[FFT_LAM + i] = (acc * inv16).v;
             }
+            // CRT blocks: kernels c- = (c[i] - c[i + 8]) / 2, c+ = (c[i] + c[i + 8]) / 2, then c+- / c++ from c+ the same way (the halves undo
+            // the two reconstruction steps y = (y+ + y-) / 2)
+            const Fp half = Fp::from_canonical(2).inv();
+            Fp cm[8], cp[8], cpm[4], cpp[4];
+            for (int i = 0; i < 8; i++) { cm[i] = (M[i][0] - M[i + 8][0]) * half; cp[i] = (M[i][0] + M[i + 8][0]) * half; }
+            for (int i = 0; i < 4; i++) { cpm[i] = (cp[i] - cp[i + 4]) * half; cpp[i] = (cp[i] + cp[i + 4]) * half; }
+            for (int k = 0; k < 8; k++) for (int j = 0; j < 8; j++) words[BLK_N8 + 8 * k + j] = (j <= k ? cm[k - j] : -cm[8 + k - j]).v;
+            for (int k = 0; k < 4; k++) for (int j = 0; j < 4; j++) {
+                words[BLK_C4 + 4 * k + j] = cpp[(k - j) & 3].v;
+                words[BLK_N4 + 4 * k + j] = (j <= k ? cpm[k - j] : -cpm[4 + k - j]).v;
+            }
         }
         valid = true;
         // self-check against the plain permutation
@@ -134,11 +152,26 @@ struct PoseidonOptTables {
         }
         for (int j = 0; j < 16; j++) { Fp acc = Fp::zero(); for (int k = 0; k < 16; k++) acc += X[k] * w16i.pow((uint64_t)(j * k)); st[j] = acc; }
     }
+    // the MDS layer from the CRT block tables, step for step as the kernels do it
+    void mds_blocks(Fp* st) const {
+        auto W = [&](int off) { return Fp::raw(words[off]); };
+        Fp am[8], ap[8], app[4], apm[4], ym[8], ypp[4], ypm[4], yp[8];
+        for (int i = 0; i < 8; i++) { am[i] = st[i] - st[i + 8]; ap[i] = st[i] + st[i + 8]; }
+        for (int i = 0; i < 4; i++) { apm[i] = ap[i] - ap[i + 4]; app[i] = ap[i] + ap[i + 4]; }
+        for (int k = 0; k < 8; k++) { Fp acc = Fp::zero(); for (int j = 0; j < 8; j++) acc += W(BLK_N8 + 8 * k + j) * am[j]; ym[k] = acc; }
+        for (int k = 0; k < 4; k++) {
+            Fp a = Fp::zero(), b = Fp::zero();
+            for (int j = 0; j < 4; j++) { a += W(BLK_C4 + 4 * k + j) * app[j]; b += W(BLK_N4 + 4 * k + j) * apm[j]; }
+            ypp[k] = a; ypm[k] = b;
+        }
+        for (int i = 0; i < 4; i++) { yp[i] = ypp[i] + ypm[i]; yp[i + 4] = ypp[i] - ypm[i]; }
+        for (int i = 0; i < 8; i++) { st[i] = yp[i] + ym[i]; st[i + 8] = yp[i] - ym[i]; }
+    }
     // the optimised schedule on the host (what the kernels do), for the self-check and the C-ABI test hook
     void permute(const Poseidon16& p, Fp* st) const {
         auto W = [&](int off) { return Fp::raw(words[off]); };
         auto sbox = [](Fp x) { Fp x2 = x * x; return x2 * x2 * x; };
-        for (int r = 0; r < 4; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); mds_convolution(st); }
+        for (int r = 0; r < 4; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); mds_blocks(st); }  // both table sets are exercised:
         st[0] += W(T_SCALARS);
         for (int i = 0; i < 21; i++) {
             const int s = SPARSE + 32 * i;
@@ -152,7 +185,7 @@ struct PoseidonOptTables {
         Fp out[16];
         for (int a = 0; a < 16; a++) { Fp acc = Fp::zero(); for (int b = 0; b < 16; b++) acc += W(F_DENSE + 16 * a + b) * st[b]; out[a] = acc; }
         for (int a = 0; a < 16; a++) st[a] = out[a];
-        for (int r = 4; r < 8; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); mds_convolution(st); }
+        for (int r = 4; r < 8; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); mds_convolution(st); }  // blocks above, transforms here
     }
 };
 
