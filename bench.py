@@ -54,6 +54,9 @@ MICROBENCH_DEFAULTS = {"full_rate": 1.03e12,   # v_add_u32 / v_sub_u32 / v_xor_b
                        "keccak_perm_per_s": 9.9e9, "clock_hz": 2.35e9, "source": "defaults (r02 measurement)"}
 KECCAK_VALU_PER_PERM = 23 * 178 + 58  # kernels/merkle.hip: instructions of one digest-only permutation
 KECCAK_FULL_RATE_PER_ROUND, KECCAK_HALF_RATE_PER_ROUND = 122, 56  # bitop3/xor vs alignbit per round
+# kernels/poseidon_mmcs.hip (POSEIDON_HALF_PER_PERM / POSEIDON_FULL_PER_PERM): instructions of one Poseidon-16 permutation as the kernels run it
+# (8 full rounds with the MDS layer as CRT blocks, 21 sparse partial rounds, one dense partial round), by issue class
+POSEIDON_HALF_PER_PERM, POSEIDON_FULL_PER_PERM = 4335, 7064
 
 
 def microbench_facts():
@@ -528,9 +531,14 @@ def main():
             if not valu_ or not ms_:
                 return None
             if name.startswith("k_poseidon"):  # Poseidon-16 kernels: Montgomery products, i.e. half-rate multiply instructions
-                rate = valu_ / (ms_ * 1e-3)
-                return {"achieved": rate, "unit": "wave64 VALU instr/s (modelled: 16 x 16 lazily accumulated products per round, 30 rounds)", "peak": mb["half_rate"],
-                        "frac": rate / mb["half_rate"], "peak_is": "issue rate of v_mul_lo/hi_u32 / v_mad_u64_u32 over the chip (tools/microbench.hip)"}
+                perms = valu_ * 64.0 / (POSEIDON_HALF_PER_PERM + POSEIDON_FULL_PER_PERM)
+                rate = perms / (ms_ * 1e-3)
+                cycles_per_perm = POSEIDON_FULL_PER_PERM * simds * mb["clock_hz"] / mb["full_rate"] + POSEIDON_HALF_PER_PERM * simds * mb["clock_hz"] / mb["half_rate"]
+                model = simds * mb["clock_hz"] * 64.0 / cycles_per_perm
+                return {"achieved": rate, "unit": "Poseidon-16 permutations/s", "peak": model, "frac": rate / model,
+                        "peak_is": "issue model: the %d half-rate (multiplies) + %d full-rate VALU instructions of one permutation as the kernels run it (sparse partial rounds, "
+                                   "MDS layer as CRT blocks) at their isolated issue rates (tools/microbench.hip); no in-register ceiling was measured for this code"
+                                   % (POSEIDON_HALF_PER_PERM, POSEIDON_FULL_PER_PERM)}
             perms = valu_ * 64.0 / KECCAK_VALU_PER_PERM
             rate = perms / (ms_ * 1e-3)
             cycles_per_perm = 24 * (KECCAK_FULL_RATE_PER_ROUND * simds * mb["clock_hz"] / mb["full_rate"] + KECCAK_HALF_RATE_PER_ROUND * simds * mb["clock_hz"] / mb["half_rate"])

@@ -493,3 +493,15 @@ def test_rust_sys_binding_is_generated_from_the_header_and_complete(tmp_path):
         cname, size, *offs = line.split()
         want_size, _, want_offs = struct_layout(structs[cname][1])
         assert (int(size), [int(o) for o in offs]) == (want_size, want_offs), cname
+
+
+def test_bench_prices_the_poseidon_kernels_with_the_kernels_own_instruction_model():
+    """bench.py's Poseidon roofline (permutations/s against an issue model) uses the per-permutation instruction counts that
+    kernels/poseidon_mmcs.hip reports to the profiler: the two files must hold the same numbers."""
+    import re
+    src = open(os.path.join(ROOT, "valida_amd", "csrc", "kernels", "poseidon_mmcs.hip")).read()
+    m = re.search(r"POSEIDON_HALF_PER_PERM = ([0-9.+ ]+), POSEIDON_FULL_PER_PERM = ([0-9.+ ]+);", src)
+    half, full = (sum(float(x) for x in g.split("+")) for g in m.groups())
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    b = re.search(r"POSEIDON_HALF_PER_PERM, POSEIDON_FULL_PER_PERM = (\d+), (\d+)", bench)
+    assert (int(b.group(1)), int(b.group(2))) == (int(half), int(full))

@@ -108,9 +108,18 @@ __global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, Poseidon
     }
 }
 
-// algorithmic VALU work: permutations x 30 rounds x (16 x 16 products + 64 reductions of 7 + S-boxes) / 64 lanes — a model for
-// the profiler's valu_ops column, like KECCAK_VALU_PER_PERM
-constexpr double POSEIDON_VALU_PER_PERM = 9.0 * (256.0 + 64.0 * 7.0 + 16.0 * 9.0 + 48.0) + 8.0 * 16.0 * 18.0 + 22.0 * 18.0 + 21.0 * (16.0 + 4 * 7.0 + 9.0 + 15.0 * 9.0);
+// Algorithmic VALU work for the profiler's valu_ops column (like KECCAK_VALU_PER_PERM): the instructions of ONE permutation as these kernels run
+// it, by issue class (bench.py holds the same two numbers and prices them at the measured issue rates).
+//   half rate (v_mad_u64_u32 / v_mul_lo_u32 / v_mul_hi_u32): a Montgomery product is 3, a lazily accumulated term 1, a reduction of <= 4 terms 2
+//     S-boxes (8 x 16 + 22) x 3 products            1350
+//     MDS layer as CRT blocks, 8 x (96 + 24 x 2)     1152
+//     sparse partial rounds, 21 x (16 + 4 x 2 + 15 x 3)  1449
+//     dense partial round, 16 x (16 + 4 x 2)          384
+//   full rate (add / sub / carry / select): a product's correction 3, a reduction 5, a modular addition 3
+//     round constants 8 x 16 x 3 = 384; S-boxes 450 x 3 = 1350; MDS 8 x (48 x 3 + 24 x 5 + 8 x 3) = 2304;
+//     sparse rounds 21 x (4 x 5 + 3 x 3 + 15 x 6 + 3) = 2562; dense round 16 x (4 x 5 + 3 x 3) = 464
+constexpr double POSEIDON_HALF_PER_PERM = 1350.0 + 1152.0 + 1449.0 + 384.0, POSEIDON_FULL_PER_PERM = 384.0 + 1350.0 + 2304.0 + 2562.0 + 464.0;
+constexpr double POSEIDON_VALU_PER_PERM = POSEIDON_HALF_PER_PERM + POSEIDON_FULL_PER_PERM;
 static double p_row_perms(int n_elems) { return (double)((n_elems + 7) / 8); }
 static double p_node_perms(int n_inject) { return n_inject > 0 ? 2.0 + p_row_perms(n_inject) : 1.0; }
 void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
