@@ -25,8 +25,26 @@ constexpr uint32_t R2_MOD_P = 1172168163u;   // 2^64 mod p
 constexpr uint32_t GENERATOR = 31;
 constexpr uint32_t TWO_ADIC_ROOT_27 = 0x1a427a41u;  // canonical; 31^15
 
+// VG_MULHI_NOP=1 (A/B builds): a scalar no-op behind the v_mul_hi_u32 that ends a Montgomery reduction's run of half-rate instructions — what
+// keccak.hpp does behind every v_alignbit_b32 (a half-rate instruction directly followed by a full-rate one of the same wave costs both a slot)
+#ifndef VG_MULHI_NOP
+#define VG_MULHI_NOP 0  // 1: behind the v_mul_hi_u32, 2: also behind the v_mul_lo_u32.  Measured (profiles/r03_ab_nops.json): 1 = no change, 2 = 5 % slower, the Poseidon leg 2.5 % slower under both
+#endif
+VG_HD uint32_t mul_lo_pinv(uint32_t lo) {  // lo * p^{-1} mod 2^32
+#if defined(__HIP_DEVICE_COMPILE__) && VG_MULHI_NOP == 2
+    uint32_t o;
+    asm("v_mul_lo_u32 %0, %1, %2\n\ts_nop 0" : "=v"(o) : "v"(lo), "v"(0x88000001u));
+    return o;
+#else
+    return lo * 0x88000001u;
+#endif
+}
 VG_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && VG_MULHI_NOP
+    uint32_t o;
+    asm("v_mul_hi_u32 %0, %1, %2\n\ts_nop 0" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+#elif defined(__HIP_DEVICE_COMPILE__)
     return __umulhi(a, b);
 #else
     return (uint32_t)(((uint64_t)a * b) >> 32);
@@ -89,7 +107,7 @@ VG_HD uint32_t monty_reduce(uint64_t t) {
     return reduce_once((uint32_t)((t + (uint64_t)m * P) >> 32));
 #else
     uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
-    uint32_t m = lo * 0x88000001u;         // lo * p^{-1} mod 2^32
+    uint32_t m = mul_lo_pinv(lo);
     uint32_t u = mul_hi_u32(m, P);         // (m * p) >> 32 ; low word of m*p equals lo
     return sub_mod(hi, u);                 // hi - u in (-p, p)
 #endif
@@ -100,7 +118,7 @@ VG_HD uint32_t monty_reduce(uint64_t t) {
 // 7 VALU instructions for 4 multiply-adds that each cost one v_mad_u64_u32.
 VG_HD uint32_t monty_reduce_wide(uint64_t t) {
     uint32_t lo = (uint32_t)t, hi = reduce_once((uint32_t)(t >> 32));
-    uint32_t m = lo * 0x88000001u;
+    uint32_t m = mul_lo_pinv(lo);
     uint32_t u = mul_hi_u32(m, P);
     return sub_mod(hi, u);
 }

@@ -26,12 +26,33 @@ __device__ __forceinline__ constexpr int keccak_rot(int i) {
     constexpr int R[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     return R[i];
 }
+// v_alignbit_b32 is a half-rate instruction, and a half-rate instruction directly followed by another VALU instruction of the same wave
+// makes both cost a full slot; ONE scalar no-op behind it restores the additive cost (profiles/r02_issue_patterns.txt: the compiled
+// order of this permutation 3.88 -> 3.48 SIMD-cycles per instruction at 8 waves per SIMD).  VK_ALIGNBIT_NOP=1 ties the no-op to every
+// rotation instruction of the thread-per-permutation kernels (the compiler keeps scheduling and register allocation; the lane-pair
+// variants are latency-bound — one wave per SIMD issues an instruction every ~5 cycles whatever it is — and stay without).  Measured in the
+// product, A/B in one session (profiles/r03_ab_keccak_nop.json): 58.1 / 59.4 -> 61.1 / 61.3 proofs/s with three proofs in flight
+// (16.84-17.21 -> 16.32-16.38 ms/step), 21.69 -> 21.38 ms for a lone proof.  Round 2's hand-scheduled asm permutation had the no-ops too
+// but cost a wave of occupancy and all of the compiler's register allocation; this form costs nothing else.  =0: A/B builds.
+#ifndef VK_ALIGNBIT_NOP
+#define VK_ALIGNBIT_NOP 1
+#endif
+template <int S> __device__ __forceinline__ uint32_t alignbit_c(uint32_t a, uint32_t b) {
+#if VK_ALIGNBIT_NOP
+    if (!__builtin_constant_p(a) && !__builtin_constant_p(b)) {
+        uint32_t o;
+        asm("v_alignbit_b32 %0, %1, %2, %3\n\ts_nop 0" : "=v"(o) : "v"(a), "v"(b), "n"(S));
+        return o;
+    }
+#endif
+    return __builtin_amdgcn_alignbit(a, b, S);
+}
 // (lo, hi) rotated left by the compile-time constant N
 template <int N> __device__ __forceinline__ void rotl_pair(uint32_t lo, uint32_t hi, uint32_t& olo, uint32_t& ohi) {
     if (N == 0) { olo = lo; ohi = hi; }
     else if (N == 32) { olo = hi; ohi = lo; }
-    else if (N < 32) { ohi = __builtin_amdgcn_alignbit(hi, lo, 32 - N); olo = __builtin_amdgcn_alignbit(lo, hi, 32 - N); }
-    else { ohi = __builtin_amdgcn_alignbit(lo, hi, 64 - N); olo = __builtin_amdgcn_alignbit(hi, lo, 64 - N); }
+    else if (N < 32) { ohi = alignbit_c<32 - N>(hi, lo); olo = alignbit_c<32 - N>(lo, hi); }
+    else { ohi = alignbit_c<64 - N>(lo, hi); olo = alignbit_c<64 - N>(hi, lo); }
 }
 // gfx950 v_bitop3_b32: any 3-input boolean function in one instruction (truth table over a=0xF0, b=0xCC, c=0xAA).
 // Operands known to be zero at compile time (the capacity lanes of a freshly padded block, in the peeled first
