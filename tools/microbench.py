@@ -16,12 +16,17 @@ BUILD = os.path.join(ROOT, "build")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
-def build():
+def build(extra=(), name="microbench"):
     os.makedirs(BUILD, exist_ok=True)
-    exe = os.path.join(BUILD, "microbench")
+    exe = os.path.join(BUILD, name)
     src = os.path.join(ROOT, "tools", "microbench.hip")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps=obj", "-I", os.path.join(ROOT, "valida_amd", "csrc"), src, "-o", exe], check=True, cwd=BUILD,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    co = os.path.join(BUILD, name + ".co")  # the code object of THIS build (every build overwrites the -save-temps file)
+    if not (os.environ.get("MICROBENCH_PREBUILT") == "1" and os.path.exists(exe) and os.path.exists(co)):  # the GPU box runs what was built here
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps=obj", "-I", os.path.join(ROOT, "valida_amd", "csrc")] + list(extra) + [src, "-o", exe], check=True,
+                       cwd=BUILD, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        import shutil
+        shutil.copyfile(os.path.join(BUILD, "microbench-hip-amdgcn-amd-amdhsa-gfx950.out"), co)
+    return exe, co
     return exe, os.path.join(BUILD, "microbench-hip-amdgcn-amd-amdhsa-gfx950.out")
 
 
@@ -60,6 +65,9 @@ def loop_bodies(code_object):
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else None
     exe, co = build()
+    exe0, _ = build(["-DVK_ALIGNBIT_NOP=0"], "microbench_nonop")
+    exe1, _ = build(["-DVK_KECCAK_PIN=0"], "microbench_nopin")
+    exe2, _ = build(["-DVK_KECCAK_PIN=2"], "microbench_rows")
     lines = ["# tools/microbench.py — gfx950 VALU issue rates (inline-asm loops) + HBM copy calibration kernels", ""]
     lines.append("## loop-body instruction counts from llvm-objdump -d of the code object (per loop iteration)")
     bodies = loop_bodies(co)
@@ -73,6 +81,19 @@ def main():
     if gpu.returncode == 0:
         lines.append("## measured on the GPU")
         lines += gpu.stdout.splitlines()
+        # the same permutation WITHOUT the scalar no-op behind every v_alignbit_b32 (keccak.hpp, VK_ALIGNBIT_NOP=0): the round-2 code
+        g0 = subprocess.run([exe0, "rates"], capture_output=True, text=True)
+        if g0.returncode == 0:
+            lines.append("## keccak.hpp built with -DVK_ALIGNBIT_NOP=0 (no s_nop behind v_alignbit_b32), same run")
+            lines += ["without s_nop: " + l for l in g0.stdout.splitlines() if l.startswith("keccak_f1600")]
+        g1 = subprocess.run([exe1, "rates"], capture_output=True, text=True)
+        if g1.returncode == 0:
+            lines.append("## keccak.hpp built with -DVK_KECCAK_PIN=0 (no scheduling barriers: hipcc groups the round's 50 xors and 46 rotations), same run")
+            lines += ["order not pinned: " + l for l in g1.stdout.splitlines() if l.startswith("keccak_f1600")]
+        g2 = subprocess.run([exe2, "rates"], capture_output=True, text=True)
+        if g2.returncode == 0:
+            lines.append("## keccak.hpp built with -DVK_KECCAK_PIN=2 (the round row by row of its output: five lanes of theta / rho / pi, then chi of the row), same run")
+            lines += ["row by row: " + l for l in g2.stdout.splitlines() if l.startswith("keccak_f1600")]
     else:
         lines.append("## no GPU run (%s)" % (gpu.stderr.strip().splitlines()[-1] if gpu.stderr.strip() else "exit %d" % gpu.returncode))
     text = "\n".join(lines) + "\n"

@@ -37,6 +37,9 @@ __device__ __forceinline__ constexpr int keccak_rot(int i) {
 #ifndef VK_ALIGNBIT_NOP
 #define VK_ALIGNBIT_NOP 1
 #endif
+#ifndef VK_KECCAK_PIN
+#define VK_KECCAK_PIN 1  // 1: a scheduling barrier behind every lane of theta / rho / pi (measured: 16.36 -> 16.21 ms/step, profiles/r03_ab_keccak_pin.json); 2: row by row (below)
+#endif
 template <int S> __device__ __forceinline__ uint32_t alignbit_c(uint32_t a, uint32_t b) {
 #if VK_ALIGNBIT_NOP
     if (!__builtin_constant_p(a) && !__builtin_constant_p(b)) {
@@ -78,6 +81,9 @@ template <int X, int Y> __device__ __forceinline__ void theta_rho_pi(const KStat
     const uint32_t tl = xor3(a.lo[src], cl[(X + 4) % 5], rl[(X + 1) % 5]);
     const uint32_t th = xor3(a.hi[src], ch[(X + 4) % 5], rh[(X + 1) % 5]);
     rotl_pair<keccak_rot(src)>(tl, th, b.lo[dst], b.hi[dst]);
+#if VK_KECCAK_PIN == 1  // A/B builds: keep a lane's two xors and two rotations together (hipcc otherwise groups the round's 50 xors and 46 rotations)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 template <int X> __device__ __forceinline__ void theta_rho_pi_col(const KState& a, const uint32_t (&cl)[5], const uint32_t (&ch)[5], const uint32_t (&rl)[5],
                                                                    const uint32_t (&rh)[5], KState& b) {
@@ -111,6 +117,40 @@ __device__ __forceinline__ void keccak_round(KState& a, uint32_t rc_lo, uint32_t
     a.lo[0] ^= rc_lo;
     a.hi[0] ^= rc_hi;
 }
+// The same round ROW BY ROW of its output (VK_KECCAK_PIN == 2, A/B builds): the five lanes whose pi-images form output row YD — source
+// (x, y) = ((3 YD + xd) % 5, xd) for xd = 0..4 — then chi of that row, a scheduling barrier behind every lane and every row: rotations
+// and xors alternate in groups of 2 + 2 and 10 instead of 50 + 46 + 50, and a row of B lives for ten instructions.
+template <int YD, int XD> __device__ __forceinline__ void theta_rho_pi_to(const KState& a, const uint32_t (&cl)[5], const uint32_t (&ch)[5], const uint32_t (&rl)[5],
+                                                                           const uint32_t (&rh)[5], uint32_t (&bl)[5], uint32_t (&bh)[5]) {
+    constexpr int X = (3 * YD + XD) % 5, Y = XD, src = X + 5 * Y;
+    static_assert((2 * X + 3 * Y) % 5 == YD, "pi^-1");
+    const uint32_t tl = xor3(a.lo[src], cl[(X + 4) % 5], rl[(X + 1) % 5]);
+    const uint32_t th = xor3(a.hi[src], ch[(X + 4) % 5], rh[(X + 1) % 5]);
+    rotl_pair<keccak_rot(src)>(tl, th, bl[XD], bh[XD]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int YD> __device__ __forceinline__ void keccak_row(const KState& a, const uint32_t (&cl)[5], const uint32_t (&ch)[5], const uint32_t (&rl)[5], const uint32_t (&rh)[5],
+                                                             KState& n) {
+    uint32_t bl[5], bh[5];
+    theta_rho_pi_to<YD, 0>(a, cl, ch, rl, rh, bl, bh); theta_rho_pi_to<YD, 1>(a, cl, ch, rl, rh, bl, bh); theta_rho_pi_to<YD, 2>(a, cl, ch, rl, rh, bl, bh);
+    theta_rho_pi_to<YD, 3>(a, cl, ch, rl, rh, bl, bh); theta_rho_pi_to<YD, 4>(a, cl, ch, rl, rh, bl, bh);
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        n.lo[x + 5 * YD] = chi32(bl[x], bl[(x + 1) % 5], bl[(x + 2) % 5]);
+        n.hi[x + 5 * YD] = chi32(bh[x], bh[(x + 1) % 5], bh[(x + 2) % 5]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void keccak_round_rows(KState& a, uint32_t rc_lo, uint32_t rc_hi) {
+    uint32_t cl[5], ch[5], rl[5], rh[5];
+    KState n;
+    column_parity(a, cl, ch, rl, rh);
+    keccak_row<0>(a, cl, ch, rl, rh, n); keccak_row<1>(a, cl, ch, rl, rh, n); keccak_row<2>(a, cl, ch, rl, rh, n);
+    keccak_row<3>(a, cl, ch, rl, rh, n); keccak_row<4>(a, cl, ch, rl, rh, n);
+    n.lo[0] ^= rc_lo;
+    n.hi[0] ^= rc_hi;
+    a = n;
+}
 // last round when only the 256-bit digest (lanes 0..3) is squeezed: row 0 of the output reads B[0..4], whose
 // pi-preimages are the diagonal lanes (x, x) — 58 ops instead of 178.
 __device__ __forceinline__ void keccak_last_round_digest(KState& a, uint32_t rc_lo, uint32_t rc_hi) {
@@ -133,7 +173,10 @@ __device__ __forceinline__ void keccak_last_round_digest(KState& a, uint32_t rc_
 template <bool DIGEST_ONLY> __device__ __forceinline__ void keccak_f1600(KState& a) {
     keccak_round(a, 0x00000001u, 0x00000000u);
 #pragma unroll 2
-    for (int round = 1; round < 23; round++) keccak_round(a, KECCAK_RC_LO[round], KECCAK_RC_HI[round]);
+    for (int round = 1; round < 23; round++) {
+        if (VK_KECCAK_PIN == 2) keccak_round_rows(a, KECCAK_RC_LO[round], KECCAK_RC_HI[round]);
+        else keccak_round(a, KECCAK_RC_LO[round], KECCAK_RC_HI[round]);
+    }
     if (DIGEST_ONLY) keccak_last_round_digest(a, 0x80008008u, 0x80000000u);
     else keccak_round(a, 0x80008008u, 0x80000000u);
 }
