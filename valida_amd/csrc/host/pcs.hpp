@@ -41,8 +41,12 @@ struct DeviceTree {
     // before_injection: called once, just before the first kernel that reads a matrix SHORTER than the tallest ones is enqueued (a layer
     // that injects rows) — commit_batches joins the stream that extends those matrices there, so the leaves and the first layers of the
     // tree (Keccak: integer-VALU work) run beside the remaining LDEs (half memory phases) instead of after them.
-    void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats, bool fetch_root = true, const std::function<void()>* before_injection = nullptr) {
+    // challenger: the FRI commit phase's DuplexChallenger step as an epilogue of the tree-top launch (KeccakTopArgs::ch_*), or null
+    struct TopChallenger { const uint32_t* pos; uint32_t* state; uint32_t* beta5; uint32_t* commit8; };
+    void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats, bool fetch_root = true, const std::function<void()>* before_injection = nullptr,
+               const TopChallenger* challenger = nullptr) {
         before_injection_ = before_injection;
+        challenger_ = challenger;
         std::vector<ColMat> cms(mats.size());
         for (size_t i = 0; i < mats.size(); i++) {
             cms[i].height = mats[i].height;
@@ -50,11 +54,13 @@ struct DeviceTree {
         }
         build_impl(c, cms, mats.size() == 1 ? &mats[0] : nullptr, fetch_root);
         before_injection_ = nullptr;
+        challenger_ = nullptr;
     }
     void build_cols(DeviceCtx* c, const std::vector<ColMat>& mats) { build_impl(c, mats, nullptr, true); }
 
   private:
     const std::function<void()>* before_injection_ = nullptr;
+    const TopChallenger* challenger_ = nullptr;
     // single_view: the tree is over ONE strided matrix (every FRI layer tree): no pointer table, columns are base + k * stride
     void build_impl(DeviceCtx* c, const std::vector<ColMat>& cms, const vk::DMatView* single_view, bool fetch_root) {
         ctx = c;
@@ -89,10 +95,12 @@ struct DeviceTree {
         layer_len.push_back(maxh);
         const bool pos = c->hash_kind == 1;
         const uint32_t* tab = c->poseidon_tab;
+        bool leaves_in_top = false;
         if (pos) {
             if (single) vk::launch_poseidon_leaves_strided(c->stream, tab, c->poseidon_sparse, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
             else vk::launch_poseidon_leaves(c->stream, tab, c->poseidon_sparse, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
-        } else if (single) vk::launch_keccak_leaves_strided(c->stream, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
+        } else if (single && vk::keccak_top_takes_leaves(maxh)) leaves_in_top = true;  // the small FRI layers: leaves, levels and challenger step in ONE launch
+        else if (single) vk::launch_keccak_leaves_strided(c->stream, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
         else vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
         vk::KeccakTopArgs top{};
@@ -117,6 +125,14 @@ struct DeviceTree {
             }
             if (inj) gi++;
             if (len == 1) break;
+        }
+        if (leaves_in_top) {
+            if (!top.levels || top.prev != layers[0].data) throw std::logic_error("mmcs: leaf prologue without a top launch over the leaf layer");
+            top.leaf_base = single_view->data; top.leaf_stride = single_view->stride; top.leaf_elems = (int)single_view->width; top.leaf_rows = maxh;
+        }
+        if (challenger_) {
+            if (!top.levels) throw std::logic_error("mmcs: the challenger epilogue needs a tree with at least one parent layer");
+            top.ch_pos = challenger_->pos; top.ch_state = challenger_->state; top.ch_beta5 = challenger_->beta5; top.ch_commit8 = challenger_->commit8;
         }
         if (top.levels) { if (pos) vk::launch_poseidon_top(c->stream, tab, c->poseidon_sparse, top); else vk::launch_keccak_top(c->stream, top); }
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");

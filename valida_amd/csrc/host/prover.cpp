@@ -62,6 +62,8 @@ Prover::~Prover() {
     if (cs_pinned_) (void)hipHostFree(cs_pinned_);
     prog_dev_.clear();
     iw_dev_.clear();
+    prep_pd_cache_.reset();
+    prep_nat_cache_.clear();
 }
 
 std::unique_ptr<DeviceTrace> Prover::upload_trace(const HostMatrix& m) {
@@ -336,19 +338,25 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         main_nat[i] = &main_own[i];
         vk::launch_ingest(c.stream_for(i, h), main[i]->raw.data, main_own[i].view(), false);
     }
-    std::vector<DMat> prep_nat(preprocessed.size());
+    std::vector<std::pair<int, uint64_t>> prep_key;
+    for (auto& pr : preprocessed) prep_key.emplace_back(pr.first, pr.second->uid);
+    static const bool prep_cache_on = [] { const char* e = getenv("VGPU_PREP_CACHE"); return !(e && e[0] == '0'); }();
+    const bool prep_hit = prep_cache_on && !prep_key.empty() && prep_key == prep_key_ && prep_pd_cache_;
+    if (!prep_hit) { prep_key_.clear(); prep_pd_cache_.reset(); prep_nat_cache_.clear(); prep_nat_cache_.resize(preprocessed.size()); }
+    std::vector<DMat>& prep_nat = prep_nat_cache_;
     std::vector<int> prep_slot(NC, -1);
     for (size_t k = 0; k < preprocessed.size(); k++) {
         const DeviceTrace* t = preprocessed[k].second;
         int chip = preprocessed[k].first;
         if (chip < 0 || (size_t)chip >= NC || prep_slot[chip] >= 0) throw std::invalid_argument("prove: bad or repeated preprocessed chip index");
         if (t->width != machine_.airs[chip].prep_width || t->height != main[chip]->height) throw std::invalid_argument("prove: preprocessed trace shape mismatch");
+        prep_slot[chip] = (int)k;
+        if (prep_hit) continue;
         prep_nat[k] = DMat(&c, t->height, t->width);
         if (!t->nat.empty())  // a device-resident working-layout trace handed in as preprocessed: copy, never read the (absent) raw image
             VG_HIP_CHECK(hipMemcpyAsync(prep_nat[k].data, t->nat.data, t->height * t->width * 4, hipMemcpyDeviceToDevice, c.stream_for(k, t->height)));
         else
             vk::launch_ingest(c.stream_for(k, t->height), t->raw.data, prep_nat[k].view(), false);
-        prep_slot[chip] = (int)k;
     }
     ingest_section.join();
     c.check_launch("ingest");
@@ -356,11 +364,15 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
 
     // ---------------- preprocessed + main commitments (lib.rs:189-225)
     t0 = Clock::now();
-    std::unique_ptr<ProverData> prep_pd;
+    ProverData* prep_pd = nullptr;
     if (!prep_nat.empty()) {
-        std::vector<CommitInput> in;
-        for (auto& m : prep_nat) in.push_back({&m, false, false});
-        prep_pd = commit_batches(&c, in, nullptr, fri_);
+        if (!prep_hit) {
+            std::vector<CommitInput> in;
+            for (auto& m : prep_nat) in.push_back({&m, false, false});
+            prep_pd_cache_ = commit_batches(&c, in, nullptr, fri_);
+            prep_key_ = prep_key;
+        }
+        prep_pd = prep_pd_cache_.get();
         ch.observe_digest(prep_pd->tree.root);
     }
     std::unique_ptr<ProverData> main_pd;
@@ -502,7 +514,6 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     read_cumulative_sums();  // the root download synchronised the stream: the asynchronous copy has landed
     perm_nat.clear();
     main_own.clear();
-    prep_nat.clear();
     tm.commit_perm = ms_since(t0);
 
     // ---------------- quotients (lib.rs:263-599)
@@ -862,8 +873,9 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     for (unsigned lf = log_max; lf-- > lb; li++) {
         uint64_t L = 2ull << lf, half = L >> 1;  // current length 2^(lf+1)
         layer_trees.emplace_back();
-        layer_trees.back().build(&c, {vk::DMatView{cur.data, half, 10, half}}, false);
-        vk::launch_fri_challenge(c.stream, pow_pos_.data, ch_dev.data, layer_trees.back().layers.back().data, betas_dev.data + 5 * li, commits_dev.data + 8 * li);
+        // the challenger step rides on the tree-top launch (its first wave, on the root it has just written): one launch and one gap less per layer
+        const DeviceTree::TopChallenger step{pow_pos_.data, ch_dev.data, betas_dev.data + 5 * li, commits_dev.data + 8 * li};
+        layer_trees.back().build(&c, {vk::DMatView{cur.data, half, 10, half}}, false, nullptr, &step);
         DBuf next(&c, (size_t)(5 * half));
         auto it = ro.find(lf);
         vk::launch_fri_fold(c.stream, cur.data, L, betas_dev.data + 5 * li, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);

@@ -1,6 +1,7 @@
 // Machine::prove on one MI355X: host orchestration of the transcript-ordered phases of
 // basic/src/lib.rs:147-675 (twin: derive/src/lib.rs:275-446) against the device kernels.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <memory>
@@ -20,7 +21,9 @@ struct HostMatrix {  // canonical row-major, host memory (the reference's RowMaj
 // A trace resident in HBM: either in the layout the reference hands over (`raw`: row-major, canonical u32, from
 // upload_trace) or already in the prover's working layout (`nat`: column-major Montgomery, natural row order, from
 // device trace generation — needs no ingest pass).
+inline uint64_t next_device_trace_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1); }
 struct DeviceTrace {
+    const uint64_t uid = next_device_trace_uid();  // identity of this upload / generation (the prover's preprocessed-commitment cache keys on it)
     DBuf raw;
     DMat nat;
     uint64_t height = 0, width = 0;
@@ -114,6 +117,13 @@ class Prover {
     MachineDesc machine_;
     FriParams fri_;
     Poseidon16 perm16_;
+    // The commitment to the PREPROCESSED traces (program ROM, range table: basic/src/lib.rs:189-201) depends on the machine and the program only,
+    // not on the witness: it is computed for the first proof that hands in a given set of preprocessed DeviceTraces and reused while the same
+    // traces (by uid) come back — their working-layout copies, LDEs and tree stay on the device.  One synchronisation point, the small
+    // LDE / tree launches and their ingest less per proof; the root is observed as ever.  VGPU_PREP_CACHE=0 recomputes every time.
+    std::vector<std::pair<int, uint64_t>> prep_key_;
+    std::vector<DMat> prep_nat_cache_;
+    std::unique_ptr<ProverData> prep_pd_cache_;
     std::vector<DBuf> prog_dev_, iw_dev_;  // per chip: program instructions, interaction words
     DBuf pow_pos_;                         // [480 rc][16 mds coefficients][16 state][1 best] for k_pow_grind
     static constexpr size_t CS_PINNED_WORDS = 5 * 256;

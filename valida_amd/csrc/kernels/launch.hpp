@@ -67,8 +67,22 @@ struct KeccakTopArgs {
     uint32_t* out[KECCAK_TOP_MAX_LEVELS];
     const uint32_t* const* cols[KECCAK_TOP_MAX_LEVELS];  // injected matrices' columns per layer (or null)
     int n_elems[KECCAK_TOP_MAX_LEVELS];
+    // Optional epilogue (FRI commit phase): the workgroup's first wave runs the DuplexChallenger step on the root it has just written —
+    // observe it, sample beta — instead of a k_fri_challenge launch of its own behind the tree (challenger_dev.hpp; arguments as
+    // launch_fri_challenge's).  ch_pos == nullptr: none.
+    // Optional prologue (trees over ONE strided matrix of <= 512 rows, i.e. the small FRI layers): the launch hashes the leaves itself
+    // into `prev` (leaf_rows rows of leaf_elems elements, columns leaf_base + k * leaf_stride) instead of a leaf launch of its own before it.
+    const uint32_t* leaf_base = nullptr;
+    uint64_t leaf_stride = 0;
+    int leaf_elems = 0;
+    uint64_t leaf_rows = 0;  // 0: none; else 2 * first_len
+    const uint32_t* ch_pos = nullptr;
+    uint32_t* ch_state = nullptr;
+    uint32_t* ch_beta5 = nullptr;
+    uint32_t* ch_commit8 = nullptr;
 };
 void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a);
+bool keccak_top_takes_leaves(uint64_t n_rows);  // whether launch_keccak_top can hash the leaves of a tree of n_rows rows itself (KeccakTopArgs::leaf_*)
 // poseidon_mmcs.hip — the same tree with PaddingFreeSponge / TruncatedPermutation over Poseidon-16 (hash kind 1).
 // pos_dev: [480 round constants][16 circulant MDS coefficients], Montgomery (the table the device challenger uses)
 void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);

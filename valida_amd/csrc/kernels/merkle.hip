@@ -11,7 +11,9 @@
 #include "launch.hpp"
 #include "keccak.hpp"
 #include "keccak_pair.hpp"
+#include "challenger_dev.hpp"
 #include <cstdlib>
+#include <stdexcept>
 
 namespace vk {
 
@@ -185,6 +187,15 @@ __global__ void __launch_bounds__(256) k_keccak_compress_pair(const uint32_t* __
 }
 __global__ void __launch_bounds__(1024) k_keccak_top_pair(KeccakTopArgs a) {
     const uint32_t* prev = a.prev;
+    if (a.leaf_rows) {  // the leaves of a small single-matrix tree: one row per lane pair, written where the first level reads them
+        if ((threadIdx.x >> 1) < a.leaf_rows) {
+            uint32_t d[4];
+            hash_row_pair(StridedCols{a.leaf_base, a.leaf_stride}, a.leaf_elems, threadIdx.x >> 1, (int)(threadIdx.x & 1), d);
+            store_digest_half(const_cast<uint32_t*>(a.prev) + 8 * (threadIdx.x >> 1), (int)(threadIdx.x & 1), d);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int l = 0; l < a.levels; l++) {
         const uint64_t len = a.first_len >> l;
         if ((threadIdx.x >> 1) < len) node_pair(prev, a.cols[l], a.n_elems[l], threadIdx.x >> 1, (int)(threadIdx.x & 1), a.out[l]);
@@ -192,6 +203,7 @@ __global__ void __launch_bounds__(1024) k_keccak_top_pair(KeccakTopArgs a) {
         __syncthreads();
         prev = a.out[l];
     }
+    if (a.ch_pos && threadIdx.x < 64) fri_challenge_step((int)threadIdx.x, a.ch_pos, a.ch_state, prev, a.ch_beta5, a.ch_commit8);
 }
 
 // Top of a tree in ONE launch: a single 1024-thread workgroup walks the last `levels` layers
@@ -220,6 +232,7 @@ __global__ void __launch_bounds__(1024) k_keccak_top(KeccakTopArgs a) {
         __syncthreads();
         prev = a.out[l];
     }
+    if (a.ch_pos && threadIdx.x < 64) fri_challenge_step((int)threadIdx.x, a.ch_pos, a.ch_state, prev, a.ch_beta5, a.ch_commit8);
 }
 
 // Algorithmic VALU work of the Keccak kernels, in wave64 instructions: permutations x (23 full rounds of 178 ops +
@@ -236,6 +249,8 @@ static bool keccak_pairs_enabled() {
 static double row_perms(int n_elems) { return (double)(n_elems / 34 + 1); }
 static double node_perms(int n_inject) { return n_inject > 0 ? 2.0 + row_perms(n_inject) : 1.0; }
 
+bool keccak_top_takes_leaves(uint64_t n_rows) { return keccak_pairs_enabled() && n_rows >= 2 && n_rows <= 512; }  // 2 threads per row, first_len = n_rows / 2 <= 256
+
 void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
     double bytes = 0, perms = 0;
     for (int l = 0; l < a.levels; l++) {
@@ -243,6 +258,11 @@ void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
         perms += (double)(a.first_len >> l) * node_perms(a.n_elems[l]);
     }
     const bool pairs = keccak_pairs_enabled() && a.first_len <= 512;
+    if (a.leaf_rows) {
+        if (!pairs || a.leaf_rows != 2 * a.first_len || !keccak_top_takes_leaves(a.leaf_rows)) throw std::logic_error("keccak top: leaf prologue on a tree it does not fit");
+        bytes += (double)a.leaf_rows * (4.0 * a.leaf_elems + 32.0);
+        perms += (double)a.leaf_rows * row_perms(a.leaf_elems);
+    }
     ProfScope ps(pairs ? "k_keccak_top_pair" : "k_keccak_top", st, bytes, perms * KECCAK_VALU_PER_PERM / 64.0);
     if (pairs) { VK_LAUNCH(k_keccak_top_pair, dim3(1), dim3(1024), 0, st, a); return; }
     VK_LAUNCH(k_keccak_top, dim3(1), dim3(1024), 0, st, a);

@@ -15,6 +15,7 @@
 // sparse-matrix form (31 products each, one dense round at the end), ~12 k instructions per permutation instead of ~26 k.
 #include "launch.hpp"
 #include "poseidon_perm.hpp"
+#include "challenger_dev.hpp"
 
 namespace vk {
 
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, Poseidon
         __syncthreads();
         prev = a.out[l];
     }
+    if (a.ch_pos && threadIdx.x < 64) fri_challenge_step((int)threadIdx.x, a.ch_pos, a.ch_state, prev, a.ch_beta5, a.ch_commit8);
 }
 
 // Algorithmic VALU work for the profiler's valu_ops column (like KECCAK_VALU_PER_PERM): the instructions of ONE permutation as these kernels run
