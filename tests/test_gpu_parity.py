@@ -979,3 +979,24 @@ def test_proofs_on_a_busy_context_queue_up(machine, rc):
     tickets = [p.prove_async(main, prep) for _ in range(3)]
     for t in reversed(tickets):  # waited for in another order than issued
         assert first_mismatch(t.wait().words, want) is None
+
+
+@pytest.mark.gpu
+def test_cached_preprocessed_commitment_follows_the_traces(machine, rc):
+    """The commitment to the preprocessed traces (program ROM, range table: basic/src/lib.rs:189-201) is kept across proofs while the SAME
+    uploaded traces come back, and recomputed for any other set: a prover that alternates between two programs gives, every time, the proof a
+    fresh prover gives (hit after a miss, miss after a hit, a re-upload of equal contents, and the switch VGPU_PREP_CACHE's reference)."""
+    p = va.Prover(machine, rc)
+    proofs = {}
+    for n in (25, 40, 25, 40):
+        w = va.Workload.fib(n)
+        if n not in proofs:  # keep the uploads of a program for its second round: the cache keys on them
+            proofs[n] = {"main": [p.upload(w.main_trace(c)) for c in range(va.NUM_CHIPS)], "prep": [(c, p.upload(m)) for c, m in w.preprocessed()], "w": w}
+            fresh = va.Prover(machine, rc)
+            proofs[n]["want"] = fresh.prove([fresh.upload(w.main_trace(c)) for c in range(va.NUM_CHIPS)], [(c, fresh.upload(m)) for c, m in w.preprocessed()]).words.copy()
+        e = proofs[n]
+        assert first_mismatch(p.prove(e["main"], e["prep"]).words, e["want"]) is None
+        assert first_mismatch(p.prove(e["main"], e["prep"]).words, e["want"]) is None  # the hit
+    e = proofs[25]
+    again = [(c, p.upload(m)) for c, m in e["w"].preprocessed()]  # equal contents, new uploads: a miss, same proof
+    assert first_mismatch(p.prove(e["main"], again).words, e["want"]) is None
