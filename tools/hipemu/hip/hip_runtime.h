@@ -126,6 +126,9 @@ inline unsigned __brev(unsigned x) {
     return (x >> 16) | (x << 16);
 }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+// wave-level primitives cannot be emulated by fibers: code that reaches one under hipemu is a test error (the kernels that use them — the
+// device challenger step behind the tree-top kernels — take that branch only when asked to)
+inline int __builtin_amdgcn_readlane(int, int) { throw std::runtime_error("hipemu: wave intrinsic (v_readlane) reached"); }
 struct uint4 { unsigned x, y, z, w; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline void __threadfence_block() {}
