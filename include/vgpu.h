@@ -243,7 +243,11 @@ int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uin
  * The traces may belong to ANOTHER prover context of the same device (a host that uploads or generates segment i+1 on a context of its
  * own while this one proves segment i): the call first waits for that context's queued work and keeps it alive until the proof is done.
  * A context runs one proof at a time; calls from several threads (and the workers of several vgpu_prove_async tickets) QUEUE on it and are
- * served one after the other, as several threads may call prove on the reference's `Machine: Sync` (machine/src/machine.rs:13). */
+ * served one after the other, as several threads may call prove on the reference's `Machine: Sync` (machine/src/machine.rs:13).
+ * The commitment to the preprocessed traces (basic/src/lib.rs:189-201) depends on the machine and the program only: the prover keeps it — the
+ * working-layout copies, LDEs and tree on the device — while the SAME vgpu_trace_t handles are handed in again, and recomputes it for any other
+ * set (a re-upload of equal contents included); the root is observed into the transcript every time.  VGPU_PREP_CACHE=0 in the environment
+ * recomputes it for every proof. */
 int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
                    const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t debug_flags, vgpu_proof_t** out);
 /* The same, asynchronously: returns at once, a host thread of its own drives this prover's streams.  Two provers on one
