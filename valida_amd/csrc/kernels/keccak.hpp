@@ -11,7 +11,8 @@ namespace vk {
 // Keccak-f[1600] on 32-bit halves.  gfx950 VALU is 32-bit: 64-bit xors are two ops anyway, but 64-bit
 // SHIFTS are slow multi-pass instructions, so every lane is kept as (lo, hi) and rotated with
 // v_alignbit_b32 (2 per rotation); chi and theta's column parity use gfx950's v_bitop3_b32 (any 3-input
-// boolean function: one op per half for chi, two for a 5-way xor).  178 full-rate VALU instructions per round.
+// boolean function: one op per half for chi, two for a 5-way xor).  178 VALU instructions per round: 122 full-rate
+// (bitop3 / xor) and 56 half-rate (alignbit) — how they ISSUE is what VK_ALIGNBIT_NOP and VK_KECCAK_PIN below are about.
 static __constant__ uint32_t KECCAK_RC_LO[24] = {0x00000001u, 0x00008082u, 0x0000808au, 0x80008000u, 0x0000808bu, 0x80000001u, 0x80008081u, 0x00008009u,
                                           0x0000008au, 0x00000088u, 0x80008009u, 0x8000000au, 0x8000808bu, 0x0000008bu, 0x00008089u, 0x00008003u,
                                           0x00008002u, 0x00000080u, 0x0000800au, 0x8000000au, 0x80008081u, 0x00008080u, 0x80000001u, 0x80008008u};
