@@ -129,6 +129,16 @@ inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned 
 // wave-level primitives cannot be emulated by fibers: code that reaches one under hipemu is a test error (the kernels that use them — the
 // device challenger step behind the tree-top kernels — take that branch only when asked to)
 inline int __builtin_amdgcn_readlane(int, int) { throw std::runtime_error("hipemu: wave intrinsic (v_readlane) reached"); }
+inline int __builtin_amdgcn_update_dpp(int, int, int, int, int, bool) { throw std::runtime_error("hipemu: wave intrinsic (DPP) reached"); }
+// per-lane integer primitives of gfx950 that ARE plain functions of their operands
+inline unsigned __builtin_amdgcn_bitop3_b32(unsigned a, unsigned b, unsigned c, unsigned truth_table) {  // bit i of the result = table[(a_i, b_i, c_i)]
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++) r |= ((truth_table >> ((((a >> i) & 1u) << 2) | (((b >> i) & 1u) << 1) | ((c >> i) & 1u))) & 1u) << i;
+    return r;
+}
+inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned shift) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (shift & 31u)); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+#define __constant__
 struct uint4 { unsigned x, y, z, w; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline void __threadfence_block() {}
