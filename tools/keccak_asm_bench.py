@@ -12,8 +12,9 @@ import keccak_asm as ka
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-VARIANTS = [("in-place 80 regs, each", "each", False, -1), ("in-place, pair", "pair", False, -1), ("in-place, none", "none", False, -1),
-            ("in-place bank-optimised, each", "each", True, -1), ("in-place bank-optimised, none", "none", True, -1), ("two-buffer 120 regs, each", "each", False, 0)]
+# (label, where the no-ops go, register placement: False = as numbered / "mod4" = round 2's bank model / "parity" = round 3's measurement, rounds per loop: -1 in-place, 0 two-buffer unrolled)
+VARIANTS = [("in-place 80 regs, each", "each", False, -1), ("in-place mod4-placed, each", "each", "mod4", -1), ("in-place parity-placed, each", "each", "parity", -1),
+            ("two-buffer 120 regs, each", "each", False, 0), ("two-buffer parity-placed, each", "each", "parity", 0), ("in-place parity-placed, none", "none", "parity", -1)]
 
 
 def asm_block(lines, top=127):
@@ -37,17 +38,21 @@ def source():
 }''']
     for k, (name, mode, bank, loop_rounds) in enumerate(VARIANTS):
         ka.PHYS.update({r: r for r in range(8, 128)})
-        if bank:
-            ka.bank_optimise(ka.add_deps(ka.round_instrs(1)))
         loc = list(range(25))
         if loop_rounds < 0:
             ins, loc = ka.inplace_permutation()
             if bank:
-                print(name, 'same-bank pairs', ka.bank_conflicts(ins), '->', ka.bank_optimise(ka.add_deps(list(ins)), steps=150000, hi=87), file=sys.stderr)
+                before = (ka.bank_conflicts(ins), ka.parity_conflicts(ins))
+                ka.bank_optimise(ka.add_deps(list(ins)), steps=200000, hi=87, model=bank)
+                print(name, "(mod-4 same-bank instructions, same-parity 3-source instructions) of %d:" % len(ins), before, "->", (ka.bank_conflicts(ins), ka.parity_conflicts(ins)), file=sys.stderr)
         else:
             ins = []
             for r in range(loop_rounds if loop_rounds else 24):
                 ins += ka.round_instrs(r)
+            if bank:
+                before = (ka.bank_conflicts(ins), ka.parity_conflicts(ins))
+                ka.bank_optimise(ka.add_deps(list(ins)), steps=200000, model=bank)
+                print(name, "(mod-4 same-bank instructions, same-parity 3-source instructions) of %d:" % len(ins), before, "->", (ka.bank_conflicts(ins), ka.parity_conflicts(ins)), file=sys.stderr)
         lines = ka.with_nops(ins, mode)
         top = max(ka.PHYS[r] for i in ins for r in (i.dst,) + tuple(i.srcs))
         if loop_rounds > 0:
