@@ -22,7 +22,11 @@
 #define __host__
 #define __forceinline__ inline
 #define __restrict__
+#ifdef HIPEMU_STATIC_SHARED  // kernels with STATIC __shared__ arrays (perm.hip): one function-local static, shared by the workgroup's fibers (they run on one OS
+#define __shared__ static    // thread); kernels with `extern __shared__` dynamic LDS (ntt.hip, ..) keep the default: the array resolves to a global the test defines
+#else
 #define __shared__
+#endif
 #define __launch_bounds__(...)
 
 struct dim3 {
