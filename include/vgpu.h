@@ -139,6 +139,11 @@ uint64_t vgpu_prover_trim(vgpu_prover_t* p);
 /* per-kernel HIP-event timing (bench): switch on/off (resets the accumulators); the profile is text,
  * one line per kernel: "name launches total_ms total_algorithmic_bytes".  Returns the size needed. */
 void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on);
+/* Optional, off by default: keep the commitment to the PREPROCESSED traces (program ROM, range table: it depends on the machine and the program only,
+ * not on the witness) across proofs while the SAME vgpu_trace_t handles are handed in again — working-layout copies, LDEs and tree stay on the
+ * device; any other set (a re-upload of equal contents included) recomputes it; the root is observed into the transcript every time.  Saves one
+ * synchronisation point and about 40 small launches per proof.  VGPU_PREP_CACHE=1 in the environment enables it for provers created afterwards. */
+void vgpu_prover_set_prep_cache(vgpu_prover_t* p, uint32_t on);
 /* restrict the timing to launches of ONE kernel name (NULL or "" = all): every timed launch carries a pair of events, which costs
  * the host and the command processor a little; a throughput measurement times only the kernel it reports a roofline for */
 void vgpu_prover_set_profiling_filter(vgpu_prover_t* p, const char* kernel_name);
@@ -244,10 +249,8 @@ int32_t vgpu_fri_fold(vgpu_prover_t* p, const uint32_t* f, uint64_t n, const uin
  * own while this one proves segment i): the call first waits for that context's queued work and keeps it alive until the proof is done.
  * A context runs one proof at a time; calls from several threads (and the workers of several vgpu_prove_async tickets) QUEUE on it and are
  * served one after the other, as several threads may call prove on the reference's `Machine: Sync` (machine/src/machine.rs:13).
- * The commitment to the preprocessed traces (basic/src/lib.rs:189-201) depends on the machine and the program only: the prover keeps it — the
- * working-layout copies, LDEs and tree on the device — while the SAME vgpu_trace_t handles are handed in again, and recomputes it for any other
- * set (a re-upload of equal contents included); the root is observed into the transcript every time.  VGPU_PREP_CACHE=0 in the environment
- * recomputes it for every proof. */
+ * The commitment to the preprocessed traces (basic/src/lib.rs:189-201) is recomputed in every call, as in the reference; see
+ * vgpu_prover_set_prep_cache for hosts that prove many segments of one program. */
 int32_t vgpu_prove(vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
                    const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t debug_flags, vgpu_proof_t** out);
 /* The same, asynchronously: returns at once, a host thread of its own drives this prover's streams.  Two provers on one

@@ -985,8 +985,9 @@ def test_proofs_on_a_busy_context_queue_up(machine, rc):
 def test_cached_preprocessed_commitment_follows_the_traces(machine, rc):
     """The commitment to the preprocessed traces (program ROM, range table: basic/src/lib.rs:189-201) is kept across proofs while the SAME
     uploaded traces come back, and recomputed for any other set: a prover that alternates between two programs gives, every time, the proof a
-    fresh prover gives (hit after a miss, miss after a hit, a re-upload of equal contents, and the switch VGPU_PREP_CACHE's reference)."""
+    fresh prover (which recomputes it every time, the default) gives: hit after a miss, miss after a hit, a re-upload of equal contents."""
     p = va.Prover(machine, rc)
+    p.set_prep_cache(True)  # off by default
     proofs = {}
     for n in (25, 40, 25, 40):
         w = va.Workload.fib(n)

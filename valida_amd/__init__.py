@@ -914,6 +914,10 @@ class Prover:
         _check(lib().vgpu_prove_async(self._h, arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)), ctypes.byref(h)))
         return Ticket(h, (main, preprocessed, self, keep))
 
+    def set_prep_cache(self, on):
+        """Keep the preprocessed commitment across proofs that hand in the same preprocessed traces (off by default: vgpu_prover_set_prep_cache)."""
+        lib().vgpu_prover_set_prep_cache(self._h, ctypes.c_uint32(1 if on else 0))
+
     def set_profiling(self, on, only=None):
         """Per-kernel HIP-event timing on / off (resets the accumulators); only = time launches of this kernel name alone."""
         lib().vgpu_prover_set_profiling_filter(self._h, only.encode() if only else None)

@@ -304,6 +304,7 @@ void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on) {
     c.profiler.reset();
     c.profiler.enabled = on != 0;
 }
+void vgpu_prover_set_prep_cache(vgpu_prover_t* p, uint32_t on) { if (p) p->p->set_prep_cache(on != 0); }
 void vgpu_prover_set_profiling_filter(vgpu_prover_t* p, const char* kernel_name) { p->p->ctx().profiler.only = kernel_name ? kernel_name : ""; }
 // "name launches total_ms total_algorithmic_bytes total_algorithmic_valu_ops\n" per kernel, accumulated since profiling was switched on
 int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap) {

@@ -31,6 +31,7 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
     ctx_->hash_kind = fri_.hash_kind;
     ctx_->poseidon_tab = pow_pos_.data;
     ctx_->poseidon_sparse = sparse;
+    { const char* e = getenv("VGPU_PREP_CACHE"); prep_cache_enabled_ = e && e[0] == '1'; }
 }
 
 // challenger.grind(bits) with the search on the device; canonical rule = smallest witness.
@@ -340,8 +341,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     }
     std::vector<std::pair<int, uint64_t>> prep_key;
     for (auto& pr : preprocessed) prep_key.emplace_back(pr.first, pr.second->uid);
-    static const bool prep_cache_on = [] { const char* e = getenv("VGPU_PREP_CACHE"); return !(e && e[0] == '0'); }();
-    const bool prep_hit = prep_cache_on && !prep_key.empty() && prep_key == prep_key_ && prep_pd_cache_;
+    const bool prep_hit = prep_cache_enabled_ && !prep_key.empty() && prep_key == prep_key_ && prep_pd_cache_;
     if (!prep_hit) { prep_key_.clear(); prep_pd_cache_.reset(); prep_nat_cache_.clear(); prep_nat_cache_.resize(preprocessed.size()); }
     std::vector<DMat>& prep_nat = prep_nat_cache_;
     std::vector<int> prep_slot(NC, -1);
@@ -370,7 +370,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             std::vector<CommitInput> in;
             for (auto& m : prep_nat) in.push_back({&m, false, false});
             prep_pd_cache_ = commit_batches(&c, in, nullptr, fri_);
-            prep_key_ = prep_key;
+            if (prep_cache_enabled_) prep_key_ = prep_key;  // off: the key stays empty, the next proof recomputes
         }
         prep_pd = prep_pd_cache_.get();
         ch.observe_digest(prep_pd->tree.root);

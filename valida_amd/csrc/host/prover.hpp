@@ -118,9 +118,15 @@ class Prover {
     FriParams fri_;
     Poseidon16 perm16_;
     // The commitment to the PREPROCESSED traces (program ROM, range table: basic/src/lib.rs:189-201) depends on the machine and the program only,
-    // not on the witness: it is computed for the first proof that hands in a given set of preprocessed DeviceTraces and reused while the same
-    // traces (by uid) come back — their working-layout copies, LDEs and tree stay on the device.  One synchronisation point, the small
-    // LDE / tree launches and their ingest less per proof; the root is observed as ever.  VGPU_PREP_CACHE=0 recomputes every time.
+    // not on the witness.  OPTIONAL (off by default: Machine::prove recomputes it in every call, and so does this prover — the bench's timed
+    // region included): with set_prep_cache(true) (C ABI vgpu_prover_set_prep_cache, or VGPU_PREP_CACHE=1 in the environment when the prover is
+    // created) it is computed for the first proof that hands in a given set of preprocessed DeviceTraces and reused while the same traces (by
+    // uid) come back — their working-layout copies, LDEs and tree stay on the device: one synchronisation point, the small LDE / tree
+    // launches and their ingest less per proof (about 0.2 ms of a lone proof); the root is observed as ever.
+    bool prep_cache_enabled_ = false;
+  public:
+    void set_prep_cache(bool on) { prep_cache_enabled_ = on; if (!on) { prep_key_.clear(); prep_pd_cache_.reset(); prep_nat_cache_.clear(); } }
+  private:
     std::vector<std::pair<int, uint64_t>> prep_key_;
     std::vector<DMat> prep_nat_cache_;
     std::unique_ptr<ProverData> prep_pd_cache_;
