@@ -33,7 +33,8 @@ enum {
     VGPU_ERR_OOM = -2,
     VGPU_ERR_HIP = -3,
     VGPU_ERR_UNSUPPORTED = -4,
-    VGPU_ERR_INTERNAL = -5
+    VGPU_ERR_INTERNAL = -5,
+    VGPU_ERR_FABRIC = -6   /* a sharded proof was given up because a peer rank failed, or the transport itself failed / ran into its deadline */
 };
 enum {
     VGPU_HASH_KECCAK256 = 0,  /* the reference's MMCS: SerializingHasher32<Keccak256Hash> + CompressionFunctionFromHasher (basic/tests/test_prover.rs:424-431) */
@@ -300,6 +301,10 @@ int32_t vgpu_comm_unique_id(uint8_t id[VGPU_COMM_ID_BYTES]);
 int32_t vgpu_comm_init(vgpu_prover_t* p, const uint8_t id[VGPU_COMM_ID_BYTES], uint32_t rank, uint32_t world, vgpu_comm_t** out);
 int32_t vgpu_comm_allgather_roots(vgpu_comm_t* c, const uint32_t* words, uint32_t n_words, uint32_t* out);
 void vgpu_comm_destroy(vgpu_comm_t* c);
+/* Deadline of every collective issued through `c` (the roots all-gather, the exchanges of vgpu_prove_sharded): one that has not completed
+ * within timeout_ms — a peer died or never entered it — is aborted (ncclCommAbort), the call fails (VGPU_ERR_HIP / VGPU_ERR_FABRIC) and the
+ * communicator is dead: every later call on it is refused, create a new one.  0 (the default, or the environment's VGPU_COMM_TIMEOUT_MS) = wait for ever. */
+int32_t vgpu_comm_set_timeout_ms(vgpu_comm_t* c, uint32_t timeout_ms);
 
 /* ---- ONE proof sharded over several GPUs.  Its commitment round alone: pcs.commit_batches of one round sharded over the
  * ranks of `comm` — column-sharded LDEs, an all-to-all into row-range shards, a subtree per rank, an all-gather of the subtree
@@ -337,10 +342,19 @@ int32_t vgpu_prove_sharded_local(vgpu_prover_t* const* provers, uint32_t world, 
  *   all_gather : every rank contributes n_words words; out receives world * n_words words, rank-major.
  *   all_to_all : send[s] (send_words[s] words) goes to rank s, recv[s] (recv_words[s] words) arrives from rank s; the entries of s == rank
  *                are null / 0 (the library keeps its own block on the device).  Device blocks are staged through page-locked host memory.
- * Failure protocol: before every exchange the ranks all_gather one status word; a rank whose proof fails (bad shapes, out of memory, a
- * HIP error) reports it there instead of going on, and EVERY rank returns an error (VGPU_ERR_*; vgpu_last_error names the failing rank)
- * instead of blocking in an exchange its peer never enters. */
+ * Failure protocol: every exchange is staged first (everything that can fail on this rank alone: staging buffers, device-to-host copies),
+ * then the ranks all_gather one status word, then the exchange runs.  A rank whose proof fails (bad shapes, out of memory, a HIP error)
+ * reports it in the status word instead of going on, and EVERY rank returns VGPU_ERR_FABRIC (vgpu_last_error names the failing rank) instead
+ * of blocking in an exchange its peer never enters.  A callback that itself returns non-zero is fatal for the transport: that rank returns
+ * at once, issues no further callback, and its peers leave through their own callback's error or through the deadline.
+ * Deadline: timeout_ms > 0 bounds every single callback.  The library then runs the callbacks on a helper thread of its own (they must be
+ * callable from another thread than the caller's); one that has not returned in time is ABANDONED there — the library never touches its
+ * buffers again, the helper thread ends if the callback ever returns — and the call fails with VGPU_ERR_FABRIC.  A peer that died costs the
+ * survivors at most timeout_ms, never a hang.  timeout_ms == 0: callbacks run on the calling thread and must bound themselves.
+ * struct_size must be sizeof(vgpu_fabric_t): a host compiled against another layout of this struct is refused, not misread. */
 typedef struct vgpu_fabric {
+    uint32_t struct_size;   /* = sizeof(vgpu_fabric_t) */
+    uint32_t timeout_ms;    /* deadline of one callback; 0 = none */
     void* user;
     uint32_t rank, world;   /* world: a power of two */
     int32_t (*all_gather)(void* user, const uint32_t* words, uint64_t n_words, uint32_t* out);
@@ -373,6 +387,7 @@ typedef struct vgpu_mem_op { uint32_t clk, addr, value, is_write; } vgpu_mem_op_
 typedef struct vgpu_alu_op { uint32_t opcode, a, b, c; } vgpu_alu_op_t;              /* e.g. Operation::Add32(a, b, c): a = result */
 typedef struct vgpu_out_op { uint32_t clk, byte; } vgpu_out_op_t;                    /* OutputChip::values entry (clk, byte) (output/src/lib.rs:21-23) */
 typedef struct vgpu_oplog_desc {
+    uint64_t struct_size;   /* = sizeof(vgpu_oplog_desc_t): vgpu_oplog_upload refuses a host compiled against another layout of this struct */
     const vgpu_cpu_op_t* cpu; uint64_t n_cpu;
     const vgpu_mem_op_t* mem; uint64_t n_mem;
     const vgpu_alu_op_t* alu[4]; uint64_t n_alu[4];   /* add, sub, lt, bitwise */

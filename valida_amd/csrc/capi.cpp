@@ -22,6 +22,8 @@ static thread_local std::string g_err;
 static int32_t fail(int32_t code, const std::string& msg) { g_err = msg; return code; }
 #define VG_TRY(...)                                                         \
     try { __VA_ARGS__; return VGPU_OK; }                                           \
+    catch (const FabricPeerFailure& e) { return fail(VGPU_ERR_FABRIC, e.what()); }          \
+    catch (const FabricTransportFailure& e) { return fail(VGPU_ERR_FABRIC, e.what()); }     \
     catch (const std::invalid_argument& e) { return fail(VGPU_ERR_INVALID_ARG, e.what()); } \
     catch (const std::bad_alloc& e) { return fail(VGPU_ERR_OOM, e.what()); }                \
     catch (const std::exception& e) {                                       \
@@ -358,6 +360,9 @@ int32_t vgpu_trace_download(vgpu_prover_t* p, const vgpu_trace_t* t, uint32_t* o
 int32_t vgpu_oplog_upload(vgpu_prover_t* p, const vgpu_oplog_desc_t* log, vgpu_oplog_t** out) {
     VG_TRY({
         if (!p || !log || !out) throw std::invalid_argument("null argument");
+        if (log->struct_size != sizeof(vgpu_oplog_desc_t))
+            throw std::invalid_argument("oplog: struct_size " + std::to_string(log->struct_size) + " is not this library's sizeof(vgpu_oplog_desc_t) = " + std::to_string(sizeof(vgpu_oplog_desc_t)) +
+                                        " (host compiled against another vgpu.h?)");
         p->p->ctx().activate();
         HostOplog h;
         h.cpu = (const vk::TgCpuOp*)log->cpu; h.n_cpu = log->n_cpu;
@@ -822,6 +827,12 @@ int32_t vgpu_comm_allgather_roots(vgpu_comm_t* c, const uint32_t* words, uint32_
         c->comm->all_gather_words(words, n_words, out);
     })
 }
+int32_t vgpu_comm_set_timeout_ms(vgpu_comm_t* c, uint32_t timeout_ms) {
+    VG_TRY({
+        if (!c) throw std::invalid_argument("null argument");
+        c->comm->timeout_ms = timeout_ms;
+    })
+}
 void vgpu_comm_destroy(vgpu_comm_t* c) { delete c; }
 
 // ---- sharded commit
@@ -888,16 +899,26 @@ int32_t vgpu_prove_sharded(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace
         *out = proof.release();
     })
 }
+static void check_fabric_struct(const vgpu_fabric_t* fabric) {
+    if (!fabric) throw std::invalid_argument("null fabric");
+    if (fabric->struct_size != sizeof(vgpu_fabric_t))
+        throw std::invalid_argument("fabric: struct_size " + std::to_string(fabric->struct_size) + " is not this library's sizeof(vgpu_fabric_t) = " + std::to_string(sizeof(vgpu_fabric_t)) +
+                                    " (host compiled against another vgpu.h?)");
+}
 int32_t vgpu_prove_sharded_fabric(vgpu_prover_t* p, const vgpu_fabric_t* fabric, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
                                   const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out) {
     VG_TRY({
-        if (!p || !fabric || !main || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
-        CallbackFabric fab((int)fabric->rank, (int)fabric->world, fabric->all_gather, fabric->all_to_all, fabric->user);
-        std::vector<Prover*> provers{p->p.get()};
+        // the fabric first: from here on whatever this rank refuses — a null argument included — is reported to the peers, who are (or will
+        // be) inside the prover waiting for this rank's first status word
+        check_fabric_struct(fabric);
+        CallbackFabric fab((int)fabric->rank, (int)fabric->world, fabric->all_gather, fabric->all_to_all, fabric->user, fabric->timeout_ms);
+        std::vector<Prover*> provers;
         std::vector<ShardedInputs> in;
         try {
+            if (!p || !main || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
+            provers.push_back(p->p.get());
             in.push_back(sharded_inputs(p, main, n_main, prep_chips, prep, n_prep));
-        } catch (...) {  // the peers are (or will be) inside the prover: tell them
+        } catch (...) {
             fab.fail();
             throw;
         }
@@ -908,8 +929,8 @@ int32_t vgpu_prove_sharded_fabric(vgpu_prover_t* p, const vgpu_fabric_t* fabric,
 }
 int32_t vgpu_fabric_selftest(const vgpu_fabric_t* fabric, uint32_t n_words, uint32_t fail_rank) {
     VG_TRY({
-        if (!fabric) throw std::invalid_argument("null argument");
-        CallbackFabric fab((int)fabric->rank, (int)fabric->world, fabric->all_gather, fabric->all_to_all, fabric->user);
+        check_fabric_struct(fabric);
+        CallbackFabric fab((int)fabric->rank, (int)fabric->world, fabric->all_gather, fabric->all_to_all, fabric->user, fabric->timeout_ms);
         const uint32_t W = fabric->world, me = fabric->rank;
         auto word = [](uint32_t from, uint32_t to, uint32_t k) { return 0x9E3779B9u * (from + 1) + 0x85EBCA6Bu * (to + 1) + k; };
         try {
@@ -924,7 +945,12 @@ int32_t vgpu_fabric_selftest(const vgpu_fabric_t* fabric, uint32_t n_words, uint
             if (me == fail_rank) throw std::invalid_argument("fabric selftest: rank " + std::to_string(me) + " fails on request");
             // 3. all_to_all of blocks whose size depends on the pair
             fab.agree();
-            std::vector<std::vector<uint32_t>> sb(W), rb(W);
+            // the blocks live in the fabric's shared state: a callback abandoned at the deadline may still write into them
+            struct Blocks { std::vector<std::vector<uint32_t>> sb, rb; };
+            auto blocks = std::make_shared<Blocks>();
+            blocks->sb.resize(W); blocks->rb.resize(W);
+            fab.sh->keep = blocks;
+            auto& sb = blocks->sb; auto& rb = blocks->rb;
             std::vector<const uint32_t*> sp(W, nullptr);
             std::vector<uint32_t*> rp(W, nullptr);
             std::vector<uint64_t> sw(W, 0), rw(W, 0);
@@ -1059,6 +1085,7 @@ int32_t vgpu_workload_cell(const vgpu_workload_t* w, uint32_t addr, uint32_t* va
     })
 }
 void vgpu_workload_oplog(const vgpu_workload_t* w, vgpu_oplog_desc_t* out) {
+    out->struct_size = sizeof(vgpu_oplog_desc_t);
     out->cpu = w->log_cpu.data(); out->n_cpu = w->log_cpu.size();
     out->mem = w->log_mem.data(); out->n_mem = w->log_mem.size();
     for (int k = 0; k < 4; k++) { out->alu[k] = w->log_alu[k].data(); out->n_alu[k] = w->log_alu[k].size(); }

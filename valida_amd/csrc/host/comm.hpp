@@ -5,6 +5,8 @@
 // enqueued on the context's stream.
 #pragma once
 #include <dlfcn.h>
+#include <chrono>
+#include <thread>
 #include <rccl/rccl.h>
 #include "runtime.hpp"
 
@@ -15,6 +17,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -43,6 +47,8 @@ struct RcclApi {
         a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.CommAbort = (decltype(a.CommAbort))sym("ncclCommAbort");
+        a.CommGetAsyncError = (decltype(a.CommGetAsyncError))sym("ncclCommGetAsyncError");
         a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
         a.Send = (decltype(a.Send))sym("ncclSend");
         a.Recv = (decltype(a.Recv))sym("ncclRecv");
@@ -70,6 +76,11 @@ struct Comm {
     uint32_t* coll_buf = nullptr;       // device: [send: COLL_WORDS][recv: COLL_WORDS * world]
     uint32_t* coll_host = nullptr;      // pinned staging of the same shape
     static constexpr size_t COLL_WORDS = 256;
+    // Deadline of one collective (vgpu_comm_set_timeout_ms; 0 = wait for ever, the default; VGPU_COMM_TIMEOUT_MS presets it): a collective a
+    // peer never enters — it died, or it failed alone — is aborted with ncclCommAbort instead of blocking this rank for ever.  After an
+    // abort the communicator is gone (`comm` null): every later call on it is refused.
+    uint32_t timeout_ms = [] { const char* e = getenv("VGPU_COMM_TIMEOUT_MS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();
+    hipEvent_t wait_ev = nullptr;
     Comm(DeviceCtx* c, const ncclUniqueId& id, int rank_, int world_) : ctx(c), rank(rank_), world(world_) {
         if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("comm: bad rank / world");
         VG_HIP_CHECK(hipSetDevice(c->device));
@@ -83,25 +94,58 @@ struct Comm {
         if (coll_stream) { (void)hipStreamSynchronize(coll_stream); (void)hipStreamDestroy(coll_stream); }
         if (coll_buf) (void)hipFree(coll_buf);
         if (coll_host) (void)hipHostFree(coll_host);
+        if (wait_ev) (void)hipEventDestroy(wait_ev);
         if (comm) (void)RcclApi::get().CommDestroy(comm);
+    }
+    void require_alive() const {
+        if (!comm) throw std::runtime_error("hip: rccl: this communicator was aborted after a collective timed out or failed; create a new one");
+    }
+    // Waits for everything enqueued on `s` (the collective just issued included).  Without a deadline: a plain stream synchronisation.  With
+    // one: polls an event and RCCL's asynchronous error state; on an error or at the deadline the communicator is ABORTED (its kernels leave
+    // the device, the stream drains) and the call throws.
+    void wait(hipStream_t s, uint32_t deadline_ms) {
+        if (!deadline_ms) { VG_HIP_CHECK(hipStreamSynchronize(s)); return; }
+        if (!wait_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&wait_ev, hipEventDisableTiming));
+        VG_HIP_CHECK(hipEventRecord(wait_ev, s));
+        const auto t0 = std::chrono::steady_clock::now();
+        auto& api = RcclApi::get();
+        for (unsigned spin = 0;; spin++) {
+            const hipError_t e = hipEventQuery(wait_ev);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) throw std::runtime_error(std::string("hipEventQuery: ") + hipGetErrorString(e));
+            ncclResult_t async = ncclSuccess;
+            const bool bad = (spin & 63) == 63 && comm && api.CommGetAsyncError(comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress;
+            const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(deadline_ms);
+            if (bad || late) {
+                ncclComm_t dead = comm;
+                comm = nullptr;
+                (void)api.CommAbort(dead);
+                (void)hipStreamSynchronize(s);
+                throw std::runtime_error(bad ? std::string("hip: rccl: asynchronous error: ") + api.GetErrorString(async) + "; communicator aborted"
+                                             : "hip: rccl: a collective did not complete within " + std::to_string(deadline_ms) + " ms (a peer that died or never entered it?); communicator aborted");
+            }
+            if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
+        }
     }
     Comm(const Comm&) = delete;
     // every rank's `n_words` words to every rank: out[r * n_words + k] = rank r's word k.  Host buffers; staged through HBM.
     void all_gather_words(const uint32_t* words, size_t n_words, uint32_t* out) {
         if (n_words > COLL_WORDS) throw std::invalid_argument("comm: at most 256 words per rank in one roots all-gather");
+        require_alive();
         VG_HIP_CHECK(hipSetDevice(ctx->device));
         memcpy(coll_host, words, n_words * 4);
         uint32_t* recv = coll_buf + COLL_WORDS;
         VG_HIP_CHECK(hipMemcpyAsync(coll_buf, coll_host, n_words * 4, hipMemcpyHostToDevice, coll_stream));
         VG_NCCL_CHECK(RcclApi::get().AllGather(coll_buf, recv, n_words, ncclUint32, comm, coll_stream));
         VG_HIP_CHECK(hipMemcpyAsync(coll_host + COLL_WORDS, recv, n_words * (size_t)world * 4, hipMemcpyDeviceToHost, coll_stream));
-        VG_HIP_CHECK(hipStreamSynchronize(coll_stream));
+        wait(coll_stream, timeout_ms);
         memcpy(out, coll_host + COLL_WORDS, n_words * (size_t)world * 4);
     }
     // device-to-device exchange: block `send[s]` (count words) goes to rank s, `recv[s]` arrives from rank s (the all-to-all of
     // the sharded commit: column shards -> row-range shards)
     void all_to_all_words(const std::vector<const uint32_t*>& send, const std::vector<size_t>& send_words, const std::vector<uint32_t*>& recv,
                           const std::vector<size_t>& recv_words) {
+        require_alive();
         ctx->activate();
         auto& api = RcclApi::get();
         VG_NCCL_CHECK(api.GroupStart());

@@ -9,12 +9,30 @@
 //     buffers): what a Rust host with its MPI / TCP / shared-memory layer plugs in, and what lets the sharded prover run one rank per
 //     process on any box (tests: torch.distributed gloo between processes sharing one GPU).
 //
-// FAILURE PROTOCOL (multi-process fabrics).  A rank validates its inputs and allocates between collectives; one that throws alone
-// would leave its peers blocked in the next collective for ever.  Hence every collective is preceded by a one-word STATUS all-gather
-// (`agree`): a rank that failed contributes a non-zero status instead of entering the collective (`fail`, called once by
-// ShardedProof::run's catch-all), its peers read it in their next `agree` and throw as well — every rank returns an error, none hangs.
-// Cost: one tiny all-gather per collective (a few dozen per proof).  LocalFabric drives all ranks from one thread: nothing to agree on.
+// FAILURE PROTOCOL (multi-process fabrics).  A rank that throws alone would leave its peers blocked in the next collective for ever.
+// Every collective therefore runs in FOUR steps:
+//     stage      everything of the collective that can fail on this rank ALONE — sizing and (re)allocating the staging buffers, the
+//                device-to-host copies of what it sends, the stream synchronisation.  Nothing collective has happened yet: a throw
+//                here is an ordinary failure between two collectives.
+//     agree      a one-word STATUS all-gather.  A rank that failed (here or anywhere since the last collective) contributes a non-zero
+//                status instead of entering the collective (`fail`, called once by ShardedProof::run's catch-all); its peers read it and
+//                throw FabricPeerFailure — every rank returns an error, none hangs.
+//     transport  the exchange itself.  Only the transport can fail now (a callback's non-zero status, an RCCL error, the DEADLINE): that
+//                is fatal for the fabric — it is marked `poisoned`, no further collective (not even the status word of `fail`) is
+//                attempted on it, because the peers are inside THIS collective and a different one would be mismatched.  The peers
+//                leave through the transport's own error or through the deadline.
+//     finish     host-to-device copies of what arrived.  A throw here is again a failure between two collectives.
+// DEADLINE.  `timeout_ms` (vgpu_fabric_t::timeout_ms, vgpu_comm_set_timeout_ms; 0 = none) bounds every transport step: a callback that has
+// not returned in time is abandoned on its helper thread (with the buffers it may still write to), an RCCL operation that has not
+// completed is aborted with ncclCommAbort; the rank throws FabricTransportFailure and the fabric is poisoned.  A peer that died —
+// segfault, OOM kill — can therefore cost the survivors at most timeout_ms, not a hang.
+// LocalFabric drives all ranks from one thread: nothing to agree on, nothing to time out.
 #pragma once
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <thread>
 #include "comm.hpp"
 
 namespace vhost {
@@ -22,36 +40,79 @@ namespace vhost {
 struct FabricPeerFailure : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+// the transport itself failed or ran into the deadline in the middle of a collective: the fabric is unusable from here on
+struct FabricTransportFailure : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// Test-only fault injection (documented in DESIGN.md §7): VGPU_FAILPOINT="<name>@<rank>" makes the named step throw on that rank, once
+// per process.  Names: fabric_stage (inside the all-to-all's staging, before the status round), fabric_finish (after the exchange).
+inline bool fabric_failpoint(const char* name, int rank) {
+    static const std::string spec = [] { const char* e = getenv("VGPU_FAILPOINT"); return std::string(e ? e : ""); }();
+    if (spec.empty()) return false;
+    static bool fired = false;
+    if (fired || spec != std::string(name) + "@" + std::to_string(rank)) return false;
+    fired = true;
+    return true;
+}
 
 struct Fabric {
     int world = 1;
     std::vector<int> hosted;  // the ranks living in this process, ascending
     bool peer_failed = false;
+    bool poisoned = false;    // a transport step failed: no collective may follow on this fabric
+    uint32_t timeout_ms = 0;  // deadline of one transport step (0: none)
     virtual ~Fabric() {}
-    // contrib[k]: n words of hosted rank hosted[k] (host memory).  out: world * n words, rank-major — what every rank receives.
-    void all_gather(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) { agree(); do_all_gather(contrib, n, out); }
     struct A2A;
-    void all_to_all(std::vector<A2A>& plan) { agree(); do_all_to_all(plan); }
+    // contrib[k]: n words of hosted rank hosted[k] (host memory).  out: world * n words, rank-major — what every rank receives.
+    void all_gather(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) {
+        check_usable();
+        ag_stage(n);
+        agree();
+        transport([&] { ag_transport(contrib, n, out); });
+    }
+    void all_to_all(std::vector<A2A>& plan) {
+        check_usable();
+        a2a_stage(plan);
+        agree();
+        transport([&] { a2a_transport(plan); });
+        a2a_finish(plan);
+    }
     // Status round before a collective: throws FabricPeerFailure on EVERY rank if any rank reported a failure.
     void agree() {
         if (!needs_agreement()) return;
+        check_usable();
         const uint32_t ok = 0;
         std::vector<uint32_t> all;
-        do_all_gather({&ok}, 1, all);
+        transport([&] { ag_transport({&ok}, 1, all); });
         for (int r = 0; r < world; r++)
             if (all[(size_t)r]) { peer_failed = true; throw FabricPeerFailure("sharded prove: rank " + std::to_string(r) + " failed (status " + std::to_string(all[(size_t)r]) + "); every rank gives up this proof"); }
     }
     // Called by a rank that cannot go on (never throws): its peers learn it in their next agree().  Not after a FabricPeerFailure — then the
-    // peers have already left.
+    // peers have already left — and not on a poisoned fabric: the peers are inside the collective that broke, not in a status round.
     void fail(uint32_t status = 1) noexcept {
-        if (!needs_agreement() || peer_failed) return;
-        try { std::vector<uint32_t> all; const uint32_t st = status ? status : 1u; do_all_gather({&st}, 1, all); peer_failed = true; } catch (...) {}
+        if (!needs_agreement() || peer_failed || poisoned) return;
+        try { std::vector<uint32_t> all; const uint32_t st = status ? status : 1u; transport([&] { ag_transport({&st}, 1, all); }); peer_failed = true; } catch (...) {}
     }
     virtual bool needs_agreement() const { return (int)hosted.size() < world; }
 
   protected:
-    virtual void do_all_gather(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) = 0;
-    virtual void do_all_to_all(std::vector<A2A>& plan) = 0;
+    void check_usable() const {
+        if (poisoned) throw FabricTransportFailure("fabric: an earlier exchange failed or timed out inside the transport; this fabric cannot be used again");
+    }
+    template <class F>
+    void transport(F&& f) {
+        try { f(); }
+        catch (const FabricPeerFailure&) { throw; }
+        catch (const std::exception& e) { poisoned = true; throw FabricTransportFailure(e.what()); }
+        catch (...) { poisoned = true; throw; }
+    }
+    // stage: sizes / allocates whatever ag_transport needs for n words per rank (and one status word); may throw freely
+    virtual void ag_stage(size_t n) { (void)n; }
+    virtual void ag_transport(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) = 0;
+    virtual void a2a_stage(std::vector<A2A>& plan) { (void)plan; }
+    virtual void a2a_transport(std::vector<A2A>& plan) = 0;
+    virtual void a2a_finish(std::vector<A2A>& plan) { (void)plan; }
 
   public:
     // Device all-to-all.  plan[k] belongs to hosted rank hosted[k]: block send[s] (send_words[s] words) goes to rank s, recv[s]
@@ -69,11 +130,11 @@ struct Fabric {
 struct LocalFabric : Fabric {
     explicit LocalFabric(int w) { world = w; for (int r = 0; r < w; r++) hosted.push_back(r); }
   protected:
-    void do_all_gather(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
+    void ag_transport(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
         out.resize((size_t)world * n);
         for (int r = 0; r < world; r++) if (n) memcpy(out.data() + (size_t)r * n, contrib[r], n * 4);
     }
-    void do_all_to_all(std::vector<A2A>& plan) override {
+    void a2a_transport(std::vector<A2A>& plan) override {
         // every context's queued work first: the blocks to be sent must be complete, and a receive buffer fresh from a context's pool
         // may still be read by kernels that context enqueued before the block was recycled (the pool orders reuse on the context's OWN
         // stream only; the copies below run outside it)
@@ -89,24 +150,52 @@ struct LocalFabric : Fabric {
 
 struct RcclFabric : Fabric {
     Comm* comm;
-    explicit RcclFabric(Comm* c) : comm(c) { world = c->world; hosted.push_back(c->rank); }
+    // staging of the all-gathers, grown in ag_stage (before the status round): device [send: cap][recv: cap * world], pinned host of the same shape
+    uint32_t* dev = nullptr;
+    uint32_t* host = nullptr;
+    size_t cap = 0;
+    explicit RcclFabric(Comm* c) : comm(c) { world = c->world; hosted.push_back(c->rank); timeout_ms = c->timeout_ms; grow(64); }
+    ~RcclFabric() override {
+        if (dev) (void)hipFree(dev);
+        if (host) (void)hipHostFree(host);
+    }
+    RcclFabric(const RcclFabric&) = delete;
 
   protected:
-    void do_all_gather(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
+    void grow(size_t n) {
+        if (n <= cap) return;
+        VG_HIP_CHECK(hipSetDevice(comm->ctx->device));
+        VG_HIP_CHECK(hipStreamSynchronize(comm->ctx->stream));
+        if (dev) { VG_HIP_CHECK(hipFree(dev)); dev = nullptr; }
+        if (host) { VG_HIP_CHECK(hipHostFree(host)); host = nullptr; }
+        cap = 0;
+        VG_HIP_CHECK(hipMalloc((void**)&dev, n * (size_t)(world + 1) * 4));
+        VG_HIP_CHECK(hipHostMalloc((void**)&host, n * (size_t)(world + 1) * 4));
+        cap = n;
+    }
+    void ag_stage(size_t n) override { grow(n ? n : 1); }
+    void ag_transport(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
         out.resize((size_t)world * n);
         if (!n) return;
+        comm->require_alive();
         DeviceCtx* c = comm->ctx;
         c->activate();
-        DBuf send(c, n + 4), recv(c, (size_t)world * n + 4);
-        VG_HIP_CHECK(hipMemcpyAsync(send.data, contrib[0], n * 4, hipMemcpyHostToDevice, c->stream));
-        VG_NCCL_CHECK(RcclApi::get().AllGather(send.data, recv.data, n, ncclUint32, comm->comm, c->stream));
-        VG_HIP_CHECK(hipMemcpyAsync(out.data(), recv.data, (size_t)world * n * 4, hipMemcpyDeviceToHost, c->stream));
-        c->sync();
+        memcpy(host, contrib[0], n * 4);
+        VG_HIP_CHECK(hipMemcpyAsync(dev, host, n * 4, hipMemcpyHostToDevice, c->stream));
+        VG_NCCL_CHECK(RcclApi::get().AllGather(dev, dev + cap, n, ncclUint32, comm->comm, c->stream));
+        VG_HIP_CHECK(hipMemcpyAsync(host + cap, dev + cap, (size_t)world * n * 4, hipMemcpyDeviceToHost, c->stream));
+        comm->wait(c->stream, timeout_ms);
+        memcpy(out.data(), host + cap, (size_t)world * n * 4);
     }
-    void do_all_to_all(std::vector<A2A>& plan) override {
+    void a2a_stage(std::vector<A2A>& plan) override {
+        A2A& p = plan.at(0);
+        if ((int)p.send.size() != world || (int)p.recv.size() != world) throw std::logic_error("fabric: plan of the wrong world size");
+        if (p.send_words[comm->rank] != p.recv_words[comm->rank]) throw std::logic_error("fabric: send / receive sizes disagree");
+    }
+    void a2a_transport(std::vector<A2A>& plan) override {
         A2A& p = plan.at(0);
         comm->all_to_all_words(p.send, p.send_words, p.recv, p.recv_words);
-        p.c->sync();
+        comm->wait(p.c->stream, timeout_ms);
     }
 };
 
@@ -116,37 +205,112 @@ struct RcclFabric : Fabric {
 struct CallbackFabric : Fabric {
     using AllGatherFn = int32_t (*)(void* user, const uint32_t* words, uint64_t n_words, uint32_t* out);
     using AllToAllFn = int32_t (*)(void* user, const uint32_t* const* send, const uint64_t* send_words, uint32_t* const* recv, const uint64_t* recv_words);
+    // What a callback may still touch after the deadline abandoned it lives HERE, shared with the helper thread: the staging buffers, the
+    // pointer tables handed to the callback, and the job slot.  The fabric can be destroyed while an abandoned callback is still blocked
+    // in the host's transport; the state dies with its last owner.
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int32_t()> job;
+        bool has_job = false, done = false, quit = false;
+        int32_t rc = 0;
+        uint32_t* host_send = nullptr;
+        uint32_t* host_recv = nullptr;
+        size_t host_send_words = 0, host_recv_words = 0;
+        std::vector<uint32_t> ag_in, ag_out;
+        std::vector<const uint32_t*> hs;
+        std::vector<uint32_t*> hr;
+        std::vector<uint64_t> sw, rw;
+        std::shared_ptr<void> keep;  // caller-owned blocks an abandoned callback may still touch (vgpu_fabric_selftest)
+        ~Shared() {
+            if (host_send) (void)hipHostFree(host_send);
+            if (host_recv) (void)hipHostFree(host_recv);
+        }
+    };
     void* user;
     int rank;
     AllGatherFn ag;
     AllToAllFn a2a;
-    uint32_t* host_send = nullptr;
-    uint32_t* host_recv = nullptr;
-    size_t host_send_words = 0, host_recv_words = 0;
-    CallbackFabric(int rank_, int world_, AllGatherFn ag_, AllToAllFn a2a_, void* user_) : user(user_), rank(rank_), ag(ag_), a2a(a2a_) {
+    std::shared_ptr<Shared> sh = std::make_shared<Shared>();
+    std::thread helper;
+    CallbackFabric(int rank_, int world_, AllGatherFn ag_, AllToAllFn a2a_, void* user_, uint32_t timeout_ms_ = 0) : user(user_), rank(rank_), ag(ag_), a2a(a2a_) {
         if (world_ < 1 || rank_ < 0 || rank_ >= world_ || !ag_ || !a2a_) throw std::invalid_argument("fabric: bad rank / world or a null callback");
         world = world_;
+        timeout_ms = timeout_ms_;
         hosted.push_back(rank_);
     }
     ~CallbackFabric() override {
-        if (host_send) (void)hipHostFree(host_send);
-        if (host_recv) (void)hipHostFree(host_recv);
+        if (helper.joinable()) {
+            { std::lock_guard<std::mutex> lk(sh->mu); sh->quit = true; }
+            sh->cv.notify_all();
+            helper.join();
+        }
     }
     CallbackFabric(const CallbackFabric&) = delete;
     bool needs_agreement() const override { return world > 1; }
     // the host-buffer exchange alone (also what vgpu_fabric_selftest drives without a device)
     void host_all_to_all(const std::vector<const uint32_t*>& send, const std::vector<uint64_t>& send_words, const std::vector<uint32_t*>& recv,
                          const std::vector<uint64_t>& recv_words) {
-        const int32_t rc = a2a(user, send.data(), send_words.data(), recv.data(), recv_words.data());
-        if (rc != 0) throw std::runtime_error("fabric: the host's all_to_all callback failed with status " + std::to_string(rc));
+        check_usable();
+        sh->hs = send; sh->sw = send_words; sh->hr = recv; sh->rw = recv_words;
+        transport([&] { run_a2a(); });
     }
 
   protected:
-    void do_all_gather(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
+    // Runs one callback under the deadline.  timeout_ms == 0: on the calling thread.  Otherwise on the helper thread; if it has not
+    // returned in time the thread is detached with the shared state it may still write to, and this rank leaves with an error.
+    int32_t call(std::function<int32_t()> job, const char* what) {
+        if (!timeout_ms) return job();
+        if (!helper.joinable()) {
+            std::shared_ptr<Shared> s = sh;
+            helper = std::thread([s] {
+                for (;;) {
+                    std::function<int32_t()> j;
+                    {
+                        std::unique_lock<std::mutex> lk(s->mu);
+                        s->cv.wait(lk, [&] { return s->has_job || s->quit; });
+                        if (s->quit) return;
+                        j = std::move(s->job);
+                        s->has_job = false;
+                    }
+                    const int32_t rc = j();
+                    { std::lock_guard<std::mutex> lk(s->mu); s->rc = rc; s->done = true; }
+                    s->cv.notify_all();
+                }
+            });
+        }
+        std::unique_lock<std::mutex> lk(sh->mu);
+        sh->job = std::move(job); sh->has_job = true; sh->done = false;
+        sh->cv.notify_all();
+        if (!sh->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return sh->done; })) {
+            sh->quit = true;  // should the callback ever return, the thread ends
+            lk.unlock();
+            helper.detach();
+            throw std::runtime_error(std::string("fabric: the host's ") + what + " callback did not return within " + std::to_string(timeout_ms) +
+                                     " ms (a peer that died or never entered the exchange?); the callback is abandoned");
+        }
+        return sh->rc;
+    }
+    void run_a2a() {
+        std::shared_ptr<Shared> s = sh;
+        AllToAllFn fn = a2a; void* u = user;
+        const int32_t rc = call([s, fn, u] { return fn(u, s->hs.data(), s->sw.data(), s->hr.data(), s->rw.data()); }, "all_to_all");
+        if (rc != 0) throw std::runtime_error("fabric: the host's all_to_all callback failed with status " + std::to_string(rc));
+    }
+    void ag_stage(size_t n) override {
+        sh->ag_in.reserve(n ? n : 1);
+        sh->ag_out.reserve((size_t)world * (n ? n : 1));
+    }
+    void ag_transport(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
         out.assign((size_t)world * n, 0u);
         if (!n) return;
-        const int32_t rc = ag(user, contrib.at(0), (uint64_t)n, out.data());
+        sh->ag_in.assign(contrib.at(0), contrib.at(0) + n);
+        sh->ag_out.assign((size_t)world * n, 0u);
+        std::shared_ptr<Shared> s = sh;
+        AllGatherFn fn = ag; void* u = user;
+        const int32_t rc = call([s, fn, u, n] { return fn(u, s->ag_in.data(), (uint64_t)n, s->ag_out.data()); }, "all_gather");
         if (rc != 0) throw std::runtime_error("fabric: the host's all_gather callback failed with status " + std::to_string(rc));
+        out = sh->ag_out;
     }
     static void grow(uint32_t*& buf, size_t& have, size_t need) {
         if (need <= have) return;
@@ -155,34 +319,43 @@ struct CallbackFabric : Fabric {
         VG_HIP_CHECK(hipHostMalloc((void**)&buf, need * 4));
         have = need;
     }
-    void do_all_to_all(std::vector<A2A>& plan) override {
+    // everything that can fail on this rank alone: staging buffers, the device-to-host copies of the blocks it sends, its own block on
+    // the device, the synchronisation — BEFORE the status round (fabric.hpp, FAILURE PROTOCOL)
+    void a2a_stage(std::vector<A2A>& plan) override {
         A2A& p = plan.at(0);
         DeviceCtx* c = p.c;
         c->activate();
+        if ((int)p.send.size() != world || (int)p.recv.size() != world) throw std::logic_error("fabric: plan of the wrong world size");
         size_t ns = 0, nr = 0;
         for (int s = 0; s < world; s++) if (s != rank) { ns += p.send_words[s]; nr += p.recv_words[s]; }
-        grow(host_send, host_send_words, ns ? ns : 1);
-        grow(host_recv, host_recv_words, nr ? nr : 1);
-        std::vector<const uint32_t*> hs((size_t)world, nullptr);
-        std::vector<uint32_t*> hr((size_t)world, nullptr);
-        std::vector<uint64_t> sw((size_t)world, 0), rw((size_t)world, 0);
+        Shared& S = *sh;
+        grow(S.host_send, S.host_send_words, ns ? ns : 1);
+        grow(S.host_recv, S.host_recv_words, nr ? nr : 1);
+        S.hs.assign((size_t)world, nullptr); S.hr.assign((size_t)world, nullptr);
+        S.sw.assign((size_t)world, 0); S.rw.assign((size_t)world, 0);
         size_t so = 0, ro = 0;
         for (int s = 0; s < world; s++) {
             if (s == rank) continue;
             if (p.send_words[s]) {
-                VG_HIP_CHECK(hipMemcpyAsync(host_send + so, p.send[s], p.send_words[s] * 4, hipMemcpyDeviceToHost, c->stream));
-                hs[(size_t)s] = host_send + so; sw[(size_t)s] = p.send_words[s]; so += p.send_words[s];
+                VG_HIP_CHECK(hipMemcpyAsync(S.host_send + so, p.send[s], p.send_words[s] * 4, hipMemcpyDeviceToHost, c->stream));
+                S.hs[(size_t)s] = S.host_send + so; S.sw[(size_t)s] = p.send_words[s]; so += p.send_words[s];
             }
-            if (p.recv_words[s]) { hr[(size_t)s] = host_recv + ro; rw[(size_t)s] = p.recv_words[s]; ro += p.recv_words[s]; }
+            if (p.recv_words[s]) { S.hr[(size_t)s] = S.host_recv + ro; S.rw[(size_t)s] = p.recv_words[s]; ro += p.recv_words[s]; }
         }
         if (p.send_words[rank]) {
             if (p.send_words[rank] != p.recv_words[rank]) throw std::logic_error("fabric: send / receive sizes disagree");
             VG_HIP_CHECK(hipMemcpyAsync(p.recv[rank], p.send[rank], p.send_words[rank] * 4, hipMemcpyDeviceToDevice, c->stream));
         }
+        if (fabric_failpoint("fabric_stage", rank)) throw std::runtime_error("fabric: failpoint fabric_stage");
         c->sync();  // the blocks to send are on the host; a receive block fresh from the pool is no longer read by queued kernels
-        host_all_to_all(hs, sw, hr, rw);
+    }
+    void a2a_transport(std::vector<A2A>&) override { run_a2a(); }
+    void a2a_finish(std::vector<A2A>& plan) override {
+        A2A& p = plan.at(0);
+        DeviceCtx* c = p.c;
+        if (fabric_failpoint("fabric_finish", rank)) throw std::runtime_error("fabric: failpoint fabric_finish");
         for (int s = 0; s < world; s++)
-            if (s != rank && p.recv_words[s]) VG_HIP_CHECK(hipMemcpyAsync(p.recv[s], hr[(size_t)s], p.recv_words[s] * 4, hipMemcpyHostToDevice, c->stream));
+            if (s != rank && p.recv_words[s]) VG_HIP_CHECK(hipMemcpyAsync(p.recv[s], sh->hr[(size_t)s], p.recv_words[s] * 4, hipMemcpyHostToDevice, c->stream));
         c->sync();
     }
 };

@@ -45,6 +45,8 @@ struct DeviceTree {
     struct TopChallenger { const uint32_t* pos; uint32_t* state; uint32_t* beta5; uint32_t* commit8; };
     void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats, bool fetch_root = true, const std::function<void()>* before_injection = nullptr,
                const TopChallenger* challenger = nullptr) {
+        // reset on every exit (a throwing build_impl included): the pointers refer to the caller's stack
+        struct Reset { DeviceTree* t; ~Reset() { t->before_injection_ = nullptr; t->challenger_ = nullptr; } } reset{this};
         before_injection_ = before_injection;
         challenger_ = challenger;
         std::vector<ColMat> cms(mats.size());
@@ -53,10 +55,8 @@ struct DeviceTree {
             for (uint64_t col = 0; col < mats[i].width; col++) cms[i].cols.push_back(mats[i].data + col * mats[i].stride);
         }
         build_impl(c, cms, mats.size() == 1 ? &mats[0] : nullptr, fetch_root);
-        before_injection_ = nullptr;
-        challenger_ = nullptr;
     }
-    void build_cols(DeviceCtx* c, const std::vector<ColMat>& mats) { build_impl(c, mats, nullptr, true); }
+    void build_cols(DeviceCtx* c, const std::vector<ColMat>& mats) { before_injection_ = nullptr; challenger_ = nullptr; build_impl(c, mats, nullptr, true); }
 
   private:
     const std::function<void()>* before_injection_ = nullptr;

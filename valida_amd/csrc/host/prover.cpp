@@ -344,6 +344,9 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     const bool prep_hit = prep_cache_enabled_ && !prep_key.empty() && prep_key == prep_key_ && prep_pd_cache_;
     if (!prep_hit) { prep_key_.clear(); prep_pd_cache_.reset(); prep_nat_cache_.clear(); prep_nat_cache_.resize(preprocessed.size()); }
     std::vector<DMat>& prep_nat = prep_nat_cache_;
+    // cache off (the default): nothing of the preprocessed round outlives this proof — the copies, their LDEs and the tree go back to the pool
+    // when prove() leaves, normally or not (vgpu_prover_trim can then return them)
+    struct DropPrep { Prover* p; ~DropPrep() { if (!p->prep_cache_enabled_) { p->prep_key_.clear(); p->prep_pd_cache_.reset(); p->prep_nat_cache_.clear(); } } } drop_prep{this};
     std::vector<int> prep_slot(NC, -1);
     for (size_t k = 0; k < preprocessed.size(); k++) {
         const DeviceTrace* t = preprocessed[k].second;

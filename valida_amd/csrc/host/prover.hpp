@@ -125,7 +125,12 @@ class Prover {
     // launches and their ingest less per proof (about 0.2 ms of a lone proof); the root is observed as ever.
     bool prep_cache_enabled_ = false;
   public:
-    void set_prep_cache(bool on) { prep_cache_enabled_ = on; if (!on) { prep_key_.clear(); prep_pd_cache_.reset(); prep_nat_cache_.clear(); } }
+    // Queues behind a running proof (prove_mu): the cached ProverData and working-layout copies are what that proof is reading.
+    void set_prep_cache(bool on) {
+        std::lock_guard<std::mutex> lk(ctx().prove_mu);
+        prep_cache_enabled_ = on;
+        if (!on) { prep_key_.clear(); prep_pd_cache_.reset(); prep_nat_cache_.clear(); }
+    }
   private:
     std::vector<std::pair<int, uint64_t>> prep_key_;
     std::vector<DMat> prep_nat_cache_;

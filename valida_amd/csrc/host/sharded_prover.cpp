@@ -141,7 +141,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         R.e = logW ? vg::reverse_bits_len((uint32_t)R.rank, logW) : 0u;
         R.ch.reset(new Challenger(&R.p->perm16_));
         if (R.p->fri_.log_blowup != fri.log_blowup || R.p->fri_.num_queries != fri.num_queries || R.p->fri_.pow_bits != fri.pow_bits || R.p->fri_.hash_kind != fri.hash_kind ||
-            R.p->machine_.airs.size() != NC)
+            R.p->fri_.observe_final_poly != fri.observe_final_poly || R.p->machine_.airs.size() != NC)
             throw std::invalid_argument("sharded prove: the ranks' prover contexts must share one configuration");
         if (in[k].main.size() != NC) throw std::invalid_argument("sharded prove: need one main trace per chip and rank");
     }
@@ -377,6 +377,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         std::vector<uint32_t> shape;
         for (size_t i = 0; i < NC; i++) { shape.push_back(log_deg[i]); shape.push_back((uint32_t)(prep_slot[i] + 1)); }
         shape.push_back(log_min_sharded); shape.push_back(fri.log_blowup); shape.push_back(fri.num_queries); shape.push_back(fri.pow_bits); shape.push_back((uint32_t)fri.hash_kind);
+        shape.push_back(fri.observe_final_poly ? 1u : 0u);
         std::vector<const uint32_t*> contrib((size_t)NH, shape.data());
         std::vector<uint32_t> all;
         f.all_gather(contrib, shape.size(), all);
