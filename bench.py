@@ -54,6 +54,18 @@ MICROBENCH_DEFAULTS = {"full_rate": 1.03e12,   # v_add_u32 / v_sub_u32 / v_xor_b
                        "keccak_perm_per_s": 9.9e9, "clock_hz": 2.35e9, "source": "defaults (r02 measurement)"}
 KECCAK_VALU_PER_PERM = 23 * 178 + 58  # kernels/merkle.hip: instructions of one digest-only permutation
 KECCAK_FULL_RATE_PER_ROUND, KECCAK_HALF_RATE_PER_ROUND = 122, 56  # bitop3/xor vs alignbit per round
+# The ISSUE BOUND every VALU roofline below is priced against (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on its
+# SIMD-32, the half-rate class — v_alignbit, 32-bit multiplies, v_mad_u64_u32 — over 4; 256 CUs x 4 SIMDs at the 2.4 GHz maximum clock).
+# No schedule of a given instruction mix can run faster than this; the measured isolated rates (tools/microbench.hip: 2.3-2.5 and
+# 4.1-4.2 cycles) and the code's own in-register ceiling are reported beside it, never as `peak`.
+GUIDE_SIMDS, GUIDE_CLOCK_HZ, GUIDE_FULL_CYCLES, GUIDE_HALF_CYCLES = 1024, 2.4e9, 2.0, 4.0
+
+
+def issue_bound_per_s(full_per_unit, half_per_unit):
+    """Units (permutations ...) per second when every SIMD does nothing but issue the unit's VALU instructions at the guide's rates; one
+    wave-instruction serves 64 units (one per lane)."""
+    return GUIDE_SIMDS * GUIDE_CLOCK_HZ * 64.0 / (full_per_unit * GUIDE_FULL_CYCLES + half_per_unit * GUIDE_HALF_CYCLES)
+
 # kernels/poseidon_mmcs.hip (POSEIDON_HALF_PER_PERM / POSEIDON_FULL_PER_PERM): instructions of one Poseidon-16 permutation as the kernels run it
 # (8 full rounds with the MDS layer as CRT blocks, 21 sparse partial rounds, one dense partial round), by issue class
 POSEIDON_HALF_PER_PERM, POSEIDON_FULL_PER_PERM = 4335, 7064
@@ -80,6 +92,9 @@ def microbench_facts():
             perms = [float(x) * 1e9 for x in re.findall(r"([0-9.]+) G perm/s", k.group(1))]
             clocks = [float(x) * 1e9 for x in re.findall(r"([0-9.]+) GHz", k.group(1))]
             facts["keccak_perm_per_s"], facts["clock_hz"] = max(perms), clocks[perms.index(max(perms))]
+        k = re.search(r"^poseidon16 chain(.*)$", txt, re.M)
+        if k:
+            facts["poseidon_perm_per_s"] = max(float(x) * 1e9 for x in re.findall(r"([0-9.]+) G perm/s", k.group(1)))
         facts["source"] = os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
         pass
@@ -527,26 +542,36 @@ def main():
         # Keccak kernels: permutations per second against (a) the product's own permutation running in registers with nothing else
         # (tools/microbench: the ceiling this code can reach) and (b) the sum of its instructions at their isolated issue rates
         def keccak_roofline(stat):
+            """VALU roofline of a Merkle kernel: permutations per second against the ISSUE BOUND of the permutation's instruction mix (the
+            guide's 2 / 4 cycles per full- / half-rate wave64 instruction at 2.4 GHz on 1024 SIMDs).  Beside it, labelled as what they are:
+            the same mix at the MEASURED isolated rates, and the code's in-register ceiling (a sample of what this very code reaches with
+            no memory traffic — NOT a bound: a launch can exceed it)."""
             launches_, ms_, _, valu_ = stat
             if not valu_ or not ms_:
                 return None
             if name.startswith("k_poseidon"):  # Poseidon-16 kernels: Montgomery products, i.e. half-rate multiply instructions
-                perms = valu_ * 64.0 / (POSEIDON_HALF_PER_PERM + POSEIDON_FULL_PER_PERM)
-                rate = perms / (ms_ * 1e-3)
-                cycles_per_perm = POSEIDON_FULL_PER_PERM * simds * mb["clock_hz"] / mb["full_rate"] + POSEIDON_HALF_PER_PERM * simds * mb["clock_hz"] / mb["half_rate"]
-                model = simds * mb["clock_hz"] * 64.0 / cycles_per_perm
-                return {"achieved": rate, "unit": "Poseidon-16 permutations/s", "peak": model, "frac": rate / model,
-                        "peak_is": "issue model: the %d half-rate (multiplies) + %d full-rate VALU instructions of one permutation as the kernels run it (sparse partial rounds, "
-                                   "MDS layer as CRT blocks) at their isolated issue rates (tools/microbench.hip); no in-register ceiling was measured for this code"
-                                   % (POSEIDON_HALF_PER_PERM, POSEIDON_FULL_PER_PERM)}
-            perms = valu_ * 64.0 / KECCAK_VALU_PER_PERM
+                full_pp, half_pp, unit = POSEIDON_FULL_PER_PERM, POSEIDON_HALF_PER_PERM, "Poseidon-16 permutations/s"
+                mix = "%d half-rate (multiplies) + %d full-rate VALU instructions per permutation as the kernels run it (sparse partial rounds, MDS layer as CRT blocks)" % (half_pp, full_pp)
+                ceiling = mb.get("poseidon_perm_per_s")
+            else:
+                full_pp, half_pp, unit = 24 * KECCAK_FULL_RATE_PER_ROUND, 24 * KECCAK_HALF_RATE_PER_ROUND, "Keccak-f[1600] permutations/s"
+                mix = "24 rounds x (122 full-rate + 56 half-rate VALU instructions)"
+                ceiling = mb.get("keccak_perm_per_s")
+            perms = valu_ * 64.0 / (POSEIDON_HALF_PER_PERM + POSEIDON_FULL_PER_PERM if name.startswith("k_poseidon") else KECCAK_VALU_PER_PERM)
             rate = perms / (ms_ * 1e-3)
-            cycles_per_perm = 24 * (KECCAK_FULL_RATE_PER_ROUND * simds * mb["clock_hz"] / mb["full_rate"] + KECCAK_HALF_RATE_PER_ROUND * simds * mb["clock_hz"] / mb["half_rate"])
-            model = simds * mb["clock_hz"] * 64.0 / cycles_per_perm
-            return {"achieved": rate, "unit": "Keccak-f[1600] permutations/s", "peak": mb["keccak_perm_per_s"], "frac": rate / mb["keccak_perm_per_s"],
-                    "peak_is": "the same permutation code chained in registers, 5 waves per SIMD, no memory traffic (tools/microbench.hip)",
-                    "issue_model_peak": model, "frac_of_issue_model": rate / model,
-                    "issue_model": "24 rounds x (122 full-rate + 56 half-rate VALU instructions) at their isolated issue rates"}
+            bound = issue_bound_per_s(full_pp, half_pp)
+            measured = simds * mb["clock_hz"] * 64.0 / (full_pp * simds * mb["clock_hz"] / mb["full_rate"] + half_pp * simds * mb["clock_hz"] / mb["half_rate"])
+            out_ = {"achieved": rate, "unit": unit, "peak": bound, "frac": rate / bound,
+                    "peak_is": "issue bound: %s at 2 / 4 SIMD-cycles per full- / half-rate wave64 instruction, 1024 SIMDs, 2.4 GHz (MI355X_MICROARCH.md)" % mix,
+                    "measured_issue_peak": measured, "frac_of_measured_issue_peak": rate / measured,
+                    "measured_issue_peak_is": "the same mix at the isolated per-class rates measured on this chip (%s)" % mb["source"],
+                    "permutations_per_launch": perms / launches_ if launches_ else None}
+            if ceiling:
+                out_["code_ceiling"] = ceiling
+                out_["frac_of_code_ceiling"] = rate / ceiling
+                out_["code_ceiling_is"] = "NOT a bound: the product's own permutation chained in registers with no memory traffic (tools/microbench.hip), a sample of what this code reaches"
+            assert out_["frac"] <= 1.0, "a roofline fraction above 1: the peak is not a bound (%r)" % (out_,)
+            return out_
         # whole proof: VALU wave-instructions per proof from the committed PMC pass x this run's step time
         _, pmc_kernels = pmc_file()
         proof_instr = None
@@ -593,12 +618,19 @@ def main():
             },
             "proof_valu_roofline": None if not proof_instr else {
                 "wave64_valu_instr_per_proof": proof_instr, "achieved_instr_per_s": proof_instr / (ms_per_step * 1e-3),
+                "issue_bound_full_rate": GUIDE_SIMDS * GUIDE_CLOCK_HZ / GUIDE_FULL_CYCLES,
+                "frac_of_issue_bound_full_rate": proof_instr / (ms_per_step * 1e-3) / (GUIDE_SIMDS * GUIDE_CLOCK_HZ / GUIDE_FULL_CYCLES),
+                "frac_of_issue_bound_half_rate": proof_instr / (ms_per_step * 1e-3) / (GUIDE_SIMDS * GUIDE_CLOCK_HZ / GUIDE_HALF_CYCLES),
                 "frac_of_full_rate_peak": proof_instr / (ms_per_step * 1e-3) / mb["full_rate"], "frac_of_half_rate_peak": proof_instr / (ms_per_step * 1e-3) / mb["half_rate"],
                 "note": "instruction counts from the committed PMC pass (SQ_INSTS_VALU per launch) x this run's launches per step; the proof's mix of full- and "
                         "half-rate instructions puts its issue peak between the two"},
             "proof_roofline": {"algorithmic_bytes_per_proof": b_alg, "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "phase_ms": {k: v / args.steps for k, v in phase.items()},
             "kernel_ms_per_step": {k: v[1] / table_steps for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])},
+            # the same table with ONE proof on the GPU (exclusive spans: with several proofs in flight the spans of their kernels overlap and a
+            # span / bytes figure of a small kernel is not interpretable — C3's table must be read here)
+            "kernel_ms_per_step_one_proof_in_flight": None if not prof1 else {k: v[1] / 2 for k, v in sorted(prof1.items(), key=lambda kv: -kv[1][1])},
+            "kernel_GBs_one_proof_in_flight": None if not prof1 else {k: (v[2] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in prof1.items()},
             "kernel_GBs": {k: (v[2] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in table.items()},
             "kernel_ms_total_per_step": sum(v[1] for v in table.values()) / table_steps,
             "kernel_table_source": "%d steps with events on every launch, run just before the timed region (same configuration); the timed region times "

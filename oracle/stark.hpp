@@ -329,8 +329,16 @@ struct ProveDebug {  // intermediate values, exposed for stage-parity tests
     std::vector<Matrix> quotient_chunks;
 };
 
+// ORACLE_TIMING=1 in the environment: wall-clock of every phase of prove() on stderr (where the CPU baseline's seconds go)
+struct PhaseClock {
+    bool on = getenv("ORACLE_TIMING") != nullptr;
+    double t0 = omp_get_wtime();
+    void lap(const char* what) { if (!on) return; double t = omp_get_wtime(); fprintf(stderr, "oracle phase %-28s %8.3f s\n", what, t - t0); t0 = t; }
+};
+
 inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, const StarkConfig& cfg, ProveDebug* dbg = nullptr,
                           bool debug_check = false) {
+    PhaseClock clk;
     size_t NC = machine.chips.size();
     Poseidon16 perm16(cfg.poseidon_constants.data());
     Challenger ch(&perm16);
@@ -349,9 +357,11 @@ inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, co
     }
     for (size_t k = 0; k < in.preprocessed.size(); k++) { prep_of[in.preprocessed[k].first] = &in.preprocessed[k].second; prep_slot[in.preprocessed[k].first] = (int)k; }
 
+    clk.lap("commit preprocessed");
     // main (lib.rs:203-225)
     MerkleTree main_tree = pcs_commit(in.main_traces, cfg.fri);
     ch.observe(main_tree.root());
+    clk.lap("commit main");
     std::vector<Ext5> rnd;
     for (int i = 0; i < 3; i++) rnd.push_back(ch.sample_ext());
 
@@ -366,9 +376,11 @@ inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, co
         perm_flat[i] = Matrix(n, 5 * W);  // flatten_to_base
         for (size_t r = 0; r < n; r++) for (size_t c = 0; c < W; c++) for (int k = 0; k < 5; k++) perm_flat[i].at(r, 5 * c + k) = perm_traces[i][r * W + c].c[k];
     }
+    clk.lap("permutation traces");
     MerkleTree perm_tree = pcs_commit(perm_flat, cfg.fri);
     ch.observe(perm_tree.root());
     Ext5 alpha = ch.sample_ext();
+    clk.lap("commit permutation");
 
     if (debug_check) {  // #[cfg(debug_assertions)] check_constraints + check_cumulative_sums
         for (size_t i = 0; i < NC; i++) {
@@ -392,8 +404,10 @@ inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, co
         quotients[i] = decompose_and_flatten(qv, coset_shift(), lqd[i]);
         coset_shifts[i] = coset_shift().exp_power_of_2(lqd[i]);
     }
+    clk.lap("quotient values + decompose");
     MerkleTree quot_tree = pcs_commit(quotients, coset_shifts, cfg.fri);
     ch.observe(quot_tree.root());
+    clk.lap("commit quotient");
 
     // opening (lib.rs:606-619)
     Ext5 zeta = ch.sample_ext();
@@ -405,6 +419,7 @@ inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, co
         rquot.points.push_back({zeta.exp_power_of_2(lqd[i])});
     }
     auto opened = pcs_open({rmain, rperm, rquot}, ch, cfg.fri);
+    clk.lap("open (values, reduce, FRI)");
 
     MachineProof proof;
     proof.main_commit = main_tree.root();

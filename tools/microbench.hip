@@ -15,6 +15,8 @@
 #include <vector>
 #include "kernels/keccak.hpp"  // -I valida_amd/csrc: the product's Keccak-f[1600]
 #include "field.hpp"           // and its Montgomery arithmetic
+#include "kernels/poseidon_perm.hpp"  // the product's Poseidon-16 permutation (MMCS kernels, proof-of-work search)
+#include "host/poseidon_opt.hpp"      // its sparse-round / CRT-block tables (host construction)
 
 #define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(_e)); exit(2); } } while (0)
 
@@ -127,6 +129,23 @@ template <bool DIGEST_ONLY> __global__ void __launch_bounds__(256) k_keccak_chai
     const uint64_t c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     uint32_t x = 0;
     for (int i = 0; i < 25; i++) x ^= a.lo[i] ^ a.hi[i];
+    out[t] = x;
+    if (t == 0) { g_clk[0] = c1 - c0; g_clk[1] = w1 - w0; }
+}
+
+// The product's Poseidon-16 (kernels/poseidon_perm.hpp: sparse partial rounds, MDS layer as CRT blocks) on register-resident state, `iters`
+// chained permutations per thread, tables through the scalar cache exactly as the MMCS kernels read them.
+__device__ const uint32_t* g_pos_tab;
+__global__ void __launch_bounds__(256) k_poseidon_chain(uint32_t* out, uint32_t seed, int iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    vg::Fp st[16];
+    for (int i = 0; i < 16; i++) st[i] = vg::Fp::raw((t * 2654435761u + i * seed) % vg::P);
+    const vk::PoseidonTab tab = vk::tab_of(g_pos_tab, true);
+    const uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; it++) vk::poseidon16_permute(st, tab);
+    const uint64_t c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    uint32_t x = 0;
+    for (int i = 0; i < 16; i++) x ^= st[i].v;
     out[t] = x;
     if (t == 0) { g_clk[0] = c1 - c0; g_clk[1] = w1 - w0; }
 }
@@ -286,6 +305,29 @@ int main(int argc, char** argv) {
                "what one 178-instruction round costs the SIMD; 122 full-rate + 56 half-rate instructions would cost ~530 at the rates above)\n");
         keccak_row("keccak_f1600 full", k_keccak_chain<false>, cu, d);
         keccak_row("keccak_f1600 digest", k_keccak_chain<true>, cu, d);
+        {
+            // Poseidon-16 of kernels/poseidon_perm.hpp: the same constants as the tests (SplitMix64 is not needed here: any constants cost the same)
+            std::vector<uint32_t> rc(480);
+            for (int i = 0; i < 480; i++) rc[i] = (uint32_t)((0x9E3779B97F4A7C15ull * (uint64_t)(i + 1)) >> 33) % vg::P;
+            vhost::Poseidon16 perm(rc.data());
+            bool sparse = false;
+            const std::vector<uint32_t> img = vhost::poseidon_device_image(rc.data(), perm, sparse);
+            uint32_t* dtab = nullptr;
+            CHECK(hipMalloc((void**)&dtab, img.size() * 4));
+            CHECK(hipMemcpy(dtab, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pos_tab), &dtab, sizeof(dtab)));
+            printf("Poseidon-16 of kernels/poseidon_perm.hpp (sparse tables %s), chained permutations in registers, at 1..5 waves per SIMD\n", sparse ? "valid" : "INVALID: plain rounds");
+            printf("%-20s", "poseidon16 chain");
+            const int iters = 64;
+            for (int wps : {1, 2, 3, 4, 5}) {
+                const int blocks = cu * wps;
+                const double ms = time_kernel(k_poseidon_chain, blocks, iters, d);
+                const double perms = (double)blocks * 256 * iters, clk = last_kernel_clock_hz();
+                printf("  %5.3f G perm/s (%.0f cyc/perm/wave, %.2f GHz)", perms / ms / 1e6, cu * 4.0 * clk * ms * 1e-3 / ((double)blocks * 4 * iters), clk / 1e9);
+            }
+            printf("\n");
+            CHECK(hipFree(dtab));
+        }
         CHECK(hipFree(d)); CHECK(hipFree(dc));
     }
     if (!strcmp(what, "copies") || !strcmp(what, "all")) copy_rows();

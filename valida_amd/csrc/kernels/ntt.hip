@@ -782,10 +782,10 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
     if (p.k_lo == 12 && mid12) {
         static const unsigned cap = [] { const char* e = getenv("VGPU_MID12_GRID"); return e ? (unsigned)atoi(e) : 4096u; }();  // persistent blocks (A/B)
         if (cap && gm.x > cap) gm.x = cap;
-        ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
+        ProfScope ps("k_lde_mid12", st, nw * (1.0 + b));
         VK_LAUNCH(k_lde_mid12, gm, dim3(256), (size_t)padded_words(4096) * 4, st, s1, s2, k, log_blowup, tb, lt);
     } else if (p.k_lo == 14 && mid12 && mid14) {
-        ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
+        ProfScope ps("k_lde_mid14", st, nw * (1.0 + b));
         VK_LAUNCH(k_lde_mid14, gm, dim3(1024), (size_t)padded_words(16384) * 4, st, s1, s2, k, log_blowup, tb, lt);
     } else {
         ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
