@@ -37,6 +37,9 @@ StarkConfig make_cfg(const uint32_t* rc, uint32_t log_blowup, uint32_t num_queri
 
 extern "C" {
 void oracle_set_observe_final_poly(int on) { g_observe_final_poly = on != 0; }
+// Fast mode (fast.hpp): the same proof words computed with AVX2 Montgomery transforms, an unrolled Keccak, batch inversions.  Process-wide.
+void oracle_set_fast(int on) { oracle::fast::enabled() = on != 0; }
+int oracle_get_fast() { return oracle::fast::enabled() ? 1 : 0; }
 // MMCS hash of every commitment made after the call: 0 = Keccak (reference), 1 = Poseidon-16 sponge / truncated permutation with
 // the given round constants (hash.hpp "MMCS hash selection")
 void oracle_set_mmcs_hash(int kind, const uint32_t* rc480) {

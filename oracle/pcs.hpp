@@ -12,8 +12,16 @@
 #include <map>
 #include <omp.h>
 #include "hash.hpp"
+#include "fast.hpp"
 
 namespace oracle {
+
+// ORACLE_TIMING=1 in the environment: wall-clock of every phase of prove() on stderr (where the CPU baseline's seconds go)
+struct PhaseClock {
+    bool on = getenv("ORACLE_TIMING") != nullptr;
+    double t0 = omp_get_wtime();
+    void lap(const char* what) { if (!on) return; double t = omp_get_wtime(); fprintf(stderr, "oracle phase %-28s %8.3f s\n", what, t - t0); t0 = t; }
+};
 
 // ---------------------------------------------------------------- DFT (App. B3)
 // In-place iterative radix-2 on one column (natural in, natural out).
@@ -120,8 +128,14 @@ inline MerkleTree mmcs_commit(std::vector<Matrix> mats) {
     std::vector<const Matrix*> group;
     while (pos < order.size() && order[pos]->height == maxh) group.push_back(order[pos++]);
     std::vector<Digest> layer(maxh);
-    #pragma omp parallel for
-    for (size_t r = 0; r < maxh; r++) layer[r] = hash_rows(group, r);
+    const bool fast_keccak = fast::enabled() && mmcs_hash().kind == 0;  // fast mode: unrolled permutation, rows absorbed in place (fast.hpp)
+    if (fast_keccak && maxh >= 4) {  // four rows per call
+        #pragma omp parallel for schedule(static)
+        for (size_t r = 0; r < maxh; r += 4) fast::keccak_hash_rows_x4(group, r, &layer[r]);
+    } else {
+        #pragma omp parallel for
+        for (size_t r = 0; r < maxh; r++) layer[r] = fast_keccak ? fast::keccak_hash_rows(group, r) : hash_rows(group, r);
+    }
     t.digest_layers.push_back(std::move(layer));
     while (t.digest_layers.back().size() > 1) {
         const auto& prev = t.digest_layers.back();
@@ -129,8 +143,30 @@ inline MerkleTree mmcs_commit(std::vector<Matrix> mats) {
         group.clear();
         while (pos < order.size() && order[pos]->height == len) group.push_back(order[pos++]);
         std::vector<Digest> next(len);
+        if (fast_keccak && len >= 4) {  // four parents per call
+            #pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < len; i += 4) {
+                const Digest* l[4] = {&prev[2 * i], &prev[2 * i + 2], &prev[2 * i + 4], &prev[2 * i + 6]};
+                const Digest* r[4] = {&prev[2 * i + 1], &prev[2 * i + 3], &prev[2 * i + 5], &prev[2 * i + 7]};
+                if (group.empty()) { fast::keccak_compress_x4(l, r, &next[i]); continue; }
+                Digest d[4], h[4];
+                fast::keccak_compress_x4(l, r, d);
+                fast::keccak_hash_rows_x4(group, i, h);
+                const Digest* dp[4] = {&d[0], &d[1], &d[2], &d[3]};
+                const Digest* hp[4] = {&h[0], &h[1], &h[2], &h[3]};
+                fast::keccak_compress_x4(dp, hp, &next[i]);
+            }
+            t.digest_layers.push_back(std::move(next));
+            continue;
+        }
         #pragma omp parallel for
         for (size_t i = 0; i < len; i++) {
+            if (fast_keccak) {
+                Digest d = fast::keccak_compress(prev[2 * i], prev[2 * i + 1]);
+                if (!group.empty()) d = fast::keccak_compress(d, fast::keccak_hash_rows(group, i));
+                next[i] = d;
+                continue;
+            }
             Digest d = compress(prev[2 * i], prev[2 * i + 1]);
             if (!group.empty()) d = compress(d, hash_rows(group, i));
             next[i] = d;
@@ -195,12 +231,19 @@ inline Fp coset_shift() { return Fp(GENERATOR); }
 
 // commit_shifted_batches: lde_i = coset_lde_batch(m_i, log_blowup, 31 / shift_i), rows bit-reversed.
 inline MerkleTree pcs_commit(const std::vector<Matrix>& polys, const std::vector<Fp>& shifts, const FriConfig& cfg) {
+    const double t_start = omp_get_wtime();
     std::vector<Matrix> ldes;
     for (size_t i = 0; i < polys.size(); i++) {
         Fp s = coset_shift() * shifts[i].inv();
-        ldes.push_back(bit_reverse_rows(coset_lde_batch(polys[i], cfg.log_blowup, s)));
+        if (fast::enabled()) ldes.push_back(fast::coset_lde_bitrev(polys[i], cfg.log_blowup, s));  // fast mode: AVX2 Montgomery transforms (fast.hpp)
+        else ldes.push_back(bit_reverse_rows(coset_lde_batch(polys[i], cfg.log_blowup, s)));
     }
-    return mmcs_commit(std::move(ldes));
+    PhaseClock clk;
+    clk.t0 = t_start;
+    clk.lap("  lde");
+    MerkleTree t = mmcs_commit(std::move(ldes));
+    clk.lap("  merkle tree");
+    return t;
 }
 inline MerkleTree pcs_commit(const std::vector<Matrix>& polys, const FriConfig& cfg) {
     return pcs_commit(polys, std::vector<Fp>(polys.size(), Fp::one()), cfg);
@@ -275,6 +318,20 @@ inline std::vector<Ext5> fold_even_odd(const std::vector<Ext5>& f, const Ext5& b
     Fp g_inv = two_adic_generator(k + 1).inv();
     Fp one_half = Fp(2).inv();
     std::vector<Ext5> out(half);
+    if (fast::enabled()) {  // the powers of 1 / g by running products scattered to their bit-reversed places, the products with reductions hoisted
+        std::vector<Fp> xi(half);
+        #pragma omp parallel for schedule(static)
+        for (size_t c0 = 0; c0 < half; c0 += 4096) {
+            Fp cur = g_inv.pow(c0);
+            for (size_t i = c0; i < std::min(half, c0 + 4096); i++) { xi[reverse_bits_len(i, k)] = cur; cur *= g_inv; }
+        }
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < half; i++) {
+            const Ext5 power = beta * (one_half * xi[i]);
+            out[i] = fast::ext_mul(power + one_half, f[2 * i]) + fast::ext_mul(-power + one_half, f[2 * i + 1]);
+        }
+        return out;
+    }
     #pragma omp parallel for
     for (size_t i = 0; i < half; i++) {
         Fp xinv = g_inv.pow(reverse_bits_len(i, k));
@@ -287,6 +344,7 @@ inline std::vector<Ext5> fold_even_odd(const std::vector<Ext5>& f, const Ext5& b
 // ExtensionMmcs::commit_matrix of a (len/2 x 2) Ext5 matrix = base MMCS over its 10-column flattening.
 inline Matrix flatten_pairs(const std::vector<Ext5>& f) {
     Matrix m(f.size() / 2, 10);
+    #pragma omp parallel for schedule(static) if (fast::enabled())
     for (size_t r = 0; r < m.height; r++)
         for (int e = 0; e < 2; e++)
             for (int c = 0; c < 5; c++) m.at(r, 5 * e + c) = f[2 * r + e].c[c];
@@ -295,11 +353,67 @@ inline Matrix flatten_pairs(const std::vector<Ext5>& f) {
 
 struct RoundData { const MerkleTree* tree; std::vector<std::vector<Ext5>> points; /* per matrix */ };
 
+// ---------------------------------------------------------------- fast mode of the opening (fast.hpp): same values, computed once
+// What the scalar code above does element by element — an Ext5 inversion per (matrix, point, LDE row), a power of the generator per row —
+// is shared here: 1 / (z - x) over an LDE domain depends on (height, z) only and comes from ONE batch inversion; the trace-domain
+// weights of interpolate_coset are a subset of it; a matrix's alpha-reduced rows are computed once for all its points.
+namespace fast {
+struct OpenTables {
+    struct Key { unsigned lh; std::array<uint32_t, 5> z; bool operator<(const Key& o) const { return lh != o.lh ? lh < o.lh : z < o.z; } };
+    std::map<Key, std::vector<Ext5>> dinv;       // [x] = 1 / (z - s g_L^bitrev(x)), x in committed (bit-reversed) order
+    std::map<unsigned, std::vector<Fp>> gpow;    // [x] = g_L^bitrev(x)
+    const std::vector<Fp>& powers(unsigned lh) {
+        auto it = gpow.find(lh);
+        if (it != gpow.end()) return it->second;
+        const size_t L = size_t(1) << lh;
+        std::vector<Fp> g(L);
+        const Fp w = two_adic_generator(lh);
+        #pragma omp parallel for schedule(static)
+        for (size_t c0 = 0; c0 < L; c0 += 4096) {
+            Fp cur = w.pow(c0);
+            for (size_t i = c0; i < std::min(L, c0 + 4096); i++) { g[reverse_bits_len(i, lh)] = cur; cur *= w; }
+        }
+        return gpow.emplace(lh, std::move(g)).first->second;
+    }
+    const std::vector<Ext5>& inverses(unsigned lh, const Ext5& z) {
+        Key key{lh, {z.c[0].v, z.c[1].v, z.c[2].v, z.c[3].v, z.c[4].v}};
+        auto it = dinv.find(key);
+        if (it != dinv.end()) return it->second;
+        const std::vector<Fp>& g = powers(lh);
+        const size_t L = size_t(1) << lh;
+        std::vector<Ext5> d(L);
+        const Fp s = Fp(GENERATOR);
+        #pragma omp parallel for schedule(static)
+        for (size_t x = 0; x < L; x++) d[x] = z - s * g[x];
+        batch_inverse_ext(d.data(), L);
+        return dinv.emplace(key, std::move(d)).first->second;
+    }
+};
+// sum_r w_r * row_r[c] for Ext5 weights and base-field rows, five lazily reduced 64-bit accumulators per column
+struct ExtAcc {
+    std::vector<uint64_t> a;  // [c][5]
+    unsigned pending = 0;
+    explicit ExtAcc(size_t width) : a(5 * width, 0) {}
+    void add_row(const Ext5& w, const Fp* row, size_t width) {
+        const uint64_t w0 = w.c[0].v, w1 = w.c[1].v, w2 = w.c[2].v, w3 = w.c[3].v, w4 = w.c[4].v;
+        for (size_t c = 0; c < width; c++) {
+            const uint64_t v = row[c].v;
+            uint64_t* p = &a[5 * c];
+            p[0] += w0 * v; p[1] += w1 * v; p[2] += w2 * v; p[3] += w3 * v; p[4] += w4 * v;
+        }
+        if (++pending == 3) { for (auto& x : a) x %= P; pending = 0; }  // 2^31 + 3 (p - 1)^2 < 2^64
+    }
+    Ext5 get(size_t c) const { Ext5 r; for (int k = 0; k < 5; k++) r.c[k] = Fp::from_u64(a[5 * c + k]); return r; }
+};
+}  // namespace fast
+
 inline std::pair<OpenedValues, PcsProof> pcs_open(const std::vector<RoundData>& rounds, Challenger& ch, const FriConfig& cfg) {
+    const double t_open0 = omp_get_wtime();
     Ext5 alpha = ch.sample_ext();
     std::map<unsigned, std::vector<Ext5>> ro;  // log_height -> reduced openings (bit-reversed domain order)
     std::map<unsigned, size_t> num_reduced;
     OpenedValues all;
+    fast::OpenTables ftab;
     for (auto& rd : rounds) {
         std::vector<std::vector<std::vector<Ext5>>> round_vals;
         for (size_t mi = 0; mi < rd.tree->leaves.size(); mi++) {
@@ -313,6 +427,49 @@ inline std::pair<OpenedValues, PcsProof> pcs_open(const std::vector<RoundData>& 
             for (size_t j = 0; j < mat.width; j++) { apow[j] = ap; ap *= alpha; }
             std::vector<std::vector<Ext5>> mat_vals;
             Fp gh = two_adic_generator(lh);
+            if (fast::enabled()) {
+                const size_t L = mat.height, n = L >> cfg.log_blowup, W = mat.width;
+                const unsigned k = log2_strict(n);
+                // the alpha-reduced rows, once for all points of this matrix
+                std::vector<Ext5> rr(L);
+                #pragma omp parallel for schedule(static)
+                for (size_t x = 0; x < L; x++) {
+                    uint64_t a[5] = {0, 0, 0, 0, 0};
+                    const Fp* row = mat.row(x);
+                    for (size_t j = 0; j < W; j++) {
+                        const uint64_t v = row[j].v;
+                        for (int q = 0; q < 5; q++) a[q] += (uint64_t)apow[j].c[q].v * v;
+                        if (j % 3 == 2) for (int q = 0; q < 5; q++) a[q] %= P;
+                    }
+                    for (int q = 0; q < 5; q++) rr[x].c[q] = Fp::from_u64(a[q]);
+                }
+                const std::vector<Fp>& gn = ftab.powers(k);  // g_n^bitrev_k(r): the trace domain's points in committed order
+                for (auto& z : rd.points[mi]) {
+                    const std::vector<Ext5>& dinv = ftab.inverses(lh, z);
+                    // interpolate_coset: the first n committed rows are the evaluations on s H_n; 1 / (z - s g_n^i) sits at the same row
+                    std::vector<Ext5> ys(W);
+                    #pragma omp parallel
+                    {
+                        fast::ExtAcc part(W);
+                        #pragma omp for schedule(static) nowait
+                        for (size_t r = 0; r < n; r++) part.add_row(dinv[r] * gn[r], mat.row(r), W);
+                        #pragma omp critical
+                        for (size_t c = 0; c < W; c++) ys[c] += part.get(c);
+                    }
+                    const Ext5 zerofier = z.exp_power_of_2(k) - coset_shift().exp_power_of_2(k);
+                    const Ext5 scale = zerofier * (Fp((uint32_t)(n % P)) * coset_shift().pow(n - 1)).inv();
+                    for (size_t c = 0; c < W; c++) ys[c] = ys[c] * scale;
+                    const Ext5 off = alpha.pow(num_reduced[lh]);
+                    Ext5 ysum;
+                    for (size_t j = 0; j < W; j++) ysum += apow[j] * ys[j];
+                    #pragma omp parallel for schedule(static)
+                    for (size_t x = 0; x < L; x++) r[x] += fast::ext_mul(fast::ext_mul(off, ysum - rr[x]), dinv[x]);
+                    num_reduced[lh] += W;
+                    mat_vals.push_back(std::move(ys));
+                }
+                round_vals.push_back(std::move(mat_vals));
+                continue;
+            }
             for (auto& z : rd.points[mi]) {
                 std::vector<Ext5> ys = interpolate_coset(mat, mat.height >> cfg.log_blowup, coset_shift(), z);
                 Ext5 off = alpha.pow(num_reduced[lh]);
@@ -333,6 +490,9 @@ inline std::pair<OpenedValues, PcsProof> pcs_open(const std::vector<RoundData>& 
         all.push_back(std::move(round_vals));
     }
 
+    PhaseClock clk;
+    clk.t0 = t_open0;
+    clk.lap("  opened values + reduced openings");
     // FRI commit phase
     unsigned log_max = ro.rbegin()->first;
     std::vector<Ext5> cur = ro[log_max];
@@ -346,8 +506,12 @@ inline std::pair<OpenedValues, PcsProof> pcs_open(const std::vector<RoundData>& 
         Ext5 beta = ch.sample_ext();
         cur = fold_even_odd(cur, beta);
         auto it = ro.find(lf);
-        if (it != ro.end()) for (size_t i = 0; i < cur.size(); i++) cur[i] += it->second[i];
+        if (it != ro.end()) {
+            #pragma omp parallel for schedule(static) if (fast::enabled())
+            for (size_t i = 0; i < cur.size(); i++) cur[i] += it->second[i];
+        }
     }
+    clk.lap("  fri commit phase");
     if (cur.size() != (size_t(1) << cfg.log_blowup)) { fprintf(stderr, "oracle: fri: bad final length\n"); abort(); }
     for (auto& x : cur) if (x != cur[0]) { fprintf(stderr, "oracle: fri: final poly not constant\n"); abort(); }
     proof.fri.final_poly = cur[0];

@@ -254,6 +254,12 @@ class ProveResult:
             self._h = None
 
 
+def set_fast(on):
+    """Fast mode (oracle/fast.hpp): identical proof words, computed the way a tuned CPU prover would (AVX2 Montgomery NTTs, unrolled Keccak,
+    batch inversions).  Used by bench.py's cpu_baseline leg (kind "port-simd") and fixture generation; the scalar mode stays the checker."""
+    lib().oracle_set_fast(ctypes.c_int(1 if on else 0))
+
+
 def set_mmcs_hash(kind, rc=None):
     """0: Keccak MMCS (the reference's); 1: Poseidon-16 sponge / truncated permutation with round constants `rc`."""
     if kind == 1:

@@ -45,6 +45,39 @@ template <class T> struct Folder {
     void assert_zero_ext(const Ext5& x) { acc = acc * alpha + x; num_constraints++; }
 };
 
+// Fast mode's ProverConstraintFolder: the same sum  acc = sum_k alpha^(K-1-k) c_k  with the K powers of alpha precomputed (K = the chip's
+// constraint count, taken from one evaluation with the folder above): a base-field constraint costs five products instead of the
+// twenty-five of acc * alpha, accumulated in five lazily reduced 64-bit sums.
+struct FastFolder {
+    using Expr = Fp;
+    TwoRows<Fp> main_, prep_;
+    TwoRows<Ext5> perm_;
+    size_t perm_width = 0;
+    Fp first, last, trans;
+    const Ext5* apow = nullptr;  // apow[k] = alpha^(K-1-k)
+    uint64_t a[5] = {0, 0, 0, 0, 0};
+    unsigned pending = 0;
+    size_t num_constraints = 0;
+    Fp from_u32(uint32_t k) const { return Fp(k); }
+    const Fp* main_local() const { return main_.local; }
+    const Fp* main_next() const { return main_.next; }
+    Fp is_first_row() const { return first; }
+    Fp is_last_row() const { return last; }
+    Fp is_transition() const { return trans; }
+    void assert_zero(const Fp& x) {
+        const Ext5& w = apow[num_constraints++];
+        const uint64_t v = x.v;
+        for (int k = 0; k < 5; k++) a[k] += (uint64_t)w.c[k].v * v;
+        if (++pending == 3) { for (int k = 0; k < 5; k++) a[k] %= P; pending = 0; }
+    }
+    void assert_zero_ext(const Ext5& x) {
+        const Ext5 t = fast::ext_mul(apow[num_constraints++], x);
+        for (int k = 0; k < 5; k++) a[k] = (a[k] + t.c[k].v) % P;
+        pending = 0;
+    }
+    Ext5 acc() const { Ext5 r; for (int k = 0; k < 5; k++) r.c[k] = Fp::from_u64(a[k]); return r; }
+};
+
 // DebugConstraintBuilder (machine/src/debug_builder.rs): records the first failing constraint index.
 struct DebugBuilder {
     using Expr = Fp;
@@ -152,6 +185,7 @@ inline std::vector<Ext5> generate_permutation_trace(const ChipDesc& chip, const 
     for (size_t m = 0; m < M; m++) { alphas[m] = bus_alpha(chip.interactions[m], rnd); max_fields = std::max(max_fields, chip.interactions[m].fields.size()); }
     Ext5 bp = Ext5::one();
     for (size_t j = 0; j < max_fields; j++) { betas.push_back(bp); bp *= rnd[2]; }
+    const bool fast_mode = fast::enabled();  // fast mode: ONE batch inversion (the reference's own batch_multiplicative_inverse_allowing_zero) instead of one per element
     #pragma omp parallel for
     for (size_t r = 0; r < n; r++) {
         const Fp* prow = prep ? prep->row(r) : nullptr;
@@ -161,8 +195,42 @@ inline std::vector<Ext5> generate_permutation_trace(const ChipDesc& chip, const 
             for (size_t j = 0; j < f.size(); j++) rlc += betas[j] * apply_vcol<Fp>(f[j], prow, main.row(r));
             rlc += alphas[m];
             // batch_multiplicative_inverse_allowing_zero: zeros stay zero (util/src/lib.rs:21-43)
-            perm[r * W + m] = rlc.is_zero() ? rlc : rlc.inv();
+            perm[r * W + m] = (fast_mode || rlc.is_zero()) ? rlc : rlc.inv();
         }
+    }
+    if (fast_mode && M) {
+        std::vector<Ext5> tmp(n * M);
+        #pragma omp parallel for schedule(static)
+        for (size_t r = 0; r < n; r++) for (size_t m = 0; m < M; m++) tmp[r * M + m] = perm[r * W + m];
+        fast::batch_inverse_ext(tmp.data(), tmp.size());
+        #pragma omp parallel for schedule(static)
+        for (size_t r = 0; r < n; r++) for (size_t m = 0; m < M; m++) perm[r * W + m] = tmp[r * M + m];
+    }
+    if (fast_mode) {
+        // the running sum as a parallel prefix sum: per-row terms, per-chunk totals, a serial scan over the chunk totals, chunk-local sums —
+        // exact arithmetic: the same values as the serial loop below
+        const size_t CH = 8192, nch = (n + CH - 1) / CH;
+        std::vector<Ext5> total(nch);
+        #pragma omp parallel for schedule(static)
+        for (size_t c = 0; c < nch; c++) {
+            Ext5 acc;
+            for (size_t r = c * CH; r < std::min(n, (c + 1) * CH); r++) {
+                const Fp* prow = prep ? prep->row(r) : nullptr;
+                for (size_t m = 0; m < M; m++) {
+                    Fp mult = apply_vcol<Fp>(chip.interactions[m].count, prow, main.row(r));
+                    if (chip.interactions[m].is_send()) acc += perm[r * W + m] * mult; else acc -= perm[r * W + m] * mult;
+                }
+                perm[r * W + M] = acc;  // chunk-local running sum
+            }
+            total[c] = acc;
+        }
+        std::vector<Ext5> before(nch);
+        Ext5 run;
+        for (size_t c = 0; c < nch; c++) { before[c] = run; run += total[c]; }
+        #pragma omp parallel for schedule(static)
+        for (size_t c = 1; c < nch; c++)
+            for (size_t r = c * CH; r < std::min(n, (c + 1) * CH); r++) perm[r * W + M] += before[c];
+        return perm;
     }
     Ext5 phi;
     for (size_t r = 0; r < n; r++) {  // serial running sum (chip.rs:178-201)
@@ -242,6 +310,52 @@ inline std::vector<Ext5> quotient_values(const ChipDesc& chip, unsigned log_degr
     for (size_t i = 0; i < next_step; i++) { zh[i] = s_pow_n * wp - Fp::one(); zh_inv[i] = zh[i].inv(); wp *= wq; }
     size_t mw = main_lde.width(), pw = prep_lde ? prep_lde->width() : 0, ew = perm_lde.width() / 5;
     std::vector<Ext5> out(qsize);
+    if (fast::enabled()) {
+        // fast mode: the points by running products, the two selector denominators by batch inversion, rows read in place (a committed
+        // row IS a contiguous row-major row; five consecutive base elements of the flattened permutation LDE ARE one Ext5), powers of alpha
+        static_assert(sizeof(Ext5) == 5 * sizeof(Fp), "Ext5 must be five packed base elements");
+        std::vector<Fp> xs(qsize), inv_first(qsize), inv_last(qsize);
+        #pragma omp parallel for schedule(static)
+        for (size_t c0 = 0; c0 < qsize; c0 += 4096) {
+            Fp cur = s * g_ext.pow(c0);
+            for (size_t i = c0; i < std::min(qsize, c0 + 4096); i++) { xs[i] = cur; inv_first[i] = cur - Fp::one(); inv_last[i] = cur - subgroup_last; cur *= g_ext; }
+        }
+        fast::batch_inverse(inv_first.data(), qsize);
+        fast::batch_inverse(inv_last.data(), qsize);
+        size_t K = 0;
+        {   // the chip's constraint count: one evaluation with the plain folder
+            std::vector<Fp> zm(mw), zp(pw);
+            std::vector<Ext5> ze(ew);
+            Folder<Fp> f;
+            f.main_ = {zm.data(), zm.data()}; f.prep_ = {zp.data(), zp.data()}; f.perm_ = {ze.data(), ze.data()};
+            f.alpha = alpha;
+            chips::eval(chip.id, f);
+            eval_permutation_constraints(chip, f, rnd, cumulative_sum);
+            K = f.num_constraints;
+        }
+        std::vector<Ext5> apow(K ? K : 1);
+        Ext5 ap = Ext5::one();
+        for (size_t k = K; k-- > 0;) { apow[k] = ap; ap = fast::ext_mul(ap, alpha); }
+        const unsigned kb = main_lde.k;
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < qsize; i++) {
+            const size_t inext = (i + next_step) % qsize;
+            const size_t r0 = reverse_bits_len(i * stride, kb), r1 = reverse_bits_len(inext * stride, kb);
+            FastFolder f;
+            f.main_ = {main_lde.m->row(r0), main_lde.m->row(r1)};
+            if (prep_lde) f.prep_ = {prep_lde->m->row(r0), prep_lde->m->row(r1)};
+            f.perm_ = {reinterpret_cast<const Ext5*>(perm_lde.m->row(r0)), reinterpret_cast<const Ext5*>(perm_lde.m->row(r1))};
+            f.trans = xs[i] - subgroup_last;
+            const Fp z = zh[i % next_step];
+            f.first = z * inv_first[i];
+            f.last = z * inv_last[i];
+            f.apow = apow.data();
+            chips::eval(chip.id, f);
+            eval_permutation_constraints(chip, f, rnd, cumulative_sum);
+            out[i] = f.acc() * zh_inv[i % next_step];
+        }
+        return out;
+    }
     #pragma omp parallel
     {
         std::vector<Fp> ml(mw), mn(mw), pl(pw), pn(pw);
@@ -277,6 +391,23 @@ inline std::vector<std::vector<Ext5>> decompose(const std::vector<Ext5>& poly, F
     size_t n = poly.size(), half = n / 2;
     Fp g_inv = two_adic_generator(log2_strict(n)).inv(), one_half = Fp(2).inv();
     std::vector<Ext5> even(half), odd(half);
+    if (fast::enabled()) {  // the same loop in chunks with their own starting power
+        const Fp sinv = shift.inv();
+        #pragma omp parallel for schedule(static)
+        for (size_t c0 = 0; c0 < half; c0 += 4096) {
+            Fp gp = sinv * g_inv.pow(c0);
+            for (size_t i = c0; i < std::min(half, c0 + 4096); i++) {
+                Ext5 a = poly[i], bb = poly[half + i];
+                even[i] = (a + bb) * one_half;
+                odd[i] = (a - bb) * (one_half * gp);
+                gp *= g_inv;
+            }
+        }
+        auto combined = decompose(even, shift * shift, log_chunks - 1);
+        auto rest = decompose(odd, shift * shift, log_chunks - 1);
+        combined.insert(combined.end(), rest.begin(), rest.end());
+        return combined;
+    }
     Fp gp = shift.inv();  // g_inv.shifted_powers(shift.inverse())
     for (size_t i = 0; i < half; i++) {
         Ext5 a = poly[i], bb = poly[half + i];
@@ -293,6 +424,7 @@ inline Matrix decompose_and_flatten(const std::vector<Ext5>& q, Fp shift, unsign
     auto chunks = decompose(q, shift, log_chunks);
     size_t degree = chunks[0].size();
     Matrix m(degree, 5 * chunks.size());
+    #pragma omp parallel for schedule(static) if (fast::enabled())
     for (size_t r = 0; r < degree; r++)
         for (size_t ch = 0; ch < chunks.size(); ch++)
             for (int k = 0; k < 5; k++) m.at(r, 5 * ch + k) = chunks[ch][r].c[k];
@@ -327,13 +459,6 @@ struct ProveDebug {  // intermediate values, exposed for stage-parity tests
     Ext5 alpha, zeta;
     std::vector<std::vector<Ext5>> perm_traces;
     std::vector<Matrix> quotient_chunks;
-};
-
-// ORACLE_TIMING=1 in the environment: wall-clock of every phase of prove() on stderr (where the CPU baseline's seconds go)
-struct PhaseClock {
-    bool on = getenv("ORACLE_TIMING") != nullptr;
-    double t0 = omp_get_wtime();
-    void lap(const char* what) { if (!on) return; double t = omp_get_wtime(); fprintf(stderr, "oracle phase %-28s %8.3f s\n", what, t - t0); t0 = t; }
 };
 
 inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, const StarkConfig& cfg, ProveDebug* dbg = nullptr,
@@ -374,6 +499,7 @@ inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, co
         size_t W = machine.chips[i].interactions.size() + 1, n = in.main_traces[i].height;
         cumulative_sums[i] = perm_traces[i][(n - 1) * W + W - 1];
         perm_flat[i] = Matrix(n, 5 * W);  // flatten_to_base
+        #pragma omp parallel for schedule(static) if (fast::enabled())
         for (size_t r = 0; r < n; r++) for (size_t c = 0; c < W; c++) for (int k = 0; k < 5; k++) perm_flat[i].at(r, 5 * c + k) = perm_traces[i][r * W + c].c[k];
     }
     clk.lap("permutation traces");
@@ -401,7 +527,9 @@ inline MachineProof prove(const MachineDesc& machine, const MachineInput& in, co
         if (prep_slot[i] >= 0) pl.reset(new LdeView(&prep_tree.leaves[prep_slot[i]]));
         auto qv = quotient_values(machine.chips[i], log_degrees[i], lqd[i], pl.get(), main_lde, perm_lde, cfg.fri.log_blowup,
                                   cumulative_sums[i], rnd, alpha);
+        if (i == 0 || i == 2) clk.lap(i == 0 ? "  quotient values (cpu)" : "  quotient values (.. mem)");
         quotients[i] = decompose_and_flatten(qv, coset_shift(), lqd[i]);
+        if (i == 0 || i == 2) clk.lap(i == 0 ? "  decompose (cpu)" : "  decompose (mem)");
         coset_shifts[i] = coset_shift().exp_power_of_2(lqd[i]);
     }
     clk.lap("quotient values + decompose");
