@@ -69,7 +69,7 @@ def issue_bound_per_s(full_per_unit, half_per_unit):
 
 # kernels/poseidon_mmcs.hip (POSEIDON_HALF_PER_PERM / POSEIDON_FULL_PER_PERM): instructions of one Poseidon-16 permutation as the kernels run it
 # (8 full rounds with the MDS layer as CRT blocks, 21 sparse partial rounds, one dense partial round), by issue class
-POSEIDON_HALF_PER_PERM, POSEIDON_FULL_PER_PERM = 4335, 7064
+POSEIDON_HALF_PER_PERM, POSEIDON_FULL_PER_PERM = 3945, 5264
 
 
 def microbench_facts():

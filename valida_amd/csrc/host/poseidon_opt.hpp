@@ -34,7 +34,11 @@ struct PoseidonOptTables {
     static constexpr int BLK_N8 = FFT_LAM + 16;       // [8][8]  y-[k] = sum_j N8[k][j] (a[j] - a[j + 8])
     static constexpr int BLK_C4 = BLK_N8 + 64;        // [4][4]  on a++[j] = (a[j] + a[j + 8]) + (a[j + 4] + a[j + 12])
     static constexpr int BLK_N4 = BLK_C4 + 16;        // [4][4]  on a+-[j] = (a[j] + a[j + 8]) - (a[j + 4] + a[j + 12])
-    static constexpr int WORDS = BLK_N4 + 16;
+    // The sparse partial rounds in groups of four with DEFERRED updates of coordinates 1..15 (kernels/poseidon_perm.hpp): inside a group a round
+    // reads the coordinates as they stood at the group's start and corrects for the group's earlier rounds through the scalars
+    // cross[r][j] = u_r . w_(4 (r / 4) + j), j < r mod 4.
+    static constexpr int CROSS = BLK_N4 + 16;         // [21 (+3 pad)][4]
+    static constexpr int WORDS = CROSS + 24 * 4;
     std::vector<uint32_t> words;
     bool valid = false;
 
@@ -128,6 +132,13 @@ struct PoseidonOptTables {
                 words[BLK_N4 + 4 * k + j] = (j <= k ? cpm[k - j] : -cpm[4 + k - j]).v;
             }
         }
+        for (int r = 0; r < 21; r++)
+            for (int j = 0; j < r % 4; j++) {
+                const int q = 4 * (r / 4) + j;
+                Fp acc = Fp::zero();
+                for (int b = 1; b < 16; b++) acc += Fp::raw(words[SPARSE + 32 * r + b]) * Fp::raw(words[SPARSE + 32 * q + 15 + b]);
+                words[CROSS + 4 * r + j] = acc.v;
+            }
         valid = true;
         // self-check against the plain permutation
         uint64_t seed = 0x9E3779B97F4A7C15ull;
@@ -173,13 +184,20 @@ struct PoseidonOptTables {
         auto sbox = [](Fp x) { Fp x2 = x * x; return x2 * x2 * x; };
         for (int r = 0; r < 4; r++) { for (int i = 0; i < 16; i++) st[i] = sbox(st[i] + W(RC_FULL + 16 * r + i)); mds_blocks(st); }  // both table sets are exercised:
         st[0] += W(T_SCALARS);
-        for (int i = 0; i < 21; i++) {
-            const int s = SPARSE + 32 * i;
-            const Fp x0 = sbox(st[0]);
-            Fp n0 = W(s) * x0;
-            for (int b = 1; b < 16; b++) n0 += W(s + b) * st[b];
-            for (int a = 1; a < 16; a++) st[a] += W(s + 15 + a) * x0;
-            st[0] = n0 + W(T_SCALARS + i + 1);
+        for (int g0 = 0; g0 < 21; g0 += 4) {  // groups of four rounds: coordinates 1..15 are updated at the group's end (as the kernels do)
+            Fp x0s[4], upd[16];
+            for (auto& u : upd) u = Fp::zero();
+            for (int k = 0; k < 4 && g0 + k < 21; k++) {
+                const int i = g0 + k, s = SPARSE + 32 * i;
+                const Fp x0 = sbox(st[0]);
+                x0s[k] = x0;
+                Fp n0 = W(s) * x0;
+                for (int b = 1; b < 16; b++) n0 += W(s + b) * st[b];
+                for (int j = 0; j < k; j++) n0 += W(CROSS + 4 * i + j) * x0s[j];
+                for (int a = 1; a < 16; a++) upd[a] += W(s + 15 + a) * x0;
+                st[0] = n0 + W(T_SCALARS + i + 1);
+            }
+            for (int a = 1; a < 16; a++) st[a] += upd[a];
         }
         st[0] = sbox(st[0]);
         Fp out[16];

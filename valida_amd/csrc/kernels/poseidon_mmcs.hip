@@ -12,7 +12,8 @@
 // coefficients are wave-uniform: they are read through the scalar cache (s_load_dwordx16 per round) rather than staged in LDS —
 // a uniform LDS read still costs a ds_read per value per wave, a scalar load costs no VALU/LDS issue slot at all.
 // Integer-VALU-bound: ~0.8 k instructions per dense round (16 x 16 lazily accumulated products); the 22 partial rounds run in their
-// sparse-matrix form (31 products each, one dense round at the end), ~12 k instructions per permutation instead of ~26 k.
+// sparse-matrix form (31 products each, one dense round at the end) with deferred updates in groups of four rounds, the S-boxes on
+// signed Montgomery products: ~9.5 k instructions per permutation (26 k in the plain form, 11.4 k in round 3).
 #include "launch.hpp"
 #include "poseidon_perm.hpp"
 #include "challenger_dev.hpp"
@@ -112,15 +113,17 @@ __global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, Poseidon
 
 // Algorithmic VALU work for the profiler's valu_ops column (like KECCAK_VALU_PER_PERM): the instructions of ONE permutation as these kernels run
 // it, by issue class (bench.py holds the same two numbers and prices them at the measured issue rates).
-//   half rate (v_mad_u64_u32 / v_mul_lo_u32 / v_mul_hi_u32): a Montgomery product is 3, a lazily accumulated term 1, a reduction of <= 4 terms 2
-//     S-boxes (8 x 16 + 22) x 3 products            1350
-//     MDS layer as CRT blocks, 8 x (96 + 24 x 2)     1152
-//     sparse partial rounds, 21 x (16 + 4 x 2 + 15 x 3)  1449
-//     dense partial round, 16 x (16 + 4 x 2)          384
-//   full rate (add / sub / carry / select): a product's correction 3, a reduction 5, a modular addition 3
-//     round constants 8 x 16 x 3 = 384; S-boxes 450 x 3 = 1350; MDS 8 x (48 x 3 + 24 x 5 + 8 x 3) = 2304;
-//     sparse rounds 21 x (4 x 5 + 3 x 3 + 15 x 6 + 3) = 2562; dense round 16 x (4 x 5 + 3 x 3) = 464
-constexpr double POSEIDON_HALF_PER_PERM = 1350.0 + 1152.0 + 1449.0 + 384.0, POSEIDON_FULL_PER_PERM = 384.0 + 1350.0 + 2304.0 + 2562.0 + 464.0;
+//   half rate (v_mad_u64_u32 / v_mad_i64_i32 / v_mul_lo_u32 / v_mul_hi_[ui]32): a Montgomery product is 3, a lazily accumulated term 1, a reduction of <= 4 terms 2
+//     S-boxes (8 x 16 + 22) x 3 products                                              1350
+//     MDS layer as CRT blocks, 8 x (96 + 24 x 2)                                       1152
+//     sparse partial rounds in groups of four with deferred updates (poseidon_perm.hpp):
+//       5 groups x (4 x (16 + 15) + 6 cross terms + 34 reductions x 2) + (31 + 19 x 2)  1059
+//     dense partial round, 16 x (16 + 4 x 2)                                            384
+//   full rate (add / sub / carry / select): a signed product's subtraction 1, a reduction 5, a modular addition 3
+//     round constants 8 x 16 x 1 = 128 (one addition: the signed S-box takes x + (c - p) unreduced); S-boxes 150 x (3 + 3) = 900 (signed Montgomery
+//     products, one correction); MDS 8 x (48 x 3 + 24 x 5 + 8 x 3) = 2304; sparse rounds 189 reductions x 5 + (5 x 34 + 19) additions x 3 - 21 x 2 = 1470;
+//     dense round 16 x (4 x 5 + 3 x 3) - 2 = 462
+constexpr double POSEIDON_HALF_PER_PERM = 1350.0 + 1152.0 + 1059.0 + 384.0, POSEIDON_FULL_PER_PERM = 128.0 + 900.0 + 2304.0 + 1470.0 + 462.0;
 constexpr double POSEIDON_VALU_PER_PERM = POSEIDON_HALF_PER_PERM + POSEIDON_FULL_PER_PERM;
 static double p_row_perms(int n_elems) { return (double)((n_elems + 7) / 8); }
 static double p_node_perms(int n_inject) { return n_inject > 0 ? 2.0 + p_row_perms(n_inject) : 1.0; }

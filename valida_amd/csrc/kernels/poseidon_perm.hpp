@@ -14,7 +14,8 @@ struct PoseidonTab {
 };
 // offsets into `opt` (words) — must match vhost::PoseidonOptTables
 constexpr int POPT_RC_FULL = 0, POPT_T = 128, POPT_SPARSE = 152, POPT_F = 152 + 21 * 32, POPT_FFT_FWD = POPT_F + 256, POPT_FFT_INV = POPT_FFT_FWD + 16,
-              POPT_FFT_LAM = POPT_FFT_INV + 16, POPT_BLK_N8 = POPT_FFT_LAM + 16, POPT_BLK_C4 = POPT_BLK_N8 + 64, POPT_BLK_N4 = POPT_BLK_C4 + 16;
+              POPT_FFT_LAM = POPT_FFT_INV + 16, POPT_BLK_N8 = POPT_FFT_LAM + 16, POPT_BLK_C4 = POPT_BLK_N8 + 64, POPT_BLK_N4 = POPT_BLK_C4 + 16,
+              POPT_CROSS = POPT_BLK_N4 + 16;
 
 // y = M x with M circulant; four products share one Montgomery reduction (4 p^2 < 2^64)
 __device__ __forceinline__ void poseidon_mds(Fp (&st)[16], const uint32_t (&m)[16]) {
@@ -79,7 +80,46 @@ __device__ __forceinline__ void poseidon_mds_blocks(Fp (&st)[16], const uint32_t
         st[i + 4] = hi + ym[i + 4]; st[i + 12] = hi - ym[i + 4];
     }
 }
-__device__ __forceinline__ Fp poseidon_sbox(Fp x) { const Fp x2 = x * x; return x2 * x2 * x; }
+// x^5.  VGPU_POSEIDON_SBOX=1 (default): SIGNED Montgomery products — (t - (t_lo p^-1 mod+- 2^32) p) / 2^32 of a signed 64-bit product with
+// |t| < p 2^31 lies in (-p, p) with NO correction step, and a product of two such values is again below p 2^31 — so x^2, x^4 and x^5 chain
+// without the three-instruction corrections and ONE correction brings the result back to [0, p): 15 instead of 18 VALU instructions per
+// S-box (150 S-boxes per permutation), the same residue, hence the same canonical value.  =0: three plain Montgomery products (A/B builds).
+#ifndef VGPU_POSEIDON_SBOX
+#define VGPU_POSEIDON_SBOX 1
+#endif
+__device__ __forceinline__ int32_t monty_signed(int64_t t) {
+    const int32_t m = (int32_t)((uint32_t)t * 0x88000001u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int32_t u = __mulhi(m, (int32_t)vg::P);
+#else
+    const int32_t u = (int32_t)(((int64_t)m * (int64_t)vg::P) >> 32);
+#endif
+    return (int32_t)(t >> 32) - u;
+}
+// x1 in [-p, p] (any representative of the residue in that range)
+__device__ __forceinline__ Fp poseidon_sbox_i(int32_t x1) {
+    const int32_t x2 = monty_signed((int64_t)x1 * x1);
+    const int32_t x4 = monty_signed((int64_t)x2 * x2);
+    const int32_t x5 = monty_signed((int64_t)x4 * x1);
+    return Fp::raw((uint32_t)(x5 + ((x5 >> 31) & (int32_t)vg::P)));
+}
+__device__ __forceinline__ Fp poseidon_sbox(Fp x) {
+#if VGPU_POSEIDON_SBOX
+    return poseidon_sbox_i((int32_t)x.v);  // < p < 2^31
+#else
+    const Fp x2 = x * x;
+    return x2 * x2 * x;
+#endif
+}
+// S-box of x + c for a wave-uniform constant c: the signed product takes x + (c - p) in [-p, p) as it is — ONE addition (the constant's
+// c - p is scalar-unit work) where the modular addition costs three instructions
+__device__ __forceinline__ Fp poseidon_sbox_plus(Fp x, uint32_t c) {
+#if VGPU_POSEIDON_SBOX
+    return poseidon_sbox_i((int32_t)x.v + (int32_t)(c - vg::P));
+#else
+    return poseidon_sbox(x + Fp::raw(c));
+#endif
+}
 
 // row . state for one row of 16 wave-uniform coefficients
 __device__ __forceinline__ Fp poseidon_dot16(const uint32_t* __restrict__ row, const Fp (&st)[16]) {
@@ -92,6 +132,45 @@ __device__ __forceinline__ Fp poseidon_dot16(const uint32_t* __restrict__ row, c
         acc += Fp::raw(vg::monty_reduce_wide(t));
     }
     return acc;
+}
+
+#ifndef VGPU_POSEIDON_DEFER
+#define VGPU_POSEIDON_DEFER 1  // the sparse partial rounds in groups of four with deferred updates (below); 0: round by round (A/B builds)
+#endif
+// N consecutive sparse rounds starting at round g0 (a multiple of 4), st[1..15] updated at the end
+template <int N> __device__ __forceinline__ void poseidon_sparse_group(Fp (&st)[16], const uint32_t* __restrict__ o, int g0) {
+    uint64_t upd[16];
+    Fp x0s[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const uint32_t* __restrict__ s = o + POPT_SPARSE + 32 * (g0 + k);
+        const uint32_t* __restrict__ cr = o + POPT_CROSS + 4 * (g0 + k);
+        const Fp x0 = poseidon_sbox_plus(st[0], o[POPT_T + g0 + k]);  // the round's scalar rides in the S-box's input
+        x0s[k] = x0;
+        // a x0 + u . x^(group start) + sum_j cross[j] x0_j: 16 + k terms, four per reduction
+        uint64_t t = (uint64_t)s[0] * x0.v;
+#pragma unroll
+        for (int b = 1; b < 4; b++) t += (uint64_t)s[b] * st[b].v;
+        Fp n0 = Fp::raw(vg::monty_reduce_wide(t));
+#pragma unroll
+        for (int b0 = 4; b0 < 16; b0 += 4) {
+            t = 0;
+#pragma unroll
+            for (int b = b0; b < b0 + 4; b++) t += (uint64_t)s[b] * st[b].v;
+            n0 += Fp::raw(vg::monty_reduce_wide(t));
+        }
+        if (k > 0) {
+            t = 0;
+#pragma unroll
+            for (int j = 0; j < k; j++) t += (uint64_t)cr[j] * x0s[j].v;
+            n0 += Fp::raw(vg::monty_reduce_wide(t));
+        }
+#pragma unroll
+        for (int a = 1; a < 16; a++) upd[a] = k == 0 ? (uint64_t)s[15 + a] * x0.v : upd[a] + (uint64_t)s[15 + a] * x0.v;
+        st[0] = n0;
+    }
+#pragma unroll
+    for (int a = 1; a < 16; a++) st[a] += Fp::raw(vg::monty_reduce_wide(upd[a]));
 }
 
 __device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonTab& tab) {
@@ -119,10 +198,21 @@ __device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonT
     for (int r = 0; r < 4; r++) {
         const uint32_t* rc = o + POPT_RC_FULL + 16 * r;
 #pragma unroll
-        for (int i = 0; i < 16; i++) st[i] = poseidon_sbox(st[i] + Fp::raw(rc[i]));
+        for (int i = 0; i < 16; i++) st[i] = poseidon_sbox_plus(st[i], rc[i]);
         if (VGPU_POSEIDON_MDS == 2) poseidon_mds_blocks(st, o); else if (VGPU_POSEIDON_MDS == 1) poseidon_mds_convolution(st, o); else poseidon_mds(st, m);
     }
+#if !VGPU_POSEIDON_DEFER
     st[0] += Fp::raw(o[POPT_T]);
+#endif
+#if VGPU_POSEIDON_DEFER
+    // The 21 sparse rounds in groups of four with the updates of coordinates 1..15 DEFERRED to the group's end: a round's dot product reads
+    // the coordinates as they stood at the group's start and adds cross[r][j] x0_j for the group's earlier rounds (u_r . w_j, host table),
+    // all in the same lazily reduced sums; the updates w_r[b] x0_r accumulate as one 64-bit multiply-add each and are reduced once per group
+    // (four products < 4 p^2 < 2^64) — 118 instead of 191 instructions per round.
+#pragma unroll 1
+    for (int g0 = 0; g0 < 20; g0 += 4) poseidon_sparse_group<4>(st, o, g0);
+    poseidon_sparse_group<1>(st, o, 20);
+#else
 #pragma unroll 1
     for (int i = 0; i < 21; i++) {
         const uint32_t* __restrict__ s = o + POPT_SPARSE + 32 * i;
@@ -136,8 +226,13 @@ __device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonT
         for (int a = 1; a < 16; a++) st[a] += Fp::raw(s[15 + a]) * x0;  // x^ + w x0
         st[0] = n0 + Fp::raw(o[POPT_T + 1 + i]);
     }
+#endif
     {
+#if VGPU_POSEIDON_DEFER
+        st[0] = poseidon_sbox_plus(st[0], o[POPT_T + 21]);  // the last partial round's scalar, still pending
+#else
         st[0] = poseidon_sbox(st[0]);
+#endif
         Fp out[16];
 #pragma unroll
         for (int a = 0; a < 16; a++) out[a] = poseidon_dot16(o + POPT_F + 16 * a, st);
@@ -148,7 +243,7 @@ __device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonT
     for (int r = 4; r < 8; r++) {
         const uint32_t* rc = o + POPT_RC_FULL + 16 * r;
 #pragma unroll
-        for (int i = 0; i < 16; i++) st[i] = poseidon_sbox(st[i] + Fp::raw(rc[i]));
+        for (int i = 0; i < 16; i++) st[i] = poseidon_sbox_plus(st[i], rc[i]);
         if (VGPU_POSEIDON_MDS == 2) poseidon_mds_blocks(st, o); else if (VGPU_POSEIDON_MDS == 1) poseidon_mds_convolution(st, o); else poseidon_mds(st, m);
     }
 }
