@@ -362,6 +362,21 @@ typedef struct vgpu_fabric {
 } vgpu_fabric_t;
 int32_t vgpu_prove_sharded_fabric(vgpu_prover_t* p, const vgpu_fabric_t* fabric, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips,
                                   const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out);
+/* The same three entry points with ROW-RANGE inputs: the traces themselves are sharded.  A chip whose LDE is sharded — at least
+ * max(4 world, 2^log_min_sharded, 2 * 2^log_blowup) LDE rows: vgpu_sharded_trace_is_split says so for a trace height — hands in ONLY its rows
+ * [rank n / world, (rank + 1) n / world) (a trace of n / world rows, natural order); every other chip its whole trace.  full_heights[i] = chip i's
+ * whole trace height n on every rank.  Per-rank trace memory and the permutation-trace work are then 1 / world too: generate_permutation_trace's
+ * running sum (machine/src/chip.rs:176-205) becomes a local scan plus ONE all-gather of the ranks' totals (5 words per chip), and every
+ * commitment round deals the row ranges into whole columns with one more all-to-all.  The preprocessed traces (constants of the program) are
+ * handed in whole on every rank.  The proof words are those of vgpu_prove on one GPU. */
+uint32_t vgpu_sharded_trace_is_split(uint32_t world, uint32_t log_blowup, uint32_t log_min_sharded, uint64_t height);
+int32_t vgpu_prove_sharded_rows(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace_t* const* main, uint32_t n_main, const uint64_t* full_heights, const uint32_t* prep_chips,
+                                const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out);
+int32_t vgpu_prove_sharded_rows_fabric(vgpu_prover_t* p, const vgpu_fabric_t* fabric, const vgpu_trace_t* const* main, uint32_t n_main, const uint64_t* full_heights,
+                                       const uint32_t* prep_chips, const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out);
+/* main[r * n_main + i] = rank r's rows (or whole trace) of chip i as uploaded through provers[r] */
+int32_t vgpu_prove_sharded_rows_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* main, uint32_t n_main, const uint64_t* full_heights,
+                                      const uint32_t* prep_chips, const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out);
 /* Host-only check of a transport before proofs depend on it (no device needed): a status round, an all_gather of n_words rank-dependent
  * words and an all_to_all of rank-pair-dependent blocks of different sizes, every received word verified.  fail_rank < world makes that
  * rank fail between two exchanges the way a failing proof would: every rank must then return a non-zero status — none may hang. */

@@ -177,6 +177,72 @@ def test_sharded_proof_of_c3_at_full_size(machine, rc):
     assert_fixture(sharded, mt, "full_c3_fib599183_blowup4.json")
 
 
+# ---- the traces themselves sharded (round-3 verdict, item 6): every sharded chip hands in only its rows [rank n / W, (rank + 1) n / W) -----------------
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_row_range_inputs_fib25_every_chip_split(machine, rc, fib25, world):
+    """prove_fibonacci with every chip above 4 * world LDE rows handed in as row ranges (the chips with preprocessed traces included: their
+    permutation traces read a row range of the whole preprocessed trace): local scans + ONE exchange of the ranks' totals reproduce
+    generate_permutation_trace's running sums and cumulative sums (machine/src/chip.rs:176-205), the commitment rounds deal rows into columns."""
+    p0, mt, prep, single = single_and_inputs(machine, rc, fib25)
+    provers = [p0] + [va.Prover(machine, rc) for _ in range(world - 1)]
+    split = [va.sharded_trace_is_split(world, m.shape[0], 1, 2) for m in mt]
+    assert any(split) and not all(split)
+    sharded = va.prove_sharded_rows_local(provers, mt, prep, log_min_sharded=2)
+    assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc)
+
+
+@pytest.mark.parametrize("world,log_min,log_blowup", [(4, 12, 1), (2, 10, 1), (8, 8, 2)])
+def test_row_range_inputs_with_split_and_whole_chips(machine, rc, world, log_min, log_blowup):
+    """fib(582): cpu / mem / add as row ranges, the small chips whole — and with C3's 4x blowup over eight ranks."""
+    w = va.Workload.fib(582)
+    p0, mt, prep, single = single_and_inputs(machine, rc, w, log_blowup=log_blowup)
+    provers = [p0] + [va.Prover(machine, rc, log_blowup=log_blowup) for _ in range(world - 1)]
+    sharded = va.prove_sharded_rows_local(provers, mt, prep, log_min_sharded=log_min)
+    assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc, log_blowup=log_blowup)
+
+
+def test_row_range_inputs_of_the_alu_workload_and_the_poseidon_mmcs(machine, rc):
+    w = va.Workload.alu(300)
+    p0, mt, prep, single = single_and_inputs(machine, rc, w, hash_kind=va.HASH_POSEIDON16)
+    provers = [p0] + [va.Prover(machine, rc, hash_kind=va.HASH_POSEIDON16) for _ in range(3)]
+    sharded = va.prove_sharded_rows_local(provers, mt, prep, log_min_sharded=6)
+    assert_same_proof(sharded.words, single.words)
+    assert_oracle_proof(sharded.words, mt, prep, rc, hash_kind=va.HASH_POSEIDON16)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_row_range_inputs_at_the_headline_size(machine, rc, world):
+    """C2 with cpu / mem / add handed in as row ranges: per-rank trace memory 1 / world; the oracle's proof by the committed fixture."""
+    w = va.Workload.fib(149794)
+    mt, prep = w.main_traces(), w.preprocessed()
+    provers = [va.Prover(machine, rc) for _ in range(world)]
+    sharded = va.prove_sharded_rows_local(provers, mt, prep)
+    assert_fixture(sharded, mt, "full_c2_fib149794.json")
+    # what a rank was handed: its share of the three big chips, the small ones whole
+    mats, full = va.row_ranges(mt, 1, world)
+    assert sum(m.nbytes for m in mats) < 1.02 * sum(m.nbytes for m in mt) / world + sum(m.nbytes for m, f in zip(mt, full) if not va.sharded_trace_is_split(world, f))
+
+
+def test_row_range_inputs_are_validated(machine, rc, fib25):
+    mt, prep = fib25.main_traces(), fib25.preprocessed()
+    provers = [va.Prover(machine, rc) for _ in range(2)]
+    real = va.row_ranges
+
+    def wrong(main_traces, rank, world, log_blowup=1, log_min_sharded=12):
+        mats, full = real(main_traces, rank, world, log_blowup, log_min_sharded)
+        mats[0] = main_traces[0]  # the whole cpu trace where a row range is due
+        return mats, full
+
+    va.row_ranges = wrong
+    try:
+        with pytest.raises(va.VgpuError, match="must hand in its row range"):
+            va.prove_sharded_rows_local(provers, mt, prep, log_min_sharded=2)
+    finally:
+        va.row_ranges = real
+
+
 def test_sharded_proof_refuses_what_it_does_not_implement(machine, rc, fib25):
     mt, prep = fib25.main_traces(), fib25.preprocessed()
     provers = [va.Prover(machine, rc) for _ in range(3)]

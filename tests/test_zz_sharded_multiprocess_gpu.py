@@ -84,11 +84,14 @@ def _worker(rank, world, store, q, fixture, log_min, sabotage, logdir, fabric_ti
 
             fab._a2a_py = broken
         stage = "upload"
+        full = None
+        if sabotage is not None and sabotage[1] == "rows":  # no sabotage: the ROW-RANGE form — this rank uploads only its rows of the sharded chips
+            mt, full = va.row_ranges(mt, rank, world, 1, log_min)
         dmain, dprep = [p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep]
         stage = "prove"
         t0 = time.time()
         try:
-            proof = fab.prove_sharded(p, dmain, dprep, log_min_sharded=log_min)
+            proof = fab.prove_sharded(p, dmain, dprep, log_min_sharded=log_min, full_heights=full)
             res = {"commitments": [int(x) for x in proof.words[2:26]], "words": int(proof.words.size), "sha": hashlib.sha256(proof.bytes()).hexdigest(),
                    "want": [g["commitments"], g["proof_words"], g["proof_sha256"]]}
         except va.VgpuError as e:
@@ -179,6 +182,13 @@ def test_one_rank_per_process_at_the_headline_size(world):
     """C2 (fib 149 794: cpu 2^20, mem 2^22 rows), cpu / mem / add sharded, FRI layers sharded down to 2^12: every process's proof has the
     sha256 of the oracle's proof of these traces."""
     _assert_oracle_proof(_run(world, "full_c2_fib149794.json", 12), world)
+
+
+@pytest.mark.parametrize("world,fixture,log_min", [(4, "fib582_oracle.json", 12), (2, "full_c2_fib149794.json", 12)])
+def test_one_rank_per_process_with_row_range_inputs(world, fixture, log_min):
+    """The traces themselves sharded across the PROCESSES (vgpu_prove_sharded_rows_fabric): every rank uploads only its rows of cpu / mem / add;
+    the running sums of the permutation traces are completed by one exchange of the ranks' totals over the fabric."""
+    _assert_oracle_proof(_run(world, fixture, log_min, sabotage=(-1, "rows")), world)
 
 
 def _assert_all_failed(res, world):

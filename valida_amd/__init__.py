@@ -648,6 +648,47 @@ def upload_replicated(provers, main_traces, preprocessed):
     return [[p.upload(m) for m in main_traces] for p in provers], [[p.upload(m) for _, m in preprocessed] for p in provers]
 
 
+def sharded_trace_is_split(world, height, log_blowup=1, log_min_sharded=12):
+    """vgpu_sharded_trace_is_split: whether a chip of this trace height hands in row ranges (its LDE is sharded) in the row-range form of a sharded proof."""
+    f = lib().vgpu_sharded_trace_is_split
+    f.restype = ctypes.c_uint32
+    return bool(f(ctypes.c_uint32(world), ctypes.c_uint32(log_blowup), ctypes.c_uint32(log_min_sharded), ctypes.c_uint64(int(height))))
+
+
+def row_ranges(main_traces, rank, world, log_blowup=1, log_min_sharded=12):
+    """Rank `rank`'s inputs of a sharded proof in ROW-RANGE form: (matrices, full_heights) — the rows [rank n / world, (rank + 1) n / world) of every chip
+    whose LDE is sharded, the whole trace of every other chip."""
+    out, full = [], []
+    for m in main_traces:
+        n = m.shape[0]
+        full.append(n)
+        if sharded_trace_is_split(world, n, log_blowup, log_min_sharded):
+            out.append(np.ascontiguousarray(m[rank * (n // world):(rank + 1) * (n // world)]))
+        else:
+            out.append(m)
+    return out, full
+
+
+def prove_sharded_rows_local(provers, main_traces, preprocessed, log_min_sharded=12):
+    """ONE proof over len(provers) prover contexts of this process with the TRACES sharded too (vgpu_prove_sharded_rows_local): context r uploads only
+    its row range of every sharded chip (row_ranges).  Returns the Proof, word for word provers[0].prove(..) of the whole traces."""
+    W = len(provers)
+    keep, full = [], None
+    for r, p in enumerate(provers):
+        mats, full = row_ranges(main_traces, r, W, p.log_blowup, log_min_sharded)
+        keep.append([p.upload(m) for m in mats])
+    keep_p = [[p.upload(m) for _, m in preprocessed] for p in provers]
+    arr = (ctypes.c_void_p * (W * len(main_traces)))(*[t._h for row in keep for t in row])
+    fh = (ctypes.c_uint64 * len(main_traces))(*full)
+    chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
+    parr = (ctypes.c_void_p * max(1, W * len(preprocessed)))(*[t._h for row in keep_p for t in row])
+    pv = (ctypes.c_void_p * W)(*[p._h for p in provers])
+    h = ctypes.c_void_p()
+    _check(lib().vgpu_prove_sharded_rows_local(pv, ctypes.c_uint32(W), arr, ctypes.c_uint32(len(main_traces)), fh, chips, parr, ctypes.c_uint32(len(preprocessed)),
+                                               ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
+    return Proof(h)
+
+
 class VgpuFabric(ctypes.Structure):
     """vgpu_fabric_t (include/vgpu.h): the host's own transport for a sharded proof, two collective callbacks over host buffers."""
     ALL_GATHER = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, c_u32p, ctypes.c_uint64, c_u32p)
@@ -732,13 +773,19 @@ class Fabric:
         code = lib().vgpu_fabric_selftest(ctypes.byref(self.c), ctypes.c_uint32(n_words), ctypes.c_uint32(fail_rank))
         return None if code == 0 else lib().vgpu_last_error().decode()
 
-    def prove_sharded(self, prover, main, preprocessed, log_min_sharded=12):
+    def prove_sharded(self, prover, main, preprocessed, log_min_sharded=12, full_heights=None):
         """This rank's share of ONE proof sharded over the fabric's ranks (vgpu_prove_sharded_fabric): every rank passes the same traces,
-        uploaded through its own prover, and receives the proof vgpu_prove gives on one GPU."""
+        uploaded through its own prover, and receives the proof vgpu_prove gives on one GPU.  full_heights given: the ROW-RANGE form
+        (vgpu_prove_sharded_rows_fabric) — `main` holds this rank's rows of every sharded chip (row_ranges)."""
         arr = (ctypes.c_void_p * len(main))(*[t._h for t in main])
         chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
         parr = (ctypes.c_void_p * max(1, len(preprocessed)))(*[t._h for _, t in preprocessed])
         h = ctypes.c_void_p()
+        if full_heights is not None:
+            fh = (ctypes.c_uint64 * len(main))(*[int(x) for x in full_heights])
+            _check(lib().vgpu_prove_sharded_rows_fabric(prover._h, ctypes.byref(self.c), arr, ctypes.c_uint32(len(main)), fh, chips, parr, ctypes.c_uint32(len(preprocessed)),
+                                                        ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
+            return Proof(h)
         _check(lib().vgpu_prove_sharded_fabric(prover._h, ctypes.byref(self.c), arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)),
                                                ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
         return Proof(h)

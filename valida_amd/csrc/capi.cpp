@@ -880,8 +880,9 @@ int32_t vgpu_commit_batches_sharded_local(vgpu_prover_t* const* provers, uint32_
 
 // ---- one proof over several ranks
 static ShardedInputs sharded_inputs(const vgpu_prover_t* p, const vgpu_trace_t* const* main, uint32_t n_main, const uint32_t* prep_chips, const vgpu_trace_t* const* prep,
-                                    uint32_t n_prep) {
+                                    uint32_t n_prep, const uint64_t* full_heights = nullptr) {
     ShardedInputs in;
+    if (full_heights) in.full_height.assign(full_heights, full_heights + n_main);
     for (uint32_t i = 0; i < n_main; i++) { check_trace(p, main[i]); in.main.push_back(main[i]->t.get()); }
     for (uint32_t i = 0; i < n_prep; i++) { check_trace(p, prep[i]); in.prep.push_back({(int)prep_chips[i], prep[i]->t.get()}); }
     return in;
@@ -924,6 +925,61 @@ int32_t vgpu_prove_sharded_fabric(vgpu_prover_t* p, const vgpu_fabric_t* fabric,
         }
         auto proof = std::make_unique<vgpu_proof>();
         proof->words = ShardedProof::run(fab, provers, in, log_min_sharded);
+        *out = proof.release();
+    })
+}
+// ---- the same with ROW-RANGE inputs: every sharded chip hands in only its rows [rank n / W, (rank + 1) n / W) (sharded_prover.hpp)
+uint32_t vgpu_sharded_trace_is_split(uint32_t world, uint32_t log_blowup, uint32_t log_min_sharded, uint64_t height) {
+    return sharded_trace_is_split(world, log_blowup, log_min_sharded, height) ? 1u : 0u;
+}
+int32_t vgpu_prove_sharded_rows(vgpu_prover_t* p, vgpu_comm_t* comm, const vgpu_trace_t* const* main, uint32_t n_main, const uint64_t* full_heights, const uint32_t* prep_chips,
+                                const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out) {
+    VG_TRY({
+        if (!p || !comm || !main || !full_heights || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
+        if (comm->owner != p->p) throw std::invalid_argument("communicator of another prover context");
+        RcclFabric fabric(comm->comm.get());
+        std::vector<Prover*> provers{p->p.get()};
+        std::vector<ShardedInputs> in{sharded_inputs(p, main, n_main, prep_chips, prep, n_prep, full_heights)};
+        auto proof = std::make_unique<vgpu_proof>();
+        proof->words = ShardedProof::run(fabric, provers, in, log_min_sharded);
+        *out = proof.release();
+    })
+}
+int32_t vgpu_prove_sharded_rows_fabric(vgpu_prover_t* p, const vgpu_fabric_t* fabric, const vgpu_trace_t* const* main, uint32_t n_main, const uint64_t* full_heights,
+                                       const uint32_t* prep_chips, const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out) {
+    VG_TRY({
+        check_fabric_struct(fabric);
+        CallbackFabric fab((int)fabric->rank, (int)fabric->world, fabric->all_gather, fabric->all_to_all, fabric->user, fabric->timeout_ms);
+        std::vector<Prover*> provers;
+        std::vector<ShardedInputs> in;
+        try {
+            if (!p || !main || !full_heights || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
+            provers.push_back(p->p.get());
+            in.push_back(sharded_inputs(p, main, n_main, prep_chips, prep, n_prep, full_heights));
+        } catch (...) {
+            fab.fail();
+            throw;
+        }
+        auto proof = std::make_unique<vgpu_proof>();
+        proof->words = ShardedProof::run(fab, provers, in, log_min_sharded);
+        *out = proof.release();
+    })
+}
+int32_t vgpu_prove_sharded_rows_local(vgpu_prover_t* const* provers, uint32_t world, const vgpu_trace_t* const* main, uint32_t n_main, const uint64_t* full_heights,
+                                      const uint32_t* prep_chips, const vgpu_trace_t* const* prep, uint32_t n_prep, uint32_t log_min_sharded, vgpu_proof_t** out) {
+    VG_TRY({
+        if (!provers || !world || !main || !full_heights || !out || (n_prep && (!prep || !prep_chips))) throw std::invalid_argument("null argument");
+        LocalFabric fabric((int)world);
+        std::vector<Prover*> ps;
+        std::vector<ShardedInputs> in;
+        for (uint32_t r = 0; r < world; r++) {
+            if (!provers[r]) throw std::invalid_argument("null prover");
+            for (uint32_t q = 0; q < r; q++) if (provers[q]->p == provers[r]->p) throw std::invalid_argument("the ranks need distinct prover contexts");
+            ps.push_back(provers[r]->p.get());
+            in.push_back(sharded_inputs(provers[r], main + (size_t)r * n_main, n_main, prep_chips, n_prep ? prep + (size_t)r * n_prep : nullptr, n_prep, full_heights));
+        }
+        auto proof = std::make_unique<vgpu_proof>();
+        proof->words = ShardedProof::run(fabric, ps, in, log_min_sharded);
         *out = proof.release();
     })
 }

@@ -69,7 +69,9 @@ struct CommitIn {
     const DMat* nat = nullptr;    // whole matrix, natural row order (left untouched)
     DMat* bitrev_full = nullptr;  // whole matrix, rows at bit-reversed positions (consumed)
     DMat* own_bitrev = nullptr;   // this rank's columns only (ascending), rows at bit-reversed positions (consumed)
-    uint64_t height = 0, width = 0;
+    const DMat* rows_nat = nullptr;  // row-range inputs: this rank's ROWS [rank n / W, (rank + 1) n / W) of every column, natural order
+    DMat* own_nat = nullptr;      // ... dealt into this rank's columns (whole, natural order) by the round's first exchange
+    uint64_t height = 0, width = 0;  // of the WHOLE matrix
 };
 
 struct FriLayer {
@@ -95,7 +97,8 @@ struct Rank {
     Ext5 rnd[3], alpha;
     // commit scratch
     std::vector<DBuf> sendbuf, recvbuf;
-    std::vector<DMat> own_lde;
+    std::vector<DMat> own_lde, own_nat;
+    std::vector<char> split;  // per chip: the main / permutation trace of this chip is held as a row range
     // quotient
     DBuf halo_send, halo_recv;
     std::vector<DMat> quot_full, quot_shard, quot_own;
@@ -209,6 +212,11 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 if (cin[i].own_bitrev->width != own[i].size() || cin[i].own_bitrev->height != cin[i].height) throw std::logic_error("sharded commit: own-column input of the wrong shape");
                 CommitInput ci{cin[i].own_bitrev, true, true};
                 R.own_lde[i] = coset_lde(c, c->stream, ci, lb, shift);
+            } else if (cin[i].own_nat) {
+                if (cin[i].own_nat->width != own[i].size() || cin[i].own_nat->height != cin[i].height) throw std::logic_error("sharded commit: dealt columns of the wrong shape");
+                CommitInput ci{cin[i].own_nat, false, false};
+                R.own_lde[i] = coset_lde(c, c->stream, ci, lb, shift);
+                cin[i].own_nat->reset();
             } else throw std::logic_error("sharded commit: a sharded matrix needs the whole input or this rank's columns");
         }
         if (!sharded) return;
@@ -316,7 +324,78 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         for (auto* t : trees) contrib.push_back(t->tree.root);
         f.all_gather(contrib, 8, roots);
     };
+    // Row-range inputs (ShardedInputs::full_height): rows -> columns.  Rank r holds rows [r n / W, (r + 1) n / W) of every column of a split
+    // matrix; the column's owner (global column g -> rank g mod W, as everywhere) receives the W segments and lays them end to end: its
+    // columns whole, in natural order, ready for the LDE.  One all-to-all per commitment round, (W - 1) / W of the round's trace words per rank.
+    auto deal_rows_to_columns = [&](std::vector<std::vector<CommitIn>>& cin) {
+        bool any = false;
+        for (auto& ci : cin[0]) any |= ci.rows_nat != nullptr;
+        if (!any) return;
+        std::vector<Fabric::A2A> plan((size_t)NH);
+        std::vector<std::vector<DBuf>> sb((size_t)NH), rb((size_t)NH);
+        auto col_base_of = [&](const std::vector<CommitIn>& v, size_t i) { uint64_t b = 0; for (size_t q = 0; q < i; q++) b += v[q].width; return b; };
+        for (int k = 0; k < NH; k++) {
+            Rank& R = rk[k];
+            DeviceCtx& c = *R.c;
+            c.activate();
+            plan[k] = Fabric::A2A(&c, W);
+            for (int t = 0; t < W; t++) {
+                size_t sw = 0, rw = 0;
+                for (size_t i = 0; i < cin[k].size(); i++) {
+                    if (!cin[k][i].rows_nat) continue;
+                    const uint64_t rows = cin[k][i].height / (uint64_t)W, base = col_base_of(cin[k], i);
+                    if (cin[k][i].rows_nat->height != rows || cin[k][i].rows_nat->width != cin[k][i].width) throw std::invalid_argument("sharded commit: a row range of the wrong shape");
+                    for (uint64_t col = 0; col < cin[k][i].width; col++) {
+                        const int o = owner_of(base + col, W);
+                        if (o == t) sw += rows;
+                        if (o == R.rank) rw += rows;
+                    }
+                }
+                sb[k].emplace_back(&c, sw + 4);
+                rb[k].emplace_back(&c, rw + 4);
+                size_t pos = 0;
+                for (size_t i = 0; i < cin[k].size(); i++) {
+                    if (!cin[k][i].rows_nat) continue;
+                    const DMat& m = *cin[k][i].rows_nat;
+                    const uint64_t base = col_base_of(cin[k], i);
+                    for (uint64_t col = 0; col < m.width; col++)
+                        if (owner_of(base + col, W) == t) {
+                            VG_HIP_CHECK(hipMemcpyAsync(sb[k][t].data + pos, m.data + col * m.height, m.height * 4, hipMemcpyDeviceToDevice, c.stream));
+                            pos += m.height;
+                        }
+                }
+                plan[k].send[t] = sb[k][t].data; plan[k].send_words[t] = sw;
+                plan[k].recv[t] = rb[k][t].data; plan[k].recv_words[t] = rw;
+            }
+        }
+        f.all_to_all(plan);
+        for (int k = 0; k < NH; k++) {
+            Rank& R = rk[k];
+            DeviceCtx& c = *R.c;
+            c.activate();
+            R.own_nat.clear();
+            R.own_nat.resize(cin[k].size());
+            std::vector<size_t> pos((size_t)W, 0);
+            for (size_t i = 0; i < cin[k].size(); i++) {
+                if (!cin[k][i].rows_nat) continue;
+                const uint64_t n = cin[k][i].height, rows = n / (uint64_t)W, base = col_base_of(cin[k], i);
+                std::vector<uint64_t> own;
+                for (uint64_t col = 0; col < cin[k][i].width; col++) if (owner_of(base + col, W) == R.rank) own.push_back(col);
+                cin[k][i].rows_nat = nullptr;
+                if (own.empty()) continue;
+                R.own_nat[i] = DMat(&c, n, own.size());
+                for (size_t q = 0; q < own.size(); q++)
+                    for (int src = 0; src < W; src++) {
+                        VG_HIP_CHECK(hipMemcpyAsync(R.own_nat[i].data + q * n + (uint64_t)src * rows, rb[k][src].data + pos[src], rows * 4, hipMemcpyDeviceToDevice, c.stream));
+                        pos[src] += rows;
+                    }
+                cin[k][i].own_nat = &R.own_nat[i];
+            }
+            c.sync();  // the receive buffers go
+        }
+    };
     auto commit_round = [&](std::vector<std::vector<CommitIn>>& cin, const std::vector<Fp>* shifts, ShRound Rank::*which) {
+        deal_rows_to_columns(cin);
         std::vector<Fabric::A2A> plan((size_t)NH);
         for (int k = 0; k < NH; k++) commit_phase_a(rk[k], cin[k], shifts, rk[k].*which, plan[k]);
         const bool sharded = (rk[0].*which).t.sharded;
@@ -340,14 +419,26 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         c.activate();
         const auto& main = in[k].main;
         R.log_deg.resize(NC); R.main_own.resize(NC); R.main_nat.resize(NC);
+        R.split.assign(NC, 0);
+        const bool row_ranges = !in[k].full_height.empty();
+        if (row_ranges && in[k].full_height.size() != NC) throw std::invalid_argument("sharded prove: one full height per chip");
         for (size_t i = 0; i < NC; i++) {
             if (!main[i]) throw std::invalid_argument("sharded prove: null trace");
             if (main[i]->width != md.airs[i].width) throw std::invalid_argument("sharded prove: trace width mismatch for chip " + md.airs[i].name);
-            const uint64_t h = main[i]->height;
+            const uint64_t hl = main[i]->height;           // the rows this rank holds
+            const uint64_t h = row_ranges ? in[k].full_height[i] : hl;
             if (h == 0 || (h & (h - 1))) throw std::invalid_argument("sharded prove: trace heights must be powers of two");
+            if (row_ranges) {
+                // the rule of sharded_trace_is_split: exactly the chips whose LDE is sharded come as row ranges
+                const bool split = W > 1 && (h << lb) >= min_big;
+                if (hl != (split ? h / (uint64_t)W : h))
+                    throw std::invalid_argument("sharded prove: chip " + md.airs[i].name + " must hand in " + (split ? "its row range (height / ranks rows)" : "its whole trace") +
+                                                ": " + std::to_string(hl) + " rows given, full height " + std::to_string(h));
+                R.split[i] = split ? 1 : 0;
+            }
             R.log_deg[i] = vg::log2_strict_u64(h);
             if (!main[i]->nat.empty()) { R.main_nat[i] = &main[i]->nat; continue; }
-            R.main_own[i] = DMat(&c, h, main[i]->width);
+            R.main_own[i] = DMat(&c, hl, main[i]->width);
             R.main_nat[i] = &R.main_own[i];
             vk::launch_ingest(c.stream, main[i]->raw.data, R.main_own[i].view(), false);
         }
@@ -358,7 +449,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             const DeviceTrace* t = prep[q].second;
             const int chip = prep[q].first;
             if (!t || chip < 0 || (size_t)chip >= NC || R.prep_slot[chip] >= 0) throw std::invalid_argument("sharded prove: bad or repeated preprocessed chip index");
-            if (t->width != md.airs[chip].prep_width || t->height != main[chip]->height) throw std::invalid_argument("sharded prove: preprocessed trace shape mismatch");
+            if (t->width != md.airs[chip].prep_width || t->height != (1ull << R.log_deg[chip])) throw std::invalid_argument("sharded prove: preprocessed trace shape mismatch (preprocessed traces are handed in whole)");
             R.prep_nat[q] = DMat(&c, t->height, t->width);
             if (!t->nat.empty()) VG_HIP_CHECK(hipMemcpyAsync(R.prep_nat[q].data, t->nat.data, t->height * t->width * 4, hipMemcpyDeviceToDevice, c.stream));
             else vk::launch_ingest(c.stream, t->raw.data, R.prep_nat[q].view(), false);
@@ -366,7 +457,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         }
         c.check_launch("ingest");
         if (k > 0) {
-            if (R.log_deg != rk[0].log_deg || R.prep_slot != rk[0].prep_slot) throw std::invalid_argument("sharded prove: the ranks' traces must have the same shapes");
+            if (R.log_deg != rk[0].log_deg || R.prep_slot != rk[0].prep_slot || R.split != rk[0].split) throw std::invalid_argument("sharded prove: the ranks' traces must have the same shapes");
         }
     }
     const std::vector<unsigned>& log_deg = rk[0].log_deg;
@@ -375,7 +466,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
     if (NH < W) {
         // ranks in other processes: every exchange below is sized from the shapes, so they must be THE SAME everywhere before the first one
         std::vector<uint32_t> shape;
-        for (size_t i = 0; i < NC; i++) { shape.push_back(log_deg[i]); shape.push_back((uint32_t)(prep_slot[i] + 1)); }
+        for (size_t i = 0; i < NC; i++) { shape.push_back(log_deg[i]); shape.push_back((uint32_t)(prep_slot[i] + 1)); shape.push_back((uint32_t)rk[0].split[i]); }
         shape.push_back(log_min_sharded); shape.push_back(fri.log_blowup); shape.push_back(fri.num_queries); shape.push_back(fri.pow_bits); shape.push_back((uint32_t)fri.hash_kind);
         shape.push_back(fri.observe_final_poly ? 1u : 0u);
         std::vector<const uint32_t*> contrib((size_t)NH, shape.data());
@@ -400,7 +491,13 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
     {
         std::vector<std::vector<CommitIn>> cin((size_t)NH);
         for (int k = 0; k < NH; k++)
-            for (auto* m : rk[k].main_nat) { CommitIn ci; ci.nat = m; ci.height = m->height; ci.width = m->width; cin[k].push_back(ci); }
+            for (size_t i = 0; i < NC; i++) {
+                const DMat* m = rk[k].main_nat[i];
+                CommitIn ci;
+                if (rk[k].split[i]) ci.rows_nat = m; else ci.nat = m;
+                ci.height = 1ull << log_deg[i]; ci.width = m->width;
+                cin[k].push_back(ci);
+            }
         commit_round(cin, nullptr, &Rank::main_rs);
         for (auto& R : rk) R.ch->observe_digest(R.main_rs.t.root);
     }
@@ -436,10 +533,13 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         R.perm_nat.resize(NC);
         for (size_t i = 0; i < NC; i++) {
             const uint32_t M = (uint32_t)md.airs[i].interactions.size();
-            const uint64_t n = R.main_nat[i]->height;
+            const uint64_t n = R.main_nat[i]->height;  // the rows this rank holds: a row range of a split chip
             R.perm_nat[i] = DMat(&c, n, 5 * (M + 1));
             vk::DMatView pv{nullptr, 0, 0, 0};
-            if (prep_slot[i] >= 0) pv = R.prep_nat[prep_slot[i]].view();
+            if (prep_slot[i] >= 0) {
+                const DMat& pm = R.prep_nat[prep_slot[i]];  // whole on every rank: a split chip reads its row range of it
+                pv = R.split[i] ? vk::DMatView{pm.data + (uint64_t)R.rank * n, n, pm.width, pm.height} : pm.view();
+            }
             scratch.emplace_back(&c, (size_t)vk::perm_scratch_words(n));
             vk::launch_perm_trace(c.stream, R.main_nat[i]->view(), pv, R.p->iw_dev_[i].data, pool_dev.data + off[i], M, R.perm_nat[i].view(), scratch.back().data);
             // cumulative sum = last row of the running-sum column (lib.rs:247-250)
@@ -455,11 +555,60 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         c.download_small(cs.data(), gout.data, cs.size() * 4);  // synchronises: pool_dev / scratch may go
         R.cumulative_sums.resize(NC);
         for (size_t i = 0; i < NC; i++) R.cumulative_sums[i] = sp_ext_from_canonical(cs.data() + 5 * i);
+        R.words = cs;  // a split chip's entry is the total of ITS rows only: completed below
+    }
+    {
+        // Row-range inputs: the running sum of a split chip (chip.rs:176-205) was scanned over each rank's own rows.  ONE exchange of the
+        // ranks' totals (5 words per chip and rank) gives every rank the sum of the rows before its range — added to its column — and the
+        // chip's cumulative sum, the total over all ranks.
+        bool any_split = false;
+        for (char sp : rk[0].split) any_split |= sp != 0;
+        if (any_split) {
+            std::vector<const uint32_t*> contrib;
+            for (auto& R : rk) contrib.push_back(R.words.data());
+            std::vector<uint32_t> all;
+            f.all_gather(contrib, 5 * NC, all);
+            for (auto& R : rk) {
+                DeviceCtx& c = *R.c;
+                c.activate();
+                std::vector<uint32_t> offs;
+                std::vector<size_t> at(NC, 0);
+                for (size_t i = 0; i < NC; i++) {
+                    if (!R.split[i]) continue;
+                    Ext5 before = Ext5::zero(), total = Ext5::zero();
+                    for (int r = 0; r < W; r++) {
+                        const Ext5 t = sp_ext_from_canonical(&all[(size_t)r * 5 * NC + 5 * i]);
+                        if (r < R.rank) before += t;
+                        total += t;
+                    }
+                    R.cumulative_sums[i] = total;
+                    at[i] = offs.size();
+                    put_ext(offs, before);
+                }
+                offs.push_back(0);
+                DBuf offs_dev(&c, offs);
+                for (size_t i = 0; i < NC; i++) {
+                    if (!R.split[i] || R.rank == 0) continue;
+                    const uint32_t M = (uint32_t)md.airs[i].interactions.size();
+                    DMat& pm = R.perm_nat[i];
+                    vk::launch_add_ext_const(c.stream, pm.data + (uint64_t)(5 * M) * pm.height, pm.height, pm.height, offs_dev.data + at[i]);
+                }
+                c.check_launch("perm trace offsets");
+                c.sync();  // offs_dev goes
+            }
+        }
+        for (auto& R : rk) R.words.clear();
     }
     {
         std::vector<std::vector<CommitIn>> cin((size_t)NH);
         for (int k = 0; k < NH; k++)
-            for (auto& m : rk[k].perm_nat) { CommitIn ci; ci.nat = &m; ci.height = m.height; ci.width = m.width; cin[k].push_back(ci); }
+            for (size_t i = 0; i < NC; i++) {
+                DMat& m = rk[k].perm_nat[i];
+                CommitIn ci;
+                if (rk[k].split[i]) ci.rows_nat = &m; else ci.nat = &m;
+                ci.height = 1ull << log_deg[i]; ci.width = m.width;
+                cin[k].push_back(ci);
+            }
         commit_round(cin, nullptr, &Rank::perm_rs);
         for (auto& R : rk) {
             R.ch->observe_digest(R.perm_rs.t.root);

@@ -91,6 +91,7 @@ void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, bool spar
 void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, bool sparse, const KeccakTopArgs& a);
 // perm.hip
 uint64_t perm_scratch_words(uint64_t n);
+void launch_add_ext_const(hipStream_t st, uint32_t* data, uint64_t stride, uint64_t n, const uint32_t* off5_dev);  // 5 columns += 5 Montgomery constants
 void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,
                        uint32_t* scratch);
 // quotient.hip

@@ -98,6 +98,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(uint32_t* __restric
     for (int i = 0; i < SCAN_ITEMS; i++) { run += v[i]; if (base + i < n) col[base + i] = run.v; }
 }
 
+// five base-field columns (one Ext5 column of a flattened trace) += a constant: the offset of a row range's running sum (sharded prover)
+__global__ void __launch_bounds__(256) k_add_ext_const(uint32_t* __restrict__ data, uint64_t stride, uint64_t n, const uint32_t* __restrict__ off5) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* col = data + (uint64_t)blockIdx.y * stride;
+    col[i] = (Fp::raw(col[i]) + Fp::raw(off5[blockIdx.y])).v;
+}
+void launch_add_ext_const(hipStream_t st, uint32_t* data, uint64_t stride, uint64_t n, const uint32_t* off5_dev) {
+    ProfScope ps("k_scan", st, 2.0 * 20.0 * n);
+    VK_LAUNCH(k_add_ext_const, dim3((unsigned)((n + 255) / 256), 5), dim3(256), 0, st, data, stride, n, off5_dev);
+}
+
 uint64_t perm_scratch_words(uint64_t n) { return 5 * ((n + SCAN_BLOCK - 1) / SCAN_BLOCK); }
 
 // main/prep: natural-order column-major.  perm: n x 5(M+1), natural order.  scratch: >= 5 * ceil(n / SCAN_BLOCK) words.
