@@ -473,6 +473,17 @@ def main():
                     torch.cuda.synchronize()
                     sharded_local[str(wn)] = {"ms_per_proof": (time.perf_counter() - t0) / 3 * 1e3, "same_words_as_the_single_gpu_proof": same}
                     del up
+                    if wn > 1:  # the same with the TRACES sharded too (row-range inputs: every context holds 1 / W of the big chips' rows)
+                        up = va.upload_row_ranges(ps, mt, prep)
+                        pr = va.prove_sharded_rows_local(ps, mt, prep, uploaded=up)
+                        same = bool(np.array_equal(pr.words, ref_words))
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(3):
+                            va.prove_sharded_rows_local(ps, mt, prep, uploaded=up)
+                        torch.cuda.synchronize()
+                        sharded_local[str(wn)]["row_range_inputs"] = {"ms_per_proof": (time.perf_counter() - t0) / 3 * 1e3, "same_words_as_the_single_gpu_proof": same}
+                        del up
             except va.VgpuError as e:  # reporting leg only: never lose the line over it
                 sharded_local["error"] = str(e)
             del extra
@@ -659,7 +670,7 @@ def main():
                                             "tracegen_s, and the row-major upload)"},
             "one_proof_over_w_ranks_on_this_gpu": None if not sharded_local else dict(sharded_local, note=(
                 "vgpu_prove_sharded_local: W prover contexts of this ONE device stand in for W ranks (row-range shards, exchanges as device-to-device "
-                "copies): what sharding costs, not a speed-up; the multi-GPU realisation (vgpu_prove_sharded over RCCL) is unmeasured here")),
+                "copies): what sharding costs, not a speed-up; row_range_inputs = vgpu_prove_sharded_rows_local, the traces themselves sharded; the multi-GPU realisation (vgpu_prove_sharded over RCCL) is unmeasured here")),
             "prover_ms_single_proof_in_flight": single if single is not None else ms_per_step,
             "proof_words": int(p.words.size),
             "proof_checked_by_vgpu_verify": verified,  # Machine::verify of the library (host) on the last timed proof

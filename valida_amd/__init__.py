@@ -669,15 +669,21 @@ def row_ranges(main_traces, rank, world, log_blowup=1, log_min_sharded=12):
     return out, full
 
 
-def prove_sharded_rows_local(provers, main_traces, preprocessed, log_min_sharded=12):
+def upload_row_ranges(provers, main_traces, preprocessed, log_min_sharded=12):
+    """The ROW-RANGE inputs of one sharded proof uploaded through the prover contexts standing in for the ranks: context r gets only its rows of
+    every sharded chip.  For prove_sharded_rows_local(.., uploaded=..)."""
+    keep, full = [], None
+    for r, p in enumerate(provers):
+        mats, full = row_ranges(main_traces, r, len(provers), p.log_blowup, log_min_sharded)
+        keep.append([p.upload(m) for m in mats])
+    return keep, [[p.upload(m) for _, m in preprocessed] for p in provers], full
+
+
+def prove_sharded_rows_local(provers, main_traces, preprocessed, log_min_sharded=12, uploaded=None):
     """ONE proof over len(provers) prover contexts of this process with the TRACES sharded too (vgpu_prove_sharded_rows_local): context r uploads only
     its row range of every sharded chip (row_ranges).  Returns the Proof, word for word provers[0].prove(..) of the whole traces."""
     W = len(provers)
-    keep, full = [], None
-    for r, p in enumerate(provers):
-        mats, full = row_ranges(main_traces, r, W, p.log_blowup, log_min_sharded)
-        keep.append([p.upload(m) for m in mats])
-    keep_p = [[p.upload(m) for _, m in preprocessed] for p in provers]
+    keep, keep_p, full = uploaded if uploaded is not None else upload_row_ranges(provers, main_traces, preprocessed, log_min_sharded)
     arr = (ctypes.c_void_p * (W * len(main_traces)))(*[t._h for row in keep for t in row])
     fh = (ctypes.c_uint64 * len(main_traces))(*full)
     chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])

@@ -63,6 +63,7 @@ struct Fabric {
     bool poisoned = false;    // a transport step failed: no collective may follow on this fabric
     uint32_t timeout_ms = 0;  // deadline of one transport step (0: none)
     virtual ~Fabric() {}
+    struct Seg;
     struct A2A;
     // contrib[k]: n words of hosted rank hosted[k] (host memory).  out: world * n words, rank-major — what every rank receives.
     void all_gather(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) {
@@ -115,16 +116,38 @@ struct Fabric {
     virtual void a2a_finish(std::vector<A2A>& plan) { (void)plan; }
 
   public:
-    // Device all-to-all.  plan[k] belongs to hosted rank hosted[k]: block send[s] (send_words[s] words) goes to rank s, recv[s]
-    // (recv_words[s] words) arrives from rank s.  Returns when the data has arrived (the contexts' streams are drained).
+    // Device all-to-all.  plan[k] belongs to hosted rank hosted[k]: the segments send[s] go to rank s, the segments recv[s] arrive from rank s,
+    // in order.  A segment is `n_runs` runs of `run` words, `pitch` words apart (a run per column of a column-major matrix: the row range a
+    // peer needs of every column this rank owns) — the exchanges move the data ONCE, from where a kernel left it to where the next kernel
+    // reads it; there is no pack / unpack copy around them (the RCCL fabric packs inside, the callback fabric stages through host memory
+    // anyway).  A sender's k-th segment to s and the receiver's k-th segment from it have the same shape.  Returns when the data has arrived
+    // (the contexts' streams are drained).
+    struct Seg {
+        uint32_t* p = nullptr;
+        size_t run = 0, n_runs = 0, pitch = 0;
+        size_t words() const { return run * n_runs; }
+    };
     struct A2A {
         DeviceCtx* c = nullptr;
-        std::vector<const uint32_t*> send;
-        std::vector<size_t> send_words;
-        std::vector<uint32_t*> recv;
-        std::vector<size_t> recv_words;
-        explicit A2A(DeviceCtx* ctx = nullptr, int world = 0) : c(ctx), send(world, nullptr), send_words(world, 0), recv(world, nullptr), recv_words(world, 0) {}
+        std::vector<std::vector<Seg>> send, recv;
+        explicit A2A(DeviceCtx* ctx = nullptr, int world = 0) : c(ctx), send(world), recv(world) {}
+        void add_send(int to, const uint32_t* p, size_t run, size_t n_runs = 1, size_t pitch = 0) { if (run && n_runs) send[(size_t)to].push_back({const_cast<uint32_t*>(p), run, n_runs, n_runs > 1 ? pitch : run}); }
+        void add_recv(int from, uint32_t* p, size_t run, size_t n_runs = 1, size_t pitch = 0) { if (run && n_runs) recv[(size_t)from].push_back({p, run, n_runs, n_runs > 1 ? pitch : run}); }
+        size_t send_words(int to) const { size_t n = 0; for (auto& g : send[(size_t)to]) n += g.words(); return n; }
+        size_t recv_words(int from) const { size_t n = 0; for (auto& g : recv[(size_t)from]) n += g.words(); return n; }
     };
+    // one segment <-> a contiguous block, or segment -> segment of the same shape (device to device)
+    static void copy_seg(void* dst, size_t dst_pitch_words, const void* src, size_t src_pitch_words, const Seg& g, hipMemcpyKind kind, hipStream_t st) {
+        if (g.n_runs == 1) VG_HIP_CHECK(hipMemcpyAsync(dst, src, g.run * 4, kind, st));
+        else VG_HIP_CHECK(hipMemcpy2DAsync(dst, dst_pitch_words * 4, src, src_pitch_words * 4, g.run * 4, g.n_runs, kind, st));
+    }
+    static void copy_matching(const std::vector<Seg>& from, const std::vector<Seg>& to, hipStream_t st) {
+        if (from.size() != to.size()) throw std::logic_error("fabric: send / receive segment lists disagree");
+        for (size_t k = 0; k < from.size(); k++) {
+            if (from[k].run != to[k].run || from[k].n_runs != to[k].n_runs) throw std::logic_error("fabric: send / receive segments of different shapes");
+            copy_seg(to[k].p, to[k].pitch, from[k].p, from[k].pitch, from[k], hipMemcpyDeviceToDevice, st);
+        }
+    }
 };
 
 struct LocalFabric : Fabric {
@@ -141,8 +164,8 @@ struct LocalFabric : Fabric {
         for (auto& p : plan) { p.c->activate(); p.c->sync(); }
         for (int r = 0; r < world; r++)
             for (int s = 0; s < world; s++) {
-                if (plan[r].send_words[s] != plan[s].recv_words[r]) throw std::logic_error("fabric: send / receive sizes disagree");
-                if (plan[r].send_words[s]) VG_HIP_CHECK(hipMemcpy(plan[s].recv[r], plan[r].send[s], plan[r].send_words[s] * 4, hipMemcpyDeviceToDevice));
+                VG_HIP_CHECK(hipSetDevice(plan[s].c->device));
+                copy_matching(plan[r].send[(size_t)s], plan[s].recv[(size_t)r], plan[s].c->stream);
             }
         for (auto& p : plan) { VG_HIP_CHECK(hipSetDevice(p.c->device)); VG_HIP_CHECK(hipDeviceSynchronize()); }  // device-to-device copies may return early
     }
@@ -187,15 +210,52 @@ struct RcclFabric : Fabric {
         comm->wait(c->stream, timeout_ms);
         memcpy(out.data(), host + cap, (size_t)world * n * 4);
     }
+    // packed staging of the all-to-all's segments (one contiguous block per peer: one ncclSend / ncclRecv per peer and direction)
+    std::vector<DBuf> pack_send, pack_recv;
     void a2a_stage(std::vector<A2A>& plan) override {
         A2A& p = plan.at(0);
         if ((int)p.send.size() != world || (int)p.recv.size() != world) throw std::logic_error("fabric: plan of the wrong world size");
-        if (p.send_words[comm->rank] != p.recv_words[comm->rank]) throw std::logic_error("fabric: send / receive sizes disagree");
+        DeviceCtx* c = p.c;
+        c->activate();
+        pack_send.clear(); pack_recv.clear();
+        pack_send.resize((size_t)world); pack_recv.resize((size_t)world);
+        for (int s = 0; s < world; s++) {
+            if (s == comm->rank) continue;
+            const size_t sw = p.send_words(s), rw = p.recv_words(s);
+            if (sw && !(p.send[(size_t)s].size() == 1 && p.send[(size_t)s][0].n_runs == 1)) {
+                pack_send[(size_t)s] = DBuf(c, sw + 4);
+                size_t pos = 0;
+                for (auto& g : p.send[(size_t)s]) { copy_seg(pack_send[(size_t)s].data + pos, g.run, g.p, g.pitch, g, hipMemcpyDeviceToDevice, c->stream); pos += g.words(); }
+            }
+            if (rw && !(p.recv[(size_t)s].size() == 1 && p.recv[(size_t)s][0].n_runs == 1)) pack_recv[(size_t)s] = DBuf(c, rw + 4);
+        }
+        c->check_launch("fabric: pack");
     }
     void a2a_transport(std::vector<A2A>& plan) override {
         A2A& p = plan.at(0);
-        comm->all_to_all_words(p.send, p.send_words, p.recv, p.recv_words);
+        std::vector<const uint32_t*> sp((size_t)world, nullptr);
+        std::vector<uint32_t*> rp((size_t)world, nullptr);
+        std::vector<size_t> sw((size_t)world, 0), rw((size_t)world, 0);
+        for (int s = 0; s < world; s++) {
+            if (s == comm->rank) continue;
+            sw[(size_t)s] = p.send_words(s); rw[(size_t)s] = p.recv_words(s);
+            if (sw[(size_t)s]) sp[(size_t)s] = pack_send[(size_t)s].data ? pack_send[(size_t)s].data : p.send[(size_t)s][0].p;
+            if (rw[(size_t)s]) rp[(size_t)s] = pack_recv[(size_t)s].data ? pack_recv[(size_t)s].data : p.recv[(size_t)s][0].p;
+        }
+        comm->all_to_all_words(sp, sw, rp, rw);
         comm->wait(p.c->stream, timeout_ms);
+    }
+    void a2a_finish(std::vector<A2A>& plan) override {
+        A2A& p = plan.at(0);
+        DeviceCtx* c = p.c;
+        copy_matching(p.send[(size_t)comm->rank], p.recv[(size_t)comm->rank], c->stream);  // the block this rank keeps
+        for (int s = 0; s < world; s++) {
+            if (s == comm->rank || !pack_recv[(size_t)s].data) continue;
+            size_t pos = 0;
+            for (auto& g : p.recv[(size_t)s]) { copy_seg(g.p, g.pitch, pack_recv[(size_t)s].data + pos, g.run, g, hipMemcpyDeviceToDevice, c->stream); pos += g.words(); }
+        }
+        c->sync();
+        pack_send.clear(); pack_recv.clear();
     }
 };
 
@@ -327,7 +387,7 @@ struct CallbackFabric : Fabric {
         c->activate();
         if ((int)p.send.size() != world || (int)p.recv.size() != world) throw std::logic_error("fabric: plan of the wrong world size");
         size_t ns = 0, nr = 0;
-        for (int s = 0; s < world; s++) if (s != rank) { ns += p.send_words[s]; nr += p.recv_words[s]; }
+        for (int s = 0; s < world; s++) if (s != rank) { ns += p.send_words(s); nr += p.recv_words(s); }
         Shared& S = *sh;
         grow(S.host_send, S.host_send_words, ns ? ns : 1);
         grow(S.host_recv, S.host_recv_words, nr ? nr : 1);
@@ -336,16 +396,15 @@ struct CallbackFabric : Fabric {
         size_t so = 0, ro = 0;
         for (int s = 0; s < world; s++) {
             if (s == rank) continue;
-            if (p.send_words[s]) {
-                VG_HIP_CHECK(hipMemcpyAsync(S.host_send + so, p.send[s], p.send_words[s] * 4, hipMemcpyDeviceToHost, c->stream));
-                S.hs[(size_t)s] = S.host_send + so; S.sw[(size_t)s] = p.send_words[s]; so += p.send_words[s];
+            const size_t sw = p.send_words(s), rw = p.recv_words(s);
+            if (sw) {
+                size_t pos = so;
+                for (auto& g : p.send[(size_t)s]) { copy_seg(S.host_send + pos, g.run, g.p, g.pitch, g, hipMemcpyDeviceToHost, c->stream); pos += g.words(); }
+                S.hs[(size_t)s] = S.host_send + so; S.sw[(size_t)s] = sw; so += sw;
             }
-            if (p.recv_words[s]) { S.hr[(size_t)s] = S.host_recv + ro; S.rw[(size_t)s] = p.recv_words[s]; ro += p.recv_words[s]; }
+            if (rw) { S.hr[(size_t)s] = S.host_recv + ro; S.rw[(size_t)s] = rw; ro += rw; }
         }
-        if (p.send_words[rank]) {
-            if (p.send_words[rank] != p.recv_words[rank]) throw std::logic_error("fabric: send / receive sizes disagree");
-            VG_HIP_CHECK(hipMemcpyAsync(p.recv[rank], p.send[rank], p.send_words[rank] * 4, hipMemcpyDeviceToDevice, c->stream));
-        }
+        copy_matching(p.send[(size_t)rank], p.recv[(size_t)rank], c->stream);  // the block this rank keeps for itself: on the device
         if (fabric_failpoint("fabric_stage", rank)) throw std::runtime_error("fabric: failpoint fabric_stage");
         c->sync();  // the blocks to send are on the host; a receive block fresh from the pool is no longer read by queued kernels
     }
@@ -354,8 +413,11 @@ struct CallbackFabric : Fabric {
         A2A& p = plan.at(0);
         DeviceCtx* c = p.c;
         if (fabric_failpoint("fabric_finish", rank)) throw std::runtime_error("fabric: failpoint fabric_finish");
-        for (int s = 0; s < world; s++)
-            if (s != rank && p.recv_words[s]) VG_HIP_CHECK(hipMemcpyAsync(p.recv[s], sh->hr[(size_t)s], p.recv_words[s] * 4, hipMemcpyHostToDevice, c->stream));
+        for (int s = 0; s < world; s++) {
+            if (s == rank) continue;
+            size_t pos = 0;
+            for (auto& g : p.recv[(size_t)s]) { copy_seg(g.p, g.pitch, sh->hr[(size_t)s] + pos, g.run, g, hipMemcpyHostToDevice, c->stream); pos += g.words(); }
+        }
         c->sync();
     }
 };

@@ -220,29 +220,22 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             } else throw std::logic_error("sharded commit: a sharded matrix needs the whole input or this rank's columns");
         }
         if (!sharded) return;
-        // pack the row range of every peer: (matrix, owned column) segments in ascending order, L / W words each
+        // The row range of every peer goes out straight from the extended columns and arrives straight in the peer's shard: per big matrix
+        // one segment of `own columns` runs of L / W words (a run per owned column; in the receiver's shard that owner's columns are W columns
+        // apart).  No pack / unpack copies: the exchange moves every LDE word exactly once.
         plan = Fabric::A2A(c, W);
         R.sendbuf.clear(); R.recvbuf.clear();
-        for (int t = 0; t < W; t++) {
-            size_t sw = 0, rw = 0;
-            for (auto& m : rs.mats)
-                if (m.big) for (uint64_t col = 0; col < m.width; col++) {
-                    const int o = owner_of(m.col_base + col, W);
-                    if (o == R.rank) sw += m.L / W;
-                    if (o == t) rw += m.L / W;
-                }
-            R.sendbuf.emplace_back(c, sw + 4);
-            R.recvbuf.emplace_back(c, rw + 4);
-            size_t pos = 0;
-            for (size_t i = 0; i < cin.size(); i++) {
-                ShMat& m = rs.mats[i];
-                if (!m.big) continue;
-                const uint64_t rows = m.L / W;
-                for (size_t k = 0; k < own[i].size(); k++, pos += rows)
-                    VG_HIP_CHECK(hipMemcpyAsync(R.sendbuf[t].data + pos, R.own_lde[i].data + k * m.L + (uint64_t)t * rows, rows * 4, hipMemcpyDeviceToDevice, c->stream));
+        for (size_t i = 0; i < cin.size(); i++) {
+            ShMat& m = rs.mats[i];
+            if (!m.big) continue;
+            const uint64_t rows = m.L / W;
+            m.shard = DMat(c, rows, m.width);
+            for (int t = 0; t < W; t++) {
+                if (!own[i].empty()) plan.add_send(t, R.own_lde[i].data + (uint64_t)t * rows, rows, own[i].size(), m.L);
+                // columns owned by rank t: the first is (t - col_base) mod W, then every W-th
+                const uint64_t first = (uint64_t)(((int64_t)t - (int64_t)(m.col_base % (uint64_t)W) + W) % W);
+                if (first < m.width) plan.add_recv(t, m.shard.data + first * rows, rows, (m.width - first + W - 1) / W, (uint64_t)W * rows);
             }
-            plan.send[t] = R.sendbuf[t].data; plan.send_words[t] = sw;
-            plan.recv[t] = R.recvbuf[t].data; plan.recv_words[t] = rw;
         }
         c->check_launch("sharded commit: lde");
     };
@@ -257,20 +250,9 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             R.own_lde.clear();
             return;
         }
-        std::vector<size_t> pos((size_t)W, 0);
-        for (auto& m : rs.mats) {
-            if (!m.big) continue;
-            const uint64_t rows = m.L / W;
-            m.shard = DMat(c, rows, m.width);
-            for (uint64_t col = 0; col < m.width; col++) {
-                const int src = owner_of(m.col_base + col, W);
-                VG_HIP_CHECK(hipMemcpyAsync(m.shard.data + col * rows, R.recvbuf[src].data + pos[src], rows * 4, hipMemcpyDeviceToDevice, c->stream));
-                pos[src] += rows;
-            }
-        }
-        // released while the copies above are queued: safe, the pool hands a block only to work enqueued LATER on this stream; the peers
-        // have finished reading the send buffers (the exchange returns when the data has arrived)
-        R.own_lde.clear(); R.sendbuf.clear(); R.recvbuf.clear();
+        // the shards were filled by the exchange; the extended columns may go (the peers have finished reading them: the exchange returns
+        // when the data has arrived)
+        R.own_lde.clear();
         for (auto& m : rs.mats) {
             if (m.big) views.push_back(m.shard.view());
             else if (m.L >= (uint64_t)W) { const uint64_t rows = m.L / W; views.push_back(vk::DMatView{m.lde.data + (uint64_t)R.rank * rows, rows, m.width, m.L}); }
@@ -332,67 +314,38 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         for (auto& ci : cin[0]) any |= ci.rows_nat != nullptr;
         if (!any) return;
         std::vector<Fabric::A2A> plan((size_t)NH);
-        std::vector<std::vector<DBuf>> sb((size_t)NH), rb((size_t)NH);
         auto col_base_of = [&](const std::vector<CommitIn>& v, size_t i) { uint64_t b = 0; for (size_t q = 0; q < i; q++) b += v[q].width; return b; };
         for (int k = 0; k < NH; k++) {
             Rank& R = rk[k];
             DeviceCtx& c = *R.c;
             c.activate();
             plan[k] = Fabric::A2A(&c, W);
-            for (int t = 0; t < W; t++) {
-                size_t sw = 0, rw = 0;
-                for (size_t i = 0; i < cin[k].size(); i++) {
-                    if (!cin[k][i].rows_nat) continue;
-                    const uint64_t rows = cin[k][i].height / (uint64_t)W, base = col_base_of(cin[k], i);
-                    if (cin[k][i].rows_nat->height != rows || cin[k][i].rows_nat->width != cin[k][i].width) throw std::invalid_argument("sharded commit: a row range of the wrong shape");
-                    for (uint64_t col = 0; col < cin[k][i].width; col++) {
-                        const int o = owner_of(base + col, W);
-                        if (o == t) sw += rows;
-                        if (o == R.rank) rw += rows;
-                    }
+            R.own_nat.clear();
+            R.own_nat.resize(cin[k].size());
+            for (size_t i = 0; i < cin[k].size(); i++) {
+                if (!cin[k][i].rows_nat) continue;
+                const DMat& m = *cin[k][i].rows_nat;
+                const uint64_t n = cin[k][i].height, rows = n / (uint64_t)W, base = col_base_of(cin[k], i), width = cin[k][i].width;
+                if (m.height != rows || m.width != width) throw std::invalid_argument("sharded commit: a row range of the wrong shape");
+                auto first_of = [&](int t) { return (uint64_t)(((int64_t)t - (int64_t)(base % (uint64_t)W) + W) % W); };
+                auto count_of = [&](int t) { const uint64_t f0 = first_of(t); return f0 < width ? (width - f0 + W - 1) / W : 0; };
+                // to rank t: my rows of the columns it owns (every W-th column of my row range) ...
+                for (int t = 0; t < W; t++) if (count_of(t)) plan[k].add_send(t, m.data + first_of(t) * rows, rows, count_of(t), (uint64_t)W * rows);
+                // ... and from rank s its rows of MY columns, laid end to end: column q of mine is whole after the W segments
+                const uint64_t mine = count_of(R.rank);
+                if (mine) {
+                    R.own_nat[i] = DMat(&c, n, mine);
+                    for (int src = 0; src < W; src++) plan[k].add_recv(src, R.own_nat[i].data + (uint64_t)src * rows, rows, mine, n);
                 }
-                sb[k].emplace_back(&c, sw + 4);
-                rb[k].emplace_back(&c, rw + 4);
-                size_t pos = 0;
-                for (size_t i = 0; i < cin[k].size(); i++) {
-                    if (!cin[k][i].rows_nat) continue;
-                    const DMat& m = *cin[k][i].rows_nat;
-                    const uint64_t base = col_base_of(cin[k], i);
-                    for (uint64_t col = 0; col < m.width; col++)
-                        if (owner_of(base + col, W) == t) {
-                            VG_HIP_CHECK(hipMemcpyAsync(sb[k][t].data + pos, m.data + col * m.height, m.height * 4, hipMemcpyDeviceToDevice, c.stream));
-                            pos += m.height;
-                        }
-                }
-                plan[k].send[t] = sb[k][t].data; plan[k].send_words[t] = sw;
-                plan[k].recv[t] = rb[k][t].data; plan[k].recv_words[t] = rw;
             }
         }
         f.all_to_all(plan);
-        for (int k = 0; k < NH; k++) {
-            Rank& R = rk[k];
-            DeviceCtx& c = *R.c;
-            c.activate();
-            R.own_nat.clear();
-            R.own_nat.resize(cin[k].size());
-            std::vector<size_t> pos((size_t)W, 0);
+        for (int k = 0; k < NH; k++)
             for (size_t i = 0; i < cin[k].size(); i++) {
                 if (!cin[k][i].rows_nat) continue;
-                const uint64_t n = cin[k][i].height, rows = n / (uint64_t)W, base = col_base_of(cin[k], i);
-                std::vector<uint64_t> own;
-                for (uint64_t col = 0; col < cin[k][i].width; col++) if (owner_of(base + col, W) == R.rank) own.push_back(col);
                 cin[k][i].rows_nat = nullptr;
-                if (own.empty()) continue;
-                R.own_nat[i] = DMat(&c, n, own.size());
-                for (size_t q = 0; q < own.size(); q++)
-                    for (int src = 0; src < W; src++) {
-                        VG_HIP_CHECK(hipMemcpyAsync(R.own_nat[i].data + q * n + (uint64_t)src * rows, rb[k][src].data + pos[src], rows * 4, hipMemcpyDeviceToDevice, c.stream));
-                        pos[src] += rows;
-                    }
-                cin[k][i].own_nat = &R.own_nat[i];
+                if (!rk[k].own_nat[i].empty()) cin[k][i].own_nat = &rk[k].own_nat[i];
             }
-            c.sync();  // the receive buffers go
-        }
     };
     auto commit_round = [&](std::vector<std::vector<CommitIn>>& cin, const std::vector<Fp>* shifts, ShRound Rank::*which) {
         deal_rows_to_columns(cin);
@@ -612,7 +565,8 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         commit_round(cin, nullptr, &Rank::perm_rs);
         for (auto& R : rk) {
             R.ch->observe_digest(R.perm_rs.t.root);
-            R.c->activate(); R.c->sync();
+            // no synchronisation: blocks released here are handed out again only to work enqueued LATER on this context's stream (runtime.hpp),
+            // and every exchange drains the stream before it touches memory from outside it
             R.perm_nat.clear(); R.main_own.clear(); R.prep_nat.clear();
         }
     }
@@ -657,24 +611,26 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             c.activate();
             plan[k] = Fabric::A2A(&c, W);
             if (!quot_rank(R)) continue;
-            R.halo_send = DBuf(&c, halo_words + 4);
             R.halo_recv = DBuf(&c, halo_words + 4);
-            for (size_t i : big_chips) {
-                size_t pos = halo_off[i];
-                auto put = [&](const DMat& sh) {
-                    VG_HIP_CHECK(hipMemcpyAsync(R.halo_send.data + pos, sh.data, sh.height * sh.width * 4, hipMemcpyDeviceToDevice, c.stream));
-                    pos += sh.height * sh.width;
-                };
+            const int to = pred_rank(R), from = next_rank(R);
+            for (size_t i : big_chips) {  // the first `rows` rows of every column of the three shards (a shard may be taller than its part of the quotient domain)
+                auto put = [&](const DMat& sh) { plan[k].add_send(to, sh.data, quot_rows(rk[0].main_rs.mats[i].L), sh.width, sh.height); };
                 if (prep_slot[i] >= 0) put(R.prep_rs.mats[prep_slot[i]].shard);
                 put(R.main_rs.mats[i].shard);
                 put(R.perm_rs.mats[i].shard);
             }
-            const int to = pred_rank(R), from = next_rank(R);
-            plan[k].send[to] = R.halo_send.data; plan[k].send_words[to] = halo_words;
-            plan[k].recv[from] = R.halo_recv.data; plan[k].recv_words[from] = halo_words;
+            {   // the same segments, laid end to end in the halo block (the quotient kernel reads each as a contiguous column-major matrix)
+                size_t pos = 0;
+                for (size_t i : big_chips) {
+                    const uint64_t rows = quot_rows(rk[0].main_rs.mats[i].L);
+                    auto get = [&](uint64_t width) { plan[k].add_recv(from, R.halo_recv.data + pos, rows, width, rows); pos += rows * width; };
+                    if (prep_slot[i] >= 0) get(R.prep_rs.mats[prep_slot[i]].width);
+                    get(R.main_rs.mats[i].width);
+                    get(R.perm_rs.mats[i].width);
+                }
+            }
         }
         f.all_to_all(plan);
-        for (auto& R : rk) R.halo_send = DBuf();
     }
     for (auto& R : rk) {
         DeviceCtx& c = *R.c;
@@ -745,8 +701,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             vk::launch_quotient(c.stream, a, c.tables);
         }
         c.check_launch("quotient");
-        c.sync();  // pool_dev goes; the halo is no longer read
-        R.halo_recv = DBuf();
+        R.halo_recv = DBuf();  // (and pool_dev) released in stream order: no synchronisation needed
     }
     // rows -> columns: the quotient commit extends whole columns
     std::vector<Fp> quot_shifts(NC, s.exp_power_of_2(1));  // lib.rs:593-596 with log_quotient_degree = 1
@@ -757,61 +712,31 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             // (global chunk column g -> rank g mod W, as in every commitment round)
             auto chunk_rows = [&](size_t i) { return quot_rows(rk[0].main_rs.mats[i].L) / 2; };
             std::vector<Fabric::A2A> plan((size_t)NH);
-            std::vector<std::vector<DBuf>> sb((size_t)NH), rb((size_t)NH);
             for (int k = 0; k < NH; k++) {
                 Rank& R = rk[k];
                 DeviceCtx& c = *R.c;
                 c.activate();
                 plan[k] = Fabric::A2A(&c, W);
-                for (int t = 0; t < W; t++) {
-                    size_t sw = 0, rw = 0;
-                    for (size_t i : big_chips) {
-                        const uint64_t rows = chunk_rows(i);
-                        for (uint64_t col = 0; col < 10; col++) {
-                            const int o = owner_of(10 * (uint64_t)i + col, W);
-                            if (o == t && quot_rank(R)) sw += rows;
-                            if (o == R.rank && t < Wq) rw += rows;
-                        }
+                R.quot_own.clear(); R.quot_own.resize(NC);
+                for (size_t i : big_chips) {
+                    const uint64_t rows = chunk_rows(i), n = rows * (uint64_t)Wq, base = 10 * (uint64_t)i;
+                    auto first_of = [&](int t) { return (uint64_t)(((int64_t)t - (int64_t)(base % (uint64_t)W) + W) % W); };
+                    auto count_of = [&](int t) { const uint64_t f0 = first_of(t); return f0 < 10 ? (10 - f0 + W - 1) / W : 0; };
+                    // a quotient rank sends every rank its chunk rows of that rank's columns (every W-th of the ten) ...
+                    if (quot_rank(R)) {
+                        const DMat& q = R.quot_shard[i];
+                        for (int t = 0; t < W; t++) if (count_of(t)) plan[k].add_send(t, q.data + first_of(t) * q.height, q.height, count_of(t), (uint64_t)W * q.height);
                     }
-                    sb[k].emplace_back(&c, sw + 4);
-                    rb[k].emplace_back(&c, rw + 4);
-                    size_t pos = 0;
-                    if (quot_rank(R))
-                        for (size_t i : big_chips) {
-                            const DMat& q = R.quot_shard[i];
-                            for (uint64_t col = 0; col < 10; col++)
-                                if (owner_of(10 * (uint64_t)i + col, W) == t) {
-                                    VG_HIP_CHECK(hipMemcpyAsync(sb[k][t].data + pos, q.data + col * q.height, q.height * 4, hipMemcpyDeviceToDevice, c.stream));
-                                    pos += q.height;
-                                }
-                        }
-                    plan[k].send[t] = sb[k][t].data; plan[k].send_words[t] = sw;
-                    plan[k].recv[t] = rb[k][t].data; plan[k].recv_words[t] = rw;
+                    // ... and every rank receives, from each quotient rank, that rank's rows of its own columns, laid end to end
+                    const uint64_t mine = count_of(R.rank);
+                    if (mine) {
+                        R.quot_own[i] = DMat(&c, n, mine);
+                        for (int src = 0; src < Wq; src++) plan[k].add_recv(src, R.quot_own[i].data + (uint64_t)src * rows, rows, mine, n);
+                    }
                 }
             }
             f.all_to_all(plan);
-            for (int k = 0; k < NH; k++) {
-                Rank& R = rk[k];
-                DeviceCtx& c = *R.c;
-                c.activate();
-                R.quot_own.clear(); R.quot_own.resize(NC);
-                std::vector<size_t> pos((size_t)W, 0);
-                for (size_t i : big_chips) {
-                    const uint64_t rows = chunk_rows(i), n = rows * (uint64_t)Wq;
-                    std::vector<uint64_t> own;
-                    for (uint64_t col = 0; col < 10; col++) if (owner_of(10 * (uint64_t)i + col, W) == R.rank) own.push_back(col);
-                    if (own.empty()) continue;
-                    R.quot_own[i] = DMat(&c, n, own.size());
-                    for (size_t q = 0; q < own.size(); q++)
-                        for (int src = 0; src < Wq; src++) {
-                            // sender `src` packed, for this rank, (chip, column) segments in ascending order: its chunk rows [src rows, (src+1) rows)
-                            VG_HIP_CHECK(hipMemcpyAsync(R.quot_own[i].data + q * n + (uint64_t)src * rows, rb[k][src].data + pos[src], rows * 4, hipMemcpyDeviceToDevice, c.stream));
-                            pos[src] += rows;
-                        }
-                }
-                R.quot_shard.clear();
-                c.sync();
-            }
+            for (auto& R : rk) R.quot_shard.clear();
         }
         for (int k = 0; k < NH; k++) {
             Rank& R = rk[k];
@@ -1048,8 +973,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             const bool big = L >= min_big;
             vk::launch_reduce_openings(c.stream, pool_dev.data + l.off, big ? L / W : L, big ? s * rho_of(R, l.lh) : s, c.tables, O.ro[l.lh].data, l.total_width, l.accumulate);
         }
-        c.check_launch("reduce openings");
-        c.sync();  // pool_dev goes
+        c.check_launch("reduce openings");  // pool_dev is released in stream order
     }
     if (log_max < lb) throw std::invalid_argument("sharded open: nothing to open");
 
