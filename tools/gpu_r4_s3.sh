@@ -8,7 +8,7 @@ grep "poseidon16" "$OUT/microbench.txt"
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "poseidon or Poseidon or pow or grind" > "$OUT/pytest_poseidon.log" 2>&1; tail -3 "$OUT/pytest_poseidon.log"
 B="python bench.py --no-cpu-baseline --no-extra-legs --mmcs poseidon --steps 9 --warmup 3"
 for rep in 1 2; do
-  for v in new pos_r3 pos_defer_only pos_sbox_only; do
+  for v in ${VARIANTS:-new pos_r3 pos_defer_only pos_sbox_only}; do
     if [ $v = new ]; then L=; else L="VGPU_LIB_PATH=$ROOT/build/variants/$v/libvgpu.so"; fi
     env $L $B > "$OUT/${v}_three_$rep.json" 2> /dev/null
     env $L $B --inflight 1 > "$OUT/${v}_single_$rep.json" 2> /dev/null

@@ -135,12 +135,11 @@ template <bool DIGEST_ONLY> __global__ void __launch_bounds__(256) k_keccak_chai
 
 // The product's Poseidon-16 (kernels/poseidon_perm.hpp: sparse partial rounds, MDS layer as CRT blocks) on register-resident state, `iters`
 // chained permutations per thread, tables through the scalar cache exactly as the MMCS kernels read them.
-__device__ const uint32_t* g_pos_tab;
-__global__ void __launch_bounds__(256) k_poseidon_chain(uint32_t* out, uint32_t seed, int iters) {
+// the table pointer is a kernel argument, as in the MMCS kernels: wave-uniform, read with scalar loads
+__global__ void __launch_bounds__(256) k_poseidon_chain(uint32_t* __restrict__ out, uint32_t seed, int iters, vk::PoseidonTab tab) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     vg::Fp st[16];
     for (int i = 0; i < 16; i++) st[i] = vg::Fp::raw((t * 2654435761u + i * seed) % vg::P);
-    const vk::PoseidonTab tab = vk::tab_of(g_pos_tab, true);
     const uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (int it = 0; it < iters; it++) vk::poseidon16_permute(st, tab);
     const uint64_t c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
@@ -315,13 +314,28 @@ int main(int argc, char** argv) {
             uint32_t* dtab = nullptr;
             CHECK(hipMalloc((void**)&dtab, img.size() * 4));
             CHECK(hipMemcpy(dtab, img.data(), img.size() * 4, hipMemcpyHostToDevice));
-            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pos_tab), &dtab, sizeof(dtab)));
             printf("Poseidon-16 of kernels/poseidon_perm.hpp (sparse tables %s), chained permutations in registers, at 1..5 waves per SIMD\n", sparse ? "valid" : "INVALID: plain rounds");
             printf("%-20s", "poseidon16 chain");
             const int iters = 64;
             for (int wps : {1, 2, 3, 4, 5}) {
                 const int blocks = cu * wps;
-                const double ms = time_kernel(k_poseidon_chain, blocks, iters, d);
+                double ms = 1e30;
+                {
+                    hipEvent_t e0, e1;
+                    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+                    hipLaunchKernelGGL(k_poseidon_chain, dim3(blocks), dim3(256), 0, 0, d, 12345u, 4, vk::tab_of(dtab, true));
+                    CHECK(hipDeviceSynchronize());
+                    for (int rep = 0; rep < 3; rep++) {
+                        CHECK(hipEventRecord(e0));
+                        hipLaunchKernelGGL(k_poseidon_chain, dim3(blocks), dim3(256), 0, 0, d, 12345u, iters, vk::tab_of(dtab, true));
+                        CHECK(hipEventRecord(e1));
+                        CHECK(hipEventSynchronize(e1));
+                        float t;
+                        CHECK(hipEventElapsedTime(&t, e0, e1));
+                        if (t < ms) ms = t;
+                    }
+                    CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+                }
                 const double perms = (double)blocks * 256 * iters, clk = last_kernel_clock_hz();
                 printf("  %5.3f G perm/s (%.0f cyc/perm/wave, %.2f GHz)", perms / ms / 1e6, cu * 4.0 * clk * ms * 1e-3 / ((double)blocks * 4 * iters), clk / 1e9);
             }

@@ -66,8 +66,29 @@ __device__ __forceinline__ void p_store_digest(uint32_t* p, const uint32_t (&d)[
     q[1] = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
+// VGPU_POSEIDON_LDS=1: the kernels read the permutation's tables (1.3 k words of matrix entries and constants) from a copy in LDS — one
+// broadcast ds_read per value — instead of through the scalar cache.  Scalar loads cost no VALU slot by themselves, but a full round needs
+// 112 table values at once and the wave has ~100 SGPRs: hipcc spilled the rest to VGPR lanes, and the v_writelane / v_readlane pairs (8 % of
+// the compress kernel's VALU instructions, plus their hazard no-ops) ARE VALU work.  =0: scalar loads (A/B builds).
+#ifndef VGPU_POSEIDON_LDS
+#define VGPU_POSEIDON_LDS 0
+#endif
+// call at the top of a kernel, by every thread of the workgroup, before any early return
+__device__ __forceinline__ PoseidonTab poseidon_tab_in_lds(const PoseidonTab& tab, uint32_t* s_opt) {
+#if VGPU_POSEIDON_LDS
+    if (tab.opt == nullptr) return tab;
+    for (int i = (int)threadIdx.x; i < POPT_WORDS; i += (int)blockDim.x) s_opt[i] = tab.opt[i];
+    __syncthreads();
+    return PoseidonTab{tab.rc, tab.mds, s_opt};
+#else
+    return tab;
+#endif
+}
+
 template <class Cols>
-__global__ void __launch_bounds__(256) k_poseidon_leaves(const Cols cols, int n_elems, uint64_t n_rows, PoseidonTab tab, uint32_t* __restrict__ digests) {
+__global__ void __launch_bounds__(256) k_poseidon_leaves(const Cols cols, int n_elems, uint64_t n_rows, PoseidonTab gtab, uint32_t* __restrict__ digests) {
+    __shared__ uint32_t s_opt[POPT_WORDS];
+    const PoseidonTab tab = poseidon_tab_in_lds(gtab, s_opt);
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     uint32_t d[8];
@@ -92,14 +113,18 @@ __device__ __forceinline__ void poseidon_node(const uint32_t* __restrict__ prev,
 }
 
 __global__ void __launch_bounds__(256) k_poseidon_compress(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int n_elems, uint64_t n_out,
-                                                           PoseidonTab tab, uint32_t* __restrict__ next) {
+                                                           PoseidonTab gtab, uint32_t* __restrict__ next) {
+    __shared__ uint32_t s_opt[POPT_WORDS];
+    const PoseidonTab tab = poseidon_tab_in_lds(gtab, s_opt);
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     poseidon_node(prev, cols, n_elems, i, tab, next);
 }
 
 // the last <= 11 levels of a tree in one launch (one 1024-thread workgroup, a barrier per level), as k_keccak_top
-__global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, PoseidonTab tab) {
+__global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, PoseidonTab gtab) {
+    __shared__ uint32_t s_opt[POPT_WORDS];
+    const PoseidonTab tab = poseidon_tab_in_lds(gtab, s_opt);
     const uint32_t* prev = a.prev;
     for (int l = 0; l < a.levels; l++) {
         const uint64_t len = a.first_len >> l;

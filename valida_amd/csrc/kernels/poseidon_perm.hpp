@@ -7,6 +7,39 @@
 
 namespace vk {
 
+// The permutation's tables are wave-uniform and read with scalar loads.  Left alone, hipcc hoists every load of a round body to its top — a
+// full round then wants 112 values in ~100 SGPRs and the rest is spilled to VGPR lanes (v_writelane / v_readlane: VALU instructions, 8 % of the
+// compress kernel).  VGPU_POSEIDON_FENCE=1 puts a compiler-level memory fence between the sections of a round, so that a section's table
+// values are loaded when it starts and are dead when it ends.  =0: A/B builds.
+#ifndef VGPU_POSEIDON_FENCE
+#define VGPU_POSEIDON_FENCE 1
+#endif
+#if VGPU_POSEIDON_FENCE && defined(__HIP_DEVICE_COMPILE__)
+#define POSEIDON_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define POSEIDON_FENCE() do { } while (0)
+#endif
+// the tables as CONSTANT-address-space memory: a uniform load from it is a scalar load whatever else the kernel does to memory
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) uint32_t* popt_ptr;
+__device__ __forceinline__ popt_ptr popt_of(const uint32_t* p) { return reinterpret_cast<popt_ptr>(reinterpret_cast<uintptr_t>(p)); }
+// K table words (K a multiple of 4, 16-byte aligned) as VOLATILE 4-word scalar loads: the loads stay where the code puts them (not hoisted to
+// the top of the round, not merged across sections), four words per scalar-memory instruction
+template <int K> __device__ __forceinline__ void popt_load(popt_ptr p, uint32_t (&out)[K]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef const volatile __attribute__((address_space(4))) u4* vp;
+#pragma unroll
+    for (int i = 0; i < K; i += 4) {
+        const u4 v = *reinterpret_cast<vp>(p + i);
+        out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z; out[i + 3] = v.w;
+    }
+}
+#else
+typedef const uint32_t* popt_ptr;
+__host__ __device__ inline popt_ptr popt_of(const uint32_t* p) { return p; }
+template <int K> __host__ __device__ inline void popt_load(popt_ptr p, uint32_t (&out)[K]) { for (int i = 0; i < K; i++) out[i] = p[i]; }
+#endif
+
 struct PoseidonTab {
     const uint32_t* __restrict__ rc;   // [30][16] Montgomery
     const uint32_t* __restrict__ mds;  // [16] circulant coefficients: M[j][i] = mds[(j - i) & 15]
@@ -15,7 +48,7 @@ struct PoseidonTab {
 // offsets into `opt` (words) — must match vhost::PoseidonOptTables
 constexpr int POPT_RC_FULL = 0, POPT_T = 128, POPT_SPARSE = 152, POPT_F = 152 + 21 * 32, POPT_FFT_FWD = POPT_F + 256, POPT_FFT_INV = POPT_FFT_FWD + 16,
               POPT_FFT_LAM = POPT_FFT_INV + 16, POPT_BLK_N8 = POPT_FFT_LAM + 16, POPT_BLK_C4 = POPT_BLK_N8 + 64, POPT_BLK_N4 = POPT_BLK_C4 + 16,
-              POPT_CROSS = POPT_BLK_N4 + 16;
+              POPT_CROSS = POPT_BLK_N4 + 16, POPT_WORDS = POPT_CROSS + 24 * 4;
 
 // y = M x with M circulant; four products share one Montgomery reduction (4 p^2 < 2^64)
 __device__ __forceinline__ void poseidon_mds(Fp (&st)[16], const uint32_t (&m)[16]) {
@@ -50,7 +83,9 @@ __device__ __forceinline__ void poseidon_mds_convolution(Fp (&st)[16], const uin
 // ... and as the CRT split x^16 - 1 = (x^8 + 1)(x^4 + 1)(x^4 - 1) of that convolution (host/poseidon_opt.hpp, BLK_*): 24 additions /
 // subtractions, a negacyclic 8 x 8, a negacyclic 4 x 4 and a cyclic 4 x 4 product with lazily accumulated terms (96 multiply-adds, 24
 // reductions), 24 additions / subtractions back.  No twiddle products; ~430 instructions.
-template <int K> __device__ __forceinline__ Fp poseidon_dot(const uint32_t* __restrict__ row, const Fp (&v)[K]) {
+template <int K> __device__ __forceinline__ Fp poseidon_dot(popt_ptr rowp, const Fp (&v)[K]) {
+    uint32_t row[K];
+    popt_load<K>(rowp, row);
     Fp acc = Fp::zero();
 #pragma unroll
     for (int i0 = 0; i0 < K; i0 += 4) {
@@ -62,17 +97,23 @@ template <int K> __device__ __forceinline__ Fp poseidon_dot(const uint32_t* __re
     }
     return acc;
 }
-__device__ __forceinline__ void poseidon_mds_blocks(Fp (&st)[16], const uint32_t* __restrict__ o) {
+__device__ __forceinline__ void poseidon_mds_blocks(Fp (&st)[16], popt_ptr o) {
     Fp am[8], ap[8], app[4], apm[4];
 #pragma unroll
     for (int i = 0; i < 8; i++) { am[i] = st[i] - st[i + 8]; ap[i] = st[i] + st[i + 8]; }
 #pragma unroll
     for (int i = 0; i < 4; i++) { apm[i] = ap[i] - ap[i + 4]; app[i] = ap[i] + ap[i + 4]; }
     Fp ym[8], ypp[4], ypm[4];
+    POSEIDON_FENCE();
 #pragma unroll
-    for (int k = 0; k < 8; k++) ym[k] = poseidon_dot<8>(o + POPT_BLK_N8 + 8 * k, am);
+    for (int k = 0; k < 4; k++) ym[k] = poseidon_dot<8>(o + POPT_BLK_N8 + 8 * k, am);
+    POSEIDON_FENCE();
+#pragma unroll
+    for (int k = 4; k < 8; k++) ym[k] = poseidon_dot<8>(o + POPT_BLK_N8 + 8 * k, am);
+    POSEIDON_FENCE();
 #pragma unroll
     for (int k = 0; k < 4; k++) { ypp[k] = poseidon_dot<4>(o + POPT_BLK_C4 + 4 * k, app); ypm[k] = poseidon_dot<4>(o + POPT_BLK_N4 + 4 * k, apm); }
+    POSEIDON_FENCE();
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const Fp lo = ypp[i] + ypm[i], hi = ypp[i] - ypm[i];
@@ -122,7 +163,9 @@ __device__ __forceinline__ Fp poseidon_sbox_plus(Fp x, uint32_t c) {
 }
 
 // row . state for one row of 16 wave-uniform coefficients
-__device__ __forceinline__ Fp poseidon_dot16(const uint32_t* __restrict__ row, const Fp (&st)[16]) {
+__device__ __forceinline__ Fp poseidon_dot16(popt_ptr rowp, const Fp (&st)[16]) {
+    uint32_t row[16];
+    popt_load<16>(rowp, row);
     Fp acc = Fp::zero();
 #pragma unroll
     for (int i0 = 0; i0 < 16; i0 += 4) {
@@ -138,13 +181,15 @@ __device__ __forceinline__ Fp poseidon_dot16(const uint32_t* __restrict__ row, c
 #define VGPU_POSEIDON_DEFER 1  // the sparse partial rounds in groups of four with deferred updates (below); 0: round by round (A/B builds)
 #endif
 // N consecutive sparse rounds starting at round g0 (a multiple of 4), st[1..15] updated at the end
-template <int N> __device__ __forceinline__ void poseidon_sparse_group(Fp (&st)[16], const uint32_t* __restrict__ o, int g0) {
+template <int N> __device__ __forceinline__ void poseidon_sparse_group(Fp (&st)[16], popt_ptr o, int g0) {
     uint64_t upd[16];
     Fp x0s[N];
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const uint32_t* __restrict__ s = o + POPT_SPARSE + 32 * (g0 + k);
-        const uint32_t* __restrict__ cr = o + POPT_CROSS + 4 * (g0 + k);
+        POSEIDON_FENCE();
+        uint32_t s[32], cr[4];
+        popt_load<32>(o + POPT_SPARSE + 32 * (g0 + k), s);
+        popt_load<4>(o + POPT_CROSS + 4 * (g0 + k), cr);
         const Fp x0 = poseidon_sbox_plus(st[0], o[POPT_T + g0 + k]);  // the round's scalar rides in the S-box's input
         x0s[k] = x0;
         // a x0 + u . x^(group start) + sum_j cross[j] x0_j: 16 + k terms, four per reduction
@@ -193,13 +238,15 @@ __device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonT
     }
     // 4 full rounds, 21 SPARSE partial rounds (31 products each instead of 256), one dense partial round, 4 full rounds — the same
     // permutation (host/poseidon_opt.hpp derives the tables and checks them against the plain form)
-    const uint32_t* __restrict__ o = tab.opt;
+    popt_ptr o = popt_of(tab.opt);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
-        const uint32_t* rc = o + POPT_RC_FULL + 16 * r;
+        POSEIDON_FENCE();
+        uint32_t rc[16];
+        popt_load<16>(o + POPT_RC_FULL + 16 * r, rc);
 #pragma unroll
         for (int i = 0; i < 16; i++) st[i] = poseidon_sbox_plus(st[i], rc[i]);
-        if (VGPU_POSEIDON_MDS == 2) poseidon_mds_blocks(st, o); else if (VGPU_POSEIDON_MDS == 1) poseidon_mds_convolution(st, o); else poseidon_mds(st, m);
+        if (VGPU_POSEIDON_MDS == 2) poseidon_mds_blocks(st, o); else if (VGPU_POSEIDON_MDS == 1) poseidon_mds_convolution(st, tab.opt); else poseidon_mds(st, m);
     }
 #if !VGPU_POSEIDON_DEFER
     st[0] += Fp::raw(o[POPT_T]);
@@ -215,7 +262,7 @@ __device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonT
 #else
 #pragma unroll 1
     for (int i = 0; i < 21; i++) {
-        const uint32_t* __restrict__ s = o + POPT_SPARSE + 32 * i;
+        popt_ptr s = o + POPT_SPARSE + 32 * i;
         const Fp x0 = poseidon_sbox(st[0]);
         Fp tmp[16];
         tmp[0] = x0;
@@ -235,16 +282,19 @@ __device__ __forceinline__ void poseidon16_permute(Fp (&st)[16], const PoseidonT
 #endif
         Fp out[16];
 #pragma unroll
-        for (int a = 0; a < 16; a++) out[a] = poseidon_dot16(o + POPT_F + 16 * a, st);
+        for (int a = 0; a < 16; a++) { if ((a & 3) == 0) POSEIDON_FENCE(); out[a] = poseidon_dot16(o + POPT_F + 16 * a, st); }
+        POSEIDON_FENCE();
 #pragma unroll
         for (int a = 0; a < 16; a++) st[a] = out[a];
     }
 #pragma unroll 1
     for (int r = 4; r < 8; r++) {
-        const uint32_t* rc = o + POPT_RC_FULL + 16 * r;
+        POSEIDON_FENCE();
+        uint32_t rc[16];
+        popt_load<16>(o + POPT_RC_FULL + 16 * r, rc);
 #pragma unroll
         for (int i = 0; i < 16; i++) st[i] = poseidon_sbox_plus(st[i], rc[i]);
-        if (VGPU_POSEIDON_MDS == 2) poseidon_mds_blocks(st, o); else if (VGPU_POSEIDON_MDS == 1) poseidon_mds_convolution(st, o); else poseidon_mds(st, m);
+        if (VGPU_POSEIDON_MDS == 2) poseidon_mds_blocks(st, o); else if (VGPU_POSEIDON_MDS == 1) poseidon_mds_convolution(st, tab.opt); else poseidon_mds(st, m);
     }
 }
 
