@@ -39,16 +39,15 @@ StarkConfig make_cfg(const uint32_t* rc, uint32_t log_blowup, uint32_t num_queri
 extern "C" {
 void oracle_set_observe_final_poly(int on) { g_observe_final_poly = on != 0; }
 // Fast mode (fast.hpp): the same proof words computed with AVX2 Montgomery transforms, an unrolled Keccak, batch inversions.  Process-wide.
-void oracle_set_fast(int on) {
-    oracle::fast::enabled() = on != 0;
-    if (on) {
-        // A proof allocates and frees tens of GB in blocks of hundreds of MB; glibc hands such blocks back to the kernel at once and every new one
-        // is page-faulted in again (measured here: 2 GB/s, single-threaded inside the vector constructors).  Keep freed memory in the heap instead:
-        // later phases of the same proof reuse pages the earlier ones faulted in (the reuse runs at memset speed).
-        const char* keep = getenv("ORACLE_KEEP_HEAP");  // =0: A/B without
-        if (!keep || keep[0] != '0') mallopt(M_MMAP_MAX, 0);
-        if (!keep || keep[0] != '0') mallopt(M_TRIM_THRESHOLD, -1);
-    }
+void oracle_set_fast(int on) { oracle::fast::enabled() = on != 0; }
+// For a process that proves ONCE and exits (oracle/cpu_baseline.py, the bench's CPU leg): a proof allocates and frees tens of GB in blocks of
+// hundreds of MB; glibc hands such blocks back to the kernel at once and every new one is page-faulted in again (single-threaded, inside the
+// vector constructors).  Keeping freed memory in the heap lets the later phases of the proof reuse pages the earlier ones faulted in: 4.1 s
+// against 5.5 s for the headline segment on the MI355X box's 16 cores.  Process-wide and permanent — NOT for long-lived test processes (the
+// CPU suite slowed down several-fold under it).
+void oracle_keep_heap() {
+    mallopt(M_MMAP_MAX, 0);
+    mallopt(M_TRIM_THRESHOLD, -1);
 }
 int oracle_get_fast() { return oracle::fast::enabled() ? 1 : 0; }
 // MMCS hash of every commitment made after the call: 0 = Keccak (reference), 1 = Poseidon-16 sponge / truncated permutation with

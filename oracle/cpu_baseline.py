@@ -28,6 +28,8 @@ def main():
     if mmcs:
         po.set_mmcs_hash(1, rc)
     po.set_fast(fast)
+    if fast and os.environ.get("ORACLE_KEEP_HEAP", "1") != "0":
+        po.keep_heap()
     res = po.prove_basic(w.main_traces(), prep[0][1], prep[1][1], rc)
     print(json.dumps({"seconds": res.seconds, "cores": po.usable_cores(), "fast": fast, "sha256": hashlib.sha256(res.bytes()).hexdigest(), "words": int(res.words.size)}), flush=True)
 

@@ -260,6 +260,11 @@ def set_fast(on):
     lib().oracle_set_fast(ctypes.c_int(1 if on else 0))
 
 
+def keep_heap():
+    """oracle_keep_heap: freed memory stays in the heap (glibc mallopt) — for the one-proof baseline process only."""
+    lib().oracle_keep_heap()
+
+
 def set_mmcs_hash(kind, rc=None):
     """0: Keccak MMCS (the reference's); 1: Poseidon-16 sponge / truncated permutation with round constants `rc`."""
     if kind == 1:

@@ -8,6 +8,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The oracle's OpenMP runtime must wait PASSIVELY and use no more threads than this process may run on.  Test modules import torch at collection
+# time, and torch's own libgomp.so.1 is then the copy the oracle library binds to — initialised before oracle/pyoracle.py gets to set these
+# variables: with spinning waits on a box whose cores are shared the verifier tests (thousands of tiny parallel regions) took minutes instead of
+# seconds.  conftest.py is imported before any test module: set them here.
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cores()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

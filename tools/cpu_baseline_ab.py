@@ -15,6 +15,8 @@ w = va.Workload.fib(n)
 prep = w.preprocessed()
 rc = va.poseidon_round_constants()
 po.set_fast(True)
+if os.environ.get("ORACLE_KEEP_HEAP", "1") != "0":
+    po.keep_heap()
 t = time.time()
 b = po.prove_basic(w.main_traces(), prep[0][1], prep[1][1], rc)
 print("fast mode: %.2f s (%.2f s inside prove) on %d cores, sha256 %s" % (time.time() - t, b.seconds, po.usable_cores(), hashlib.sha256(b.bytes()).hexdigest()), flush=True)
