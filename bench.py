@@ -313,6 +313,9 @@ def main():
                 probe = cm.allgather_roots(np.full(24, rank, dtype=np.uint32))
                 if [int(r[0]) for r in probe] != list(range(world)):
                     raise RuntimeError("probe all-gather returned %s" % probe[:, 0].tolist())
+                # every later collective of the library is bounded: a rank that died mid-run aborts the communicator of its peers (ncclCommAbort)
+                # after this long instead of hanging them until the driver's own limit
+                cm.set_timeout_ms(int(os.environ.get("VGPU_BENCH_COLLECTIVE_TIMEOUT_MS", "120000")))
                 box["comm"] = cm
             except Exception as e:  # noqa: BLE001 - the scaling run must not die on the optional route
                 box["error"] = e
