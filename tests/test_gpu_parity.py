@@ -862,6 +862,14 @@ def test_rccl_communicator_of_the_library_world_of_one(prover, fib25):
     mt = fib25.main_traces()
     dm = [prover.upload(m) for m in mt]
     assert first_mismatch(comm.commit_batches_sharded(dm), prover.commit_batches(dm).root) is None
+    # the same collectives under a deadline (vgpu_comm_set_timeout_ms: event + ncclCommGetAsyncError polling instead of a stream synchronisation;
+    # what bench.py --gpus N runs with), and a whole sharded proof through the deadline-bounded exchanges of the RCCL fabric
+    comm.set_timeout_ms(20000)
+    assert np.array_equal(comm.allgather_roots(roots[::-1].copy()), roots[::-1].reshape(1, 24))
+    prep = fib25.preprocessed()
+    single = prover.prove(dm, [(c, prover.upload(m)) for c, m in prep])
+    sharded = comm.prove_sharded([prover.upload(m) for m in mt], [(c, prover.upload(m)) for c, m in prep], log_min_sharded=4)
+    assert first_mismatch(sharded.words, single.words) is None
 
 
 @pytest.mark.gpu
