@@ -279,6 +279,75 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
     }
 }
 
+// ---- thread per POINT (round 4; the compiled chips) ------------------------------------------------------------------------------------
+// k_quotient above gives a thread the PAIR (x, -x) = storage rows 2m, 2m + 1 and evaluates the two points one after the other: a wave's
+// loads of a column then touch every second row of a 512-byte stretch, twice — once per point, a whole chip's worth of other columns apart:
+// the second visit misses the caches, and the PMC passes see 2.0-2.2x the algorithmic bytes.  Here adjacent LANES take the two points of a
+// pair: a wave reads 64 consecutive storage rows of a column in ONE fully used 256-byte request, every LDE word is fetched once, a thread
+// holds one point's live values instead of being written for two.  The pair's decomposition (quotient.rs:63-67, App. B11: even = (a + b) / 2,
+// odd = (a - b) / (2 x)) needs both values: one DPP quad_perm exchange of the five limbs, then the even lane forms the sum (chunk columns
+// 0..4) and the odd lane the difference (columns 5..9).  Same successor-closed workgroup tiles as k_quotient — 8 groups x 32 pairs (16 x 16
+// with the natural-order store) — now 512 threads.  One inversion per point instead of one per pair (+37 of some hundreds of products).
+// Values identical to k_quotient's: every parity test runs through it.  VGPU_QUOT_PER_POINT=0 (environment) selects the pair kernel (A/B).
+template <int CHIP>
+__global__ void __launch_bounds__(512) k_quotient_pt(QuotientArgs a, DeviceTables tb) {
+    const uint64_t n = 1ull << a.log_n;
+    const uint32_t T = threadIdx.x >> 1, pt = threadIdx.x & 1u;  // the pair's slot in the workgroup, and which of its two points
+    uint64_t m = (uint64_t)blockIdx.x * 256 + T;
+    const bool tiled = a.log_n >= 9;
+    const bool nat_tile = tiled && a.out_natural;
+    if (nat_tile) {
+        m = ((uint64_t)(T >> 4) << (a.log_n - 4)) | ((uint64_t)blockIdx.x << 4) | (T & 15u);
+    } else if (tiled) {
+        const uint32_t B = blockIdx.x, top = B >> (a.log_n - 9), mid = B & ((1u << (a.log_n - 9)) - 1u);
+        m = ((uint64_t)top << (a.log_n - 1)) | ((uint64_t)(T >> 5) << (a.log_n - 4)) | ((uint64_t)mid << 5) | (T & 31u);
+    }
+    if (m >= n) return;  // both lanes of a pair leave together; never in a tiled launch
+    const int kq = a.log_n + 1;
+    const uint32_t Qmask = (uint32_t)(2 * n - 1);
+    const uint32_t j = (uint32_t)(2 * m) + pt;                                            // storage row of this point
+    const uint32_t i0 = vg::reverse_bits_len((uint32_t)m, (unsigned)a.log_n);           // natural index of the pair's even row
+    const uint32_t i = i0 + pt * (uint32_t)n;                                             // ... of this point
+    const Fp s = Fp::raw(a.coset_shift), g_inv = Fp::raw(a.g_inv);
+    const Fp x0 = s * domain_point(tb, (uint32_t)(2 * m));
+    const Fp x = pt ? -x0 : x0;                                                           // w_Q^(i0 + n) = -w_Q^i0
+    const Fp d0 = x - Fp::one(), d1 = x - g_inv;
+    const Fp inv = (d0 * d1).inv();
+    const uint32_t par = i & 1u;
+    PointCtx p;
+    p.row = j;
+    p.next_row = vg::reverse_bits_len((i + a.next_step_p1 - 1u) & Qmask, (unsigned)kq);
+    p.is_trans = d1;
+    p.is_first = Fp::raw(a.zh[par]) * (inv * d1);
+    p.is_last = Fp::raw(a.zh[par]) * (inv * d0);
+    Ext5 q = run_native<CHIP>(a, p);
+    q = (q + perm_constraints(a, p)) * Fp::raw(a.zh_inv[par]);
+    Ext5 o;  // the partner lane's value
+#pragma unroll
+    for (int c = 0; c < 5; c++) o.c[c] = Fp::raw((uint32_t)__builtin_amdgcn_update_dpp(0, (int)q.c[c].v, 0xB1, 0xF, 0xF, true));
+    const Fp x0_inv = Fp::raw(a.coset_shift_inv) * inv_domain_point(tb, (uint32_t)(2 * m));
+    Fp outv[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) outv[c] = (pt ? (o.c[c] - q.c[c]) * x0_inv : q.c[c] + o.c[c]).halve();  // odd lane: (q0 - q1) / (2 x0); even lane: (q0 + q1) / 2
+    const uint32_t col0 = 5u * pt;
+    if (nat_tile) {
+        __shared__ uint32_t tr[10 * 256];
+        const uint32_t A = T >> 4, r = T & 15u, slot = (r << 4) | (__brev(A) >> 28);
+#pragma unroll
+        for (int c = 0; c < 5; c++) tr[(col0 + c) * 256 + slot] = outv[c].v;
+        __syncthreads();
+        // 512 threads store the 10 x 256 tile: the first 256 the sum columns, the others the difference columns; slot t <-> row as in k_quotient
+        const uint32_t t = threadIdx.x & 255u, half = threadIdx.x >> 8, A2 = t >> 4, r2 = t & 15u;
+        const uint64_t row = ((uint64_t)(__brev(A2) >> 28) << (a.log_n - 4)) | ((uint64_t)(a.log_n > 8 ? __brev((uint32_t)blockIdx.x) >> (32 - (a.log_n - 8)) : 0u) << 4) | r2;
+#pragma unroll
+        for (int c = 0; c < 5; c++) a.out.data[(uint64_t)(5 * half + c) * a.out.stride + row] = tr[(5 * half + c) * 256 + t];
+        return;
+    }
+    const uint64_t pos = a.out_natural ? (uint64_t)i0 : m;
+#pragma unroll
+    for (int c = 0; c < 5; c++) a.out.data[(uint64_t)(col0 + c) * a.out.stride + pos] = outv[c].v;
+}
+
 // ---- log_quotient_degree >= 2 (AIRs of degree 4..9 captured through vgpu_air_*; no chip of the reference needs it) -------------
 // The quotient domain s*H_{Qn}, Q = 2^lqd, is the first Qn storage rows; thread m owns storage rows Qm .. Qm+Q-1 = natural indices
 // i0 + n bitrev_lqd(r), i.e. the Q points x0 w_Q^{bitrev(r)}: every pair decompose() butterflies at any level of its recursion
@@ -437,6 +506,19 @@ void launch_quotient(hipStream_t st, const QuotientArgs& a_in, const DeviceTable
                                     "k_quotient.static_data", "k_quotient", "k_quotient"};
     const char* pname = getenv("VGPU_PROF_QUOTIENT_BY_CHIP") && a.native_chip >= 0 && a.native_chip < 14 ? names[a.native_chip] : "k_quotient";
     ProfScope ps(pname, st, 4.0 * n * (2.0 * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 10.0));
+    static const bool per_point = [] { const char* e = getenv("VGPU_QUOT_PER_POINT"); return !(e && e[0] == '0'); }();
+    if (a.native_chip != QuotientArgs::INTERPRET && per_point) {
+        // thread per point, 512 threads = 256 pairs per workgroup (k_quotient_pt)
+        const dim3 grid((unsigned)((n + 255) / 256)), block(512);
+        switch (a.native_chip) {
+#define VG_NATIVE_PT(C) case vchips::C: VK_LAUNCH((k_quotient_pt<vchips::C>), grid, block, 0, st, a, tb); break;
+            VG_NATIVE_PT(CHIP_CPU) VG_NATIVE_PT(CHIP_ADD) VG_NATIVE_PT(CHIP_SUB) VG_NATIVE_PT(CHIP_MUL) VG_NATIVE_PT(CHIP_SHIFT) VG_NATIVE_PT(CHIP_LT)
+            VG_NATIVE_PT(CHIP_COM) VG_NATIVE_PT(CHIP_BITWISE) VG_NATIVE_PT(CHIP_OUTPUT) VG_NATIVE_PT(CHIP_STATIC_DATA)
+#undef VG_NATIVE_PT
+            default: VK_LAUNCH((k_quotient_pt<-1>), grid, block, 0, st, a, tb); break;
+        }
+        return;
+    }
     if (a.native_chip != QuotientArgs::INTERPRET) {
         // the BasicMachine chips: eval compiled ahead of time, one kernel per chip with constraints
         const dim3 grid((unsigned)((n + 255) / 256)), block(256);
