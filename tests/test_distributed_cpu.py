@@ -320,3 +320,65 @@ def test_a_rank_that_never_enters_the_exchange_costs_its_peers_the_deadline():
     rank, msg, errors, took = res[0]
     assert msg is not None and "did not return within 2000 ms" in msg, (msg, errors)
     assert 1.5 < took < 20, took
+
+
+# ---- round 4: the TRACES sharded too (vgpu_prove_sharded_rows*, sharded_prover.cpp "row-range inputs") over a real process group: four gloo
+# ranks, the CPU oracle standing in for the device kernels.  Every rank holds rows [r n / W, (r + 1) n / W) of a chip's main trace and checks
+# what the device code relies on:
+#   running sum   generate_permutation_trace (machine/src/chip.rs:176-205) over the whole trace = the oracle's trace over the rank's rows (a local
+#                 scan from zero) + the totals of the ranks before it (ONE all-gather of 5 words per rank); the reciprocal columns are row-local;
+#                 the chip's cumulative sum is the total over all ranks;
+#   rows -> cols  the all-to-all that deals the row ranges into whole columns (global column g -> rank g mod W) reassembles every owned column.
+def _row_range_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import valida_amd as va
+    from oracle import pyoracle as po
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    P = 2013265921
+    w = va.Workload.fib(582)
+    rng = np.random.default_rng(17)  # the same challenges on every rank (the transcript is replicated)
+    challenges = rng.integers(0, P, 15, dtype=np.uint32)
+    for chip in (0, 2, 3):  # cpu, mem, add: the chips a C2 proof splits (no preprocessed trace)
+        main = w.main_trace(chip)
+        n = main.shape[0]
+        rows = n // world
+        mine = np.ascontiguousarray(main[rank * rows:(rank + 1) * rows])
+        whole = po.perm_trace(chip, main, challenges)            # ground truth: the row-serial running sum over the whole trace
+        local = po.perm_trace(chip, mine, challenges)            # what a rank computes: reciprocals of its rows, running sum from zero
+        M = whole.shape[1] // 5 - 1
+        assert np.array_equal(local[:, :5 * M], whole[rank * rows:(rank + 1) * rows, :5 * M])  # reciprocal columns are row-local
+        totals = [None] * world
+        dist.all_gather_object(totals, [int(x) for x in local[-1, 5 * M:]])  # ONE exchange: every rank's total
+        before = [sum(t[k] for t in totals[:rank]) % P for k in range(5)]
+        fixed = (local[:, 5 * M:].astype(np.uint64) + np.array(before, dtype=np.uint64)) % P
+        assert np.array_equal(fixed.astype(np.uint32), whole[rank * rows:(rank + 1) * rows, 5 * M:])
+        cumulative = [sum(t[k] for t in totals) % P for k in range(5)]
+        assert cumulative == [int(x) for x in whole[-1, 5 * M:]]
+        # rows -> columns: to rank t my rows of the columns it owns; column base 3 (the matrix is not the first of its round)
+        base, width = 3, main.shape[1]
+        send = [mine[:, [c for c in range(width) if (base + c) % world == t]] for t in range(world)]
+        box = [None] * world
+        dist.all_gather_object(box, send)  # gloo has no all-to-all: every rank picks its row of the matrix of messages
+        own = [c for c in range(width) if (base + c) % world == rank]
+        assert np.array_equal(np.concatenate([box[src][rank] for src in range(world)], axis=0), main[:, own])
+    q.put(rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_range_inputs_protocol_over_gloo():
+    world, port = 4, 35500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_row_range_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    done = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert done == list(range(world))
