@@ -121,14 +121,74 @@ __global__ void __launch_bounds__(256) k_poseidon_compress(const uint32_t* __res
     poseidon_node(prev, cols, n_elems, i, tab, next);
 }
 
+// ---- ONE PERMUTATION PER 16-LANE ROW (round 4): for the one-permutation-deep levels of a tree top --------------------------------------------
+// A tree top is a chain: level after level of at most a few dozen nodes, each a permutation deep (three with an injected matrix).  With a
+// thread per node a lone wave issues the permutation's ~9 200 dependent instructions one after the other (~19 us per level); spread over the 16
+// lanes of a DPP row — lane l holds state[l] — a round is an S-box (every lane, or lane 0 in the partial rounds), the round constant of the
+// lane, and the circulant MDS layer as 16 row rotations (v_mov_dpp row_ror:d brings x[(l - d) & 15] to lane l) times the wave-uniform
+// coefficient mds[d], accumulated lazily four at a time: ~85 dependent instructions per round, ~2 600 per permutation, four permutations per
+// wave.  Plain rounds (no sparse form: the partial rounds' saving is in the products the other lanes do in parallel anyway).  Levels of more
+// than 64 nodes stay with the thread-per-node permutation (1024 threads / 16 lanes = 64 rows).  VGPU_POSEIDON_ROWS=0: A/B builds.
+#ifndef VGPU_POSEIDON_ROWS
+#define VGPU_POSEIDON_ROWS 1
+#endif
+template <int D> __device__ __forceinline__ uint32_t p_row_ror(uint32_t v) {
+    if (D == 0) return v;
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + D, 0xF, 0xF, true);  // DPP row_ror:D — lane l of each row reads lane (l - D) & 15
+}
+template <int D0> __device__ __forceinline__ Fp p_mds4(uint32_t x, const uint32_t (&m)[16]) {
+    uint64_t t = (uint64_t)m[D0] * p_row_ror<D0>(x);
+    t += (uint64_t)m[D0 + 1] * p_row_ror<D0 + 1>(x);
+    t += (uint64_t)m[D0 + 2] * p_row_ror<D0 + 2>(x);
+    t += (uint64_t)m[D0 + 3] * p_row_ror<D0 + 3>(x);
+    return Fp::raw(vg::monty_reduce_wide(t));
+}
+// st = this lane's coordinate; all 16 lanes of the row run it together
+__device__ __forceinline__ Fp poseidon16_row(Fp st, const PoseidonTab& tab, const uint32_t (&m)[16], int l16) {
+    uint32_t c_next = tab.rc[l16];  // the lane's round constant, fetched one round ahead (a vector load in the dependent chain would cost more than the round)
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        const uint32_t c = c_next;
+        c_next = tab.rc[16 * (r < 29 ? r + 1 : 0) + l16];
+        const bool full = r < 4 || r >= 26;
+        const Fp x = (full || l16 == 0) ? poseidon_sbox_plus(st, c) : st + Fp::raw(c);
+        st = (p_mds4<0>(x.v, m) + p_mds4<4>(x.v, m)) + (p_mds4<8>(x.v, m) + p_mds4<12>(x.v, m));  // y[l] = sum_d mds[d] x[(l - d) & 15]
+    }
+    return st;
+}
+// one tree node by the 16 lanes of a row: compress of the two child digests, plus the injected rows' hash and a second compress
+__device__ __forceinline__ void poseidon_node_row(const uint32_t* __restrict__ prev, const uint32_t* const* cols, int n_elems, uint64_t node, int l16, const PoseidonTab& tab,
+                                                  const uint32_t (&m)[16], uint32_t* __restrict__ next) {
+    Fp st = poseidon16_row(Fp::from_canonical(prev[16 * node + l16]), tab, m, l16);  // lanes 0..7: left digest, 8..15: right — as they lie in the layer below
+    if (n_elems > 0) {
+        const Fp d = st;
+        Fp h = Fp::zero();
+        for (int base = 0; base < n_elems; base += 8) {  // PaddingFreeSponge: each chunk of 8 overwrites the head of the state
+            if (l16 < 8 && base + l16 < n_elems) h = Fp::raw(cols[base + l16][node]);
+            h = poseidon16_row(h, tab, m, l16);
+        }
+        // compress(d, h): the canonical words of both digests re-enter as field elements (canonical -> Montgomery is the identity on the value)
+        const uint32_t hs = p_row_ror<8>(h.v);  // lane 8 + k reads lane k
+        st = poseidon16_row(l16 < 8 ? d : Fp::raw(hs), tab, m, l16);
+    }
+    if (l16 < 8) next[8 * node + l16] = st.canonical();
+}
+
 // the last <= 11 levels of a tree in one launch (one 1024-thread workgroup, a barrier per level), as k_keccak_top
 __global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, PoseidonTab gtab) {
     __shared__ uint32_t s_opt[POPT_WORDS];
     const PoseidonTab tab = poseidon_tab_in_lds(gtab, s_opt);
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
     const uint32_t* prev = a.prev;
     for (int l = 0; l < a.levels; l++) {
         const uint64_t len = a.first_len >> l;
-        if (threadIdx.x < len) poseidon_node(prev, a.cols[l], a.n_elems[l], threadIdx.x, tab, a.out[l]);
+        if (VGPU_POSEIDON_ROWS && len <= 64) {
+            if ((threadIdx.x >> 4) < len) poseidon_node_row(prev, a.cols[l], a.n_elems[l], threadIdx.x >> 4, (int)(threadIdx.x & 15), tab, m, a.out[l]);
+        } else if (threadIdx.x < len) {
+            poseidon_node(prev, a.cols[l], a.n_elems[l], threadIdx.x, tab, a.out[l]);
+        }
         __threadfence_block();
         __syncthreads();
         prev = a.out[l];
