@@ -103,6 +103,7 @@ struct Rank {
     DBuf halo_send, halo_recv;
     std::vector<DMat> quot_full, quot_shard, quot_own;
     std::vector<uint32_t> words;
+    std::vector<uint32_t> perm_totals;  // canonical: per chip the last running sum of this rank's rows (row-range inputs)
 };
 
 }  // namespace
@@ -508,7 +509,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         c.download_small(cs.data(), gout.data, cs.size() * 4);  // synchronises: pool_dev / scratch may go
         R.cumulative_sums.resize(NC);
         for (size_t i = 0; i < NC; i++) R.cumulative_sums[i] = sp_ext_from_canonical(cs.data() + 5 * i);
-        R.words = cs;  // a split chip's entry is the total of ITS rows only: completed below
+        R.perm_totals = cs;  // a split chip's entry is the total of ITS rows only: completed below
     }
     {
         // Row-range inputs: the running sum of a split chip (chip.rs:176-205) was scanned over each rank's own rows.  ONE exchange of the
@@ -518,7 +519,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         for (char sp : rk[0].split) any_split |= sp != 0;
         if (any_split) {
             std::vector<const uint32_t*> contrib;
-            for (auto& R : rk) contrib.push_back(R.words.data());
+            for (auto& R : rk) contrib.push_back(R.perm_totals.data());
             std::vector<uint32_t> all;
             f.all_gather(contrib, 5 * NC, all);
             for (auto& R : rk) {
@@ -550,7 +551,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 c.sync();  // offs_dev goes
             }
         }
-        for (auto& R : rk) R.words.clear();
+        for (auto& R : rk) R.perm_totals.clear();
     }
     {
         std::vector<std::vector<CommitIn>> cin((size_t)NH);
