@@ -529,15 +529,18 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         std::vector<uint32_t> pool;
         std::vector<size_t> off(NC);
         std::vector<uint32_t> Ks(NC);
+        // the powers of alpha ONCE for all chips (this loop sits between two kernels of a lone proof with the GPU idle: the per-chip
+        // recomputation cost 4x the products)
+        uint32_t maxK = 0;
+        for (size_t i = 0; i < NC; i++) maxK = std::max<uint32_t>(maxK, machine_.airs[i].program.num_asserts + (uint32_t)machine_.airs[i].interactions.size() + 3);
+        std::vector<Ext5> apow_all(maxK);
+        { Ext5 p = Ext5::one(); for (auto& e : apow_all) { e = p; p *= alpha; } }
         for (size_t i = 0; i < NC; i++) {
             auto& air = machine_.airs[i];
             uint32_t M = (uint32_t)air.interactions.size(), K = air.program.num_asserts + M + 3;
             Ks[i] = K;
             off[i] = pool.size();
-            std::vector<Ext5> ap(K);
-            Ext5 p = Ext5::one();
-            for (uint32_t k = 0; k < K; k++) { ap[K - 1 - k] = p; p *= alpha; }  // constraint k is scaled by alpha^(K-1-k)
-            for (auto& e : ap) put_ext(pool, e);
+            for (uint32_t k = 0; k < K; k++) put_ext(pool, apow_all[K - 1 - k]);  // constraint k is scaled by alpha^(K-1-k)
             for (auto& e : bus_alphas[i]) put_ext(pool, e);
             for (auto& e : betas[i]) put_ext(pool, e);
             put_ext(pool, cumulative_sums[i]);
@@ -678,6 +681,38 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     }
     PcsOpening res;
     auto t0 = Clock::now();
+    // The opening's first transcript step (TwoAdicFriPcs::open samples alpha before anything else, App. B9; the opened values are not
+    // observed): taken HERE, before the kernels of the opened values are even enqueued, so that everything of the reduced openings that does
+    // not depend on the values themselves — the powers of alpha, the offsets alpha^num_reduced, the point slots — is computed by the host
+    // WHILE the GPU evaluates the opened values instead of after their download with the GPU idle (a 0.13 ms gap of a lone proof).
+    const Ext5 alpha_b = ch.sample_ext();
+    struct MatEntry { const DMat* lde; std::vector<std::tuple<uint32_t, Ext5, Ext5>> pts; size_t r, i; };  // (slot, alpha^offset, Y)
+    struct Group { std::vector<Ext5> zs; std::map<PointKey, uint32_t> slot; std::vector<MatEntry> mats; uint64_t num_reduced = 0; };
+    std::map<unsigned, Group> groups;
+    std::vector<Ext5> apow;
+    auto prepare_groups = [&]() {  // everything but Y
+        size_t max_width = 0;
+        for (auto& r : rounds) for (auto& l : r.pd->ldes) max_width = std::max<size_t>(max_width, l.width);
+        apow.resize(max_width);
+        { Ext5 p = Ext5::one(); for (auto& a : apow) { a = p; p *= alpha_b; } }
+        for (size_t r = 0; r < NR; r++)
+            for (size_t i = 0; i < rounds[r].pd->ldes.size(); i++) {
+                const DMat& lde = rounds[r].pd->ldes[i];
+                unsigned lh = vg::log2_strict_u64(lde.height);
+                Group& g = groups[lh];
+                MatEntry me{&lde, {}, r, i};
+                for (size_t p = 0; p < rounds[r].points[i].size(); p++) {
+                    const Ext5& z = rounds[r].points[i][p];
+                    auto key = key_of(z);
+                    auto it = g.slot.find(key);
+                    uint32_t slot;
+                    if (it == g.slot.end()) { slot = (uint32_t)g.zs.size(); g.slot[key] = slot; g.zs.push_back(z); } else slot = it->second;
+                    me.pts.emplace_back(slot, alpha_b.pow(g.num_reduced), Ext5::zero());
+                    g.num_reduced += lde.width;
+                }
+                g.mats.push_back(std::move(me));
+            }
+    };
 
     // ---- opened values p_j(z) by barycentric evaluation over the first n rows of each bit-reversed LDE (App. B9)
     res.opened.resize(NR);
@@ -762,6 +797,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         }
         open_section.join();
         c.check_launch("opened values");
+        prepare_groups();  // host work beside the kernels just enqueued
         std::vector<uint32_t> out(out_words + 4);
         c.download_small(out.data(), out_dev.data, out_words * 4);  // through pinned memory
         for (auto& j : jobs)
@@ -772,37 +808,18 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
 
     // ---- reduced openings per LDE height (App. B9): ro[x] += alpha^offset * sum_j alpha^j (ys_j - row_j(x)) / (z - x)
     t0 = Clock::now();
-    const Ext5 alpha_b = ch.sample_ext();
     std::map<unsigned, DBuf> ro;  // log_height -> pair-layout vector
     unsigned log_max = 0;
     {
-        struct MatEntry { const DMat* lde; std::vector<std::tuple<uint32_t, Ext5, Ext5>> pts; };  // (slot, alpha^offset, Y)
-        struct Group { std::vector<Ext5> zs; std::map<PointKey, uint32_t> slot; std::vector<MatEntry> mats; uint64_t num_reduced = 0; };
-        std::map<unsigned, Group> groups;
-        size_t max_width = 0;
-        for (auto& r : rounds) for (auto& l : r.pd->ldes) max_width = std::max<size_t>(max_width, l.width);
-        std::vector<Ext5> apow(max_width);
-        { Ext5 p = Ext5::one(); for (auto& a : apow) { a = p; p *= alpha_b; } }
-        for (size_t r = 0; r < NR; r++)
-            for (size_t i = 0; i < rounds[r].pd->ldes.size(); i++) {
-                const DMat& lde = rounds[r].pd->ldes[i];
-                unsigned lh = vg::log2_strict_u64(lde.height);
-                Group& g = groups[lh];
-                MatEntry me{&lde, {}};
-                for (size_t p = 0; p < rounds[r].points[i].size(); p++) {
-                    const Ext5& z = rounds[r].points[i][p];
-                    auto key = key_of(z);
-                    auto it = g.slot.find(key);
-                    uint32_t slot;
-                    if (it == g.slot.end()) { slot = (uint32_t)g.zs.size(); g.slot[key] = slot; g.zs.push_back(z); } else slot = it->second;
+        // Y = sum_col alpha^col y_col per (matrix, point): the one part that needed the values
+        for (auto& kv : groups)
+            for (auto& me : kv.second.mats)
+                for (size_t p = 0; p < me.pts.size(); p++) {
                     Ext5 Y = Ext5::zero();
-                    auto& ys = res.opened[r][i][p];
+                    auto& ys = res.opened[me.r][me.i][p];
                     for (size_t col = 0; col < ys.size(); col++) Y += apow[col] * ys[col];
-                    me.pts.emplace_back(slot, alpha_b.pow(g.num_reduced), Y);
-                    g.num_reduced += lde.width;
+                    std::get<2>(me.pts[p]) = Y;
                 }
-                g.mats.push_back(std::move(me));
-            }
         // one descriptor per (height, chunk of <= MAX_OPEN_POINTS distinct points); later chunks accumulate into the vector
         struct Launch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; };
         std::vector<Launch> launches;
