@@ -61,6 +61,7 @@ uint32_t Prover::grind(Challenger& ch) {
 }
 Prover::~Prover() {
     if (cs_pinned_) (void)hipHostFree(cs_pinned_);
+    if (open_pinned_) (void)hipHostFree(open_pinned_);
     prog_dev_.clear();
     iw_dev_.clear();
     prep_pd_cache_.reset();
@@ -716,14 +717,16 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
 
     // ---- opened values p_j(z) by barycentric evaluation over the first n rows of each bit-reversed LDE (App. B9)
     res.opened.resize(NR);
+    struct Job { size_t r, i; int p0, np; uint64_t c0, cw; size_t w[2]; size_t scale_off, out_off; };
+    std::vector<Job> jobs;
+    size_t out_words = 0;
+    DBuf out_dev;             // the opened values, canonical words, as k_col_dot_finish leaves them
+    uint32_t* out_host = nullptr;  // their pinned landing area: read after the opening's one synchronisation (the end of the FRI commit phase)
     {
         std::map<std::pair<unsigned, PointKey>, size_t> wkey;  // distinct (log_n, point) -> weight vector
         struct WEntry { unsigned log_n; Ext5 z; size_t pool_off; DBuf buf; };
         std::vector<WEntry> wlist;
         std::vector<uint32_t> pool;
-        struct Job { size_t r, i; int p0, np; uint64_t c0, cw; size_t w[2]; size_t scale_off, out_off; };
-        std::vector<Job> jobs;
-        size_t out_words = 0;
         for (size_t r = 0; r < NR; r++) {
             res.opened[r].resize(rounds[r].pd->ldes.size());
             for (size_t i = 0; i < rounds[r].pd->ldes.size(); i++) {
@@ -783,7 +786,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                 // jobs_dev returns to the pool while the launch is queued: safe, the pool hands a block only to work enqueued later on this stream
             }
         }
-        DBuf out_dev(&c, out_words + 4);
+        out_dev = DBuf(&c, out_words + 4);
         std::vector<DBuf> partials;
         Section open_section(&c);
         size_t job_idx = 0;
@@ -797,12 +800,18 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         }
         open_section.join();
         c.check_launch("opened values");
+        // the values travel to the host BESIDE the reduced openings and the FRI commit phase (no synchronisation here: k_open_y below reads them
+        // on the device); a pinned area of this prover's own, the generic staging buffer is reused by the downloads that follow
+        {
+            std::lock_guard<std::recursive_mutex> lk(c.host_mu);
+            if (open_pinned_words_ < out_words + 4) {
+                if (open_pinned_) { VG_HIP_CHECK(hipStreamSynchronize(c.stream)); VG_HIP_CHECK(hipHostFree(open_pinned_)); open_pinned_ = nullptr; open_pinned_words_ = 0; }
+                VG_HIP_CHECK(hipHostMalloc((void**)&open_pinned_, (out_words + 4) * 4));
+                open_pinned_words_ = out_words + 4;
+            }
+            out_host = open_pinned_;
+        }
         prepare_groups();  // host work beside the kernels just enqueued
-        std::vector<uint32_t> out(out_words + 4);
-        c.download_small(out.data(), out_dev.data, out_words * 4);  // through pinned memory
-        for (auto& j : jobs)
-            for (uint64_t col = 0; col < j.cw; col++)
-                for (int p = 0; p < j.np; p++) res.opened[j.r][j.i][j.p0 + p][j.c0 + col] = ext_from_canonical(&out[j.out_off + (col * j.np + p) * 5]);
     }
     res.ms_values = ms_since(t0);
 
@@ -811,15 +820,10 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     std::map<unsigned, DBuf> ro;  // log_height -> pair-layout vector
     unsigned log_max = 0;
     {
-        // Y = sum_col alpha^col y_col per (matrix, point): the one part that needed the values
-        for (auto& kv : groups)
-            for (auto& me : kv.second.mats)
-                for (size_t p = 0; p < me.pts.size(); p++) {
-                    Ext5 Y = Ext5::zero();
-                    auto& ys = res.opened[me.r][me.i][p];
-                    for (size_t col = 0; col < ys.size(); col++) Y += apow[col] * ys[col];
-                    std::get<2>(me.pts[p]) = Y;
-                }
+        // Y = sum_col alpha^col y_col per (matrix, point) is the one part that needs the VALUES: its slot in the descriptors stays empty here and
+        // k_open_y fills it on the device (y_slots: where, and from which col_dot outputs)
+        struct YSlot { size_t pool_off, r, i, p; };
+        std::vector<YSlot> y_slots;
         // one descriptor per (height, chunk of <= MAX_OPEN_POINTS distinct points); later chunks accumulate into the vector
         struct Launch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; };
         std::vector<Launch> launches;
@@ -849,13 +853,43 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                     uint32_t cnt = 0;
                     for (auto& t : me->pts) cnt += std::get<0>(t) >= s0 && std::get<0>(t) < s1;
                     pool.push_back(cnt);
-                    for (auto& t : me->pts)
-                        if (std::get<0>(t) >= s0 && std::get<0>(t) < s1) { pool.push_back(std::get<0>(t) - s0); put_ext(pool, std::get<1>(t)); put_ext(pool, std::get<2>(t)); }
+                    for (size_t pi = 0; pi < me->pts.size(); pi++) {
+                        auto& t = me->pts[pi];
+                        if (std::get<0>(t) >= s0 && std::get<0>(t) < s1) {
+                            pool.push_back(std::get<0>(t) - s0);
+                            put_ext(pool, std::get<1>(t));
+                            y_slots.push_back({pool.size(), me->r, me->i, pi});
+                            put_ext(pool, Ext5::zero());  // Y: written by k_open_y
+                        }
+                    }
                 }
                 if (g.zs.size() <= s1) break;
             }
         }
+        // Y of every (matrix, point), on the device: its tables ride in the same upload as the reduce descriptors (one host-to-device copy in the
+        // dependent chain, not four)
+        const size_t apw_at = pool.size();
+        for (auto& a : apow) put_ext(pool, a);
+        std::vector<uint32_t> ydesc, yoff;
+        for (auto& ys : y_slots) {
+            yoff.push_back((uint32_t)ydesc.size());
+            ydesc.push_back((uint32_t)ys.pool_off);
+            const size_t n_seg_at = ydesc.size();
+            ydesc.push_back(0);
+            for (auto& j : jobs)
+                if (j.r == ys.r && j.i == ys.i && (size_t)j.p0 <= ys.p && ys.p < (size_t)(j.p0 + j.np)) {
+                    ydesc.push_back((uint32_t)j.out_off); ydesc.push_back((uint32_t)j.np); ydesc.push_back((uint32_t)(ys.p - (size_t)j.p0));
+                    ydesc.push_back((uint32_t)j.c0); ydesc.push_back((uint32_t)j.cw);
+                    ydesc[n_seg_at]++;
+                }
+        }
+        const size_t ydesc_at = pool.size();
+        pool.insert(pool.end(), ydesc.begin(), ydesc.end());
+        const size_t yoff_at = pool.size();
+        pool.insert(pool.end(), yoff.begin(), yoff.end());
+        pool.push_back(0);
         DBuf pool_dev(&c, pool);
+        vk::launch_open_y(c.stream, out_dev.data, pool_dev.data + apw_at, pool_dev.data + ydesc_at, pool_dev.data + yoff_at, (uint32_t)y_slots.size(), pool_dev.data);
         for (auto& kv : groups) { ro[kv.first] = DBuf(&c, (size_t)(5ull << kv.first)); log_max = std::max(log_max, kv.first); }
         Section reduce_section(&c);
         std::map<unsigned, hipStream_t> stream_of;  // chunks of one height must stay on one stream (they accumulate in order)
@@ -867,6 +901,8 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         }
         reduce_section.join();
         c.check_launch("reduce openings");
+        // the opened values travel to the host from here on, behind the last kernel that reads them and beside the FRI commit phase
+        if (out_words) VG_HIP_CHECK(hipMemcpyAsync(out_host, out_dev.data, out_words * 4, hipMemcpyDeviceToHost, c.stream));
     }
     res.ms_reduce = ms_since(t0);
     if (log_max < lb + 0u) throw std::invalid_argument("open: nothing to open");
@@ -916,6 +952,15 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         memcpy(commits.data(), pin + n0, n1 * 4);
         memcpy(fin.data(), pin + n0 + n1, n2 * 4);
     }
+    // the opened values arrived long ago (same stream): into the result (one streaming copy out of the pinned area first)
+    {
+        std::vector<uint32_t> out(out_words + 4);
+        if (out_words) memcpy(out.data(), out_host, out_words * 4);
+        for (auto& j : jobs)
+            for (uint64_t col = 0; col < j.cw; col++)
+                for (int p = 0; p < j.np; p++) res.opened[j.r][j.i][j.p0 + p][j.c0 + col] = ext_from_canonical(&out[j.out_off + (col * j.np + p) * 5]);
+    }
+    out_dev = DBuf();
     for (int i = 0; i < 16; i++) ch.state[i] = Fp::raw(chw[i]);
     ch.in.clear();
     for (uint32_t i = 0; i < chw[32]; i++) ch.in.push_back(Fp::raw(chw[16 + i]));

@@ -139,6 +139,8 @@ class Prover {
     DBuf pow_pos_;                         // [480 rc][16 mds coefficients][16 state][1 best] for k_pow_grind
     static constexpr size_t CS_PINNED_WORDS = 5 * 256;
     uint32_t* cs_pinned_ = nullptr;        // pinned landing area of the chips' cumulative sums (asynchronous D2H inside prove)
+    uint32_t* open_pinned_ = nullptr;      // pinned landing area of an opening's values (asynchronous D2H beside the reduced openings / FRI); one opening at a time per prover
+    size_t open_pinned_words_ = 0;
     uint32_t grind(Challenger& ch);
     void fill_quotient_args(vk::QuotientArgs& a, int chip, vk::DMatView main_lde, vk::DMatView perm_lde, vk::DMatView prep_lde, unsigned log_n, const uint32_t* consts_dev);
 };

@@ -133,6 +133,8 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
 // accumulate: add to the vector already in `out` (a height with more than MAX_OPEN_POINTS_PER_LAUNCH distinct opening points is
 // reduced in several launches)
 constexpr int MAX_OPEN_POINTS_PER_LAUNCH = 4;
+// Y of every (matrix, point) written into the reduce descriptors on the device (open.hip, k_open_y)
+void launch_open_y(hipStream_t st, const uint32_t* vals_dev, const uint32_t* apow_dev, const uint32_t* desc_dev, const uint32_t* entry_off_dev, uint32_t n_entries, uint32_t* pool_dev);
 void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width,
                             bool accumulate = false);
 // beta5_dev: the folding challenge as 5 Montgomery words in device memory (written by k_fri_challenge)

@@ -529,6 +529,41 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
     else VK_LAUNCH(k_col_dot<2>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
     VK_LAUNCH(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
 }
+// ---- Y = sum_col alpha^col y_col of every (matrix, point) of an opening, on the device (round 4) --------------------------------------
+// k_reduce_openings needs, per (matrix, point), the alpha-weighted sum of the OPENED VALUES of that matrix at that point.  The host used to
+// form it from the downloaded values — the one thing that tied the reduced openings to a host round trip.  One wave per (matrix, point) reads
+// the values where k_col_dot_finish left them (canonical words), weighs them and writes the sum (Montgomery) into its slot of the reduce
+// descriptors: col_dot -> this -> k_reduce_openings run back to back, the values travel to the host beside them.
+// desc: per entry at entry_off[e]: [word offset of Y in `pool`] [n_seg] then n_seg x { out_off, np, p_local, c0, cw }: the values of columns
+// c0 .. c0 + cw of the matrix at this point sit at vals[out_off + (col * np + p_local) * 5 ..].  apow: alpha^c, 5 words each.
+__global__ void __launch_bounds__(64) k_open_y(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ apow, const uint32_t* __restrict__ desc,
+                                              const uint32_t* __restrict__ entry_off, uint32_t* __restrict__ pool) {
+    const uint32_t* d = desc + entry_off[blockIdx.x];
+    const uint32_t y_dst = d[0], n_seg = d[1];
+    Ext5 acc = Ext5::zero();
+    for (uint32_t sgi = 0; sgi < n_seg; sgi++) {
+        const uint32_t* sg = d + 2 + 5 * sgi;
+        const uint32_t out_off = sg[0], np = sg[1], pl = sg[2], c0 = sg[3], cw = sg[4];
+        for (uint32_t col = threadIdx.x; col < cw; col += 64) {
+            const uint32_t* v = vals + out_off + (col * np + pl) * 5;
+            Ext5 y;
+#pragma unroll
+            for (int k = 0; k < 5; k++) y.c[k] = Fp::from_canonical(v[k]);
+            acc += ext_from_words(apow + 5 * (c0 + col)) * y;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) acc.c[k] = wave_sum(acc.c[k]);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) pool[y_dst + k] = acc.c[k].v;
+    }
+}
+void launch_open_y(hipStream_t st, const uint32_t* vals_dev, const uint32_t* apow_dev, const uint32_t* desc_dev, const uint32_t* entry_off_dev, uint32_t n_entries, uint32_t* pool_dev) {
+    if (!n_entries) return;
+    ProfScope ps("k_open_y", st, 0.0);
+    VK_LAUNCH(k_open_y, dim3(n_entries), dim3(64), 0, st, vals_dev, apow_dev, desc_dev, entry_off_dev, pool_dev);
+}
 void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width, bool accumulate) {
     ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + (accumulate ? 10.0 : 5.0)));
     VK_LAUNCH(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out, accumulate ? 1 : 0);
