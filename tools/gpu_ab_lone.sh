@@ -4,8 +4,8 @@
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$1; mkdir -p "$OUT"; export TMPDIR=/tmp
 for i in $(seq 1 ${3:-5}); do
-  python bench.py --no-cpu-baseline --no-extra-legs --inflight 1 > "$OUT/a_$i.json" 2>/dev/null
-  VGPU_LIB_PATH=$ROOT/$2 python bench.py --no-cpu-baseline --no-extra-legs --inflight 1 > "$OUT/b_$i.json" 2>/dev/null
+  python bench.py --no-cpu-baseline --no-extra-legs --inflight 1 --steps ${STEPS:-12} > "$OUT/a_$i.json" 2>/dev/null
+  VGPU_LIB_PATH=$ROOT/$2 python bench.py --no-cpu-baseline --no-extra-legs --inflight 1 --steps ${STEPS:-12} > "$OUT/b_$i.json" 2>/dev/null
 done
 python - "$OUT" ${3:-5} <<'P'
 import json, sys

@@ -939,6 +939,71 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         cur = std::move(next);
     }
     c.check_launch("fri fold");
+    // ---- the query openings' TEMPLATE, built and uploaded while the GPU runs the commit phase just enqueued: every descriptor of the gather
+    // except the query index, and every word of the proof tail the host writes itself (the data-dependent ones — roots, final polynomial, witness —
+    // as placeholders).  After the indices are sampled only they travel (k_gather_q).
+    const size_t NQ = fri_.num_queries, NL = layer_trees.size();
+    if (NQ > 256) throw std::invalid_argument("open: at most 256 queries");
+    std::vector<uint32_t> templ;
+    std::vector<std::pair<uint32_t, uint32_t>> fix;  // (position in the tail, value) of the words the host writes
+    size_t fix_roots_at = 0, fix_final_at = 0;
+    uint32_t tail_pos = 0;
+    {
+        size_t n_desc = 0, n_fix = 8 * NL + 16;
+        for (size_t l = 0; l < NL; l++) n_desc += 1 + layer_trees[l].log_max_height;
+        for (size_t r = 0; r < NR; r++) n_desc += rounds[r].pd->ldes.size() + rounds[r].pd->tree.log_max_height;
+        n_desc *= NQ;
+        n_fix += NQ * (2 + 2 * NL + NR * 2);
+        for (size_t r = 0; r < NR; r++) n_fix += NQ * rounds[r].pd->ldes.size();
+        templ.reserve(8 * n_desc + 8);
+        fix.reserve(n_fix);
+        uint32_t& pos = tail_pos;
+        auto host_word = [&](uint32_t v) { fix.emplace_back(pos++, v); };
+        auto gather = [&](const uint32_t* base, uint64_t stride, uint32_t count, uint32_t kind, size_t q, uint32_t mode, uint32_t shift, uint32_t aux) {
+            const uint64_t pv = (uint64_t)base;
+            const uint32_t d8[8] = {(uint32_t)pv, (uint32_t)(pv >> 32), (uint32_t)stride, (uint32_t)(stride >> 32), count | (kind << 28), pos, (uint32_t)q | (mode << 8) | (shift << 16), aux};
+            templ.insert(templ.end(), d8, d8 + 8);
+            pos += count;
+        };
+        // the path of leaf (index >> shift0) in tree t: level l's sibling is ((index >> shift0) >> l) ^ 1
+        auto gather_path = [&](const DeviceTree& t, size_t q, uint32_t shift0) {
+            host_word(t.log_max_height);
+            for (unsigned l = 0; l < t.log_max_height; l++) gather(t.layers[l].data, 1, 8, 1, q, 1, shift0 + l, 0);
+        };
+        host_word((uint32_t)NL);
+        fix_roots_at = fix.size();
+        for (size_t l = 0; l < NL; l++) for (int w = 0; w < 8; w++) host_word(0);  // the commit-phase roots: filled in after the synchronisation
+        host_word((uint32_t)NQ);
+        for (size_t q = 0; q < NQ; q++) {
+            host_word((uint32_t)NL);
+            for (size_t l = 0; l < NL; l++) {
+                // idx_i = index >> l, sibling value at pair idx_i >> 1 of the half the bit idx_i & 1 does NOT select (pair layout, 5 limbs `half` apart)
+                const uint64_t half = 1ull << (log_max - 1 - l);
+                gather(layer_bufs[l].data, half, 5, 0, q, 2, (uint32_t)l, (uint32_t)(5 * half));
+                gather_path(layer_trees[l], q, (uint32_t)l + 1);
+            }
+        }
+        fix_final_at = fix.size();
+        for (int k = 0; k < 6; k++) host_word(0);  // final polynomial (5) and proof-of-work witness: filled in later
+        host_word((uint32_t)NQ);
+        for (size_t q = 0; q < NQ; q++) {
+            host_word((uint32_t)NR);
+            for (size_t r = 0; r < NR; r++) {
+                const DeviceTree& t = rounds[r].pd->tree;
+                const uint32_t shift_r = log_max - t.log_max_height;  // idx_r = index >> shift_r
+                host_word((uint32_t)rounds[r].pd->ldes.size());
+                for (auto& lde : rounds[r].pd->ldes) {
+                    const unsigned lh = vg::log2_strict_u64(lde.height);
+                    host_word((uint32_t)lde.width);
+                    gather(lde.data, lde.height, (uint32_t)lde.width, 0, q, 0, shift_r + (t.log_max_height - lh), 0);
+                }
+                gather_path(t, q, shift_r);
+            }
+        }
+    }
+    const size_t tail_words = tail_pos;
+    templ.push_back(0);
+    DBuf templ_dev(&c, templ), gout(&c, tail_words + 4);  // the upload is enqueued behind the commit phase; nothing waits for it until the gather
     // `cur` now holds 2^lb values that must all be equal (a constant polynomial)
     std::vector<uint32_t> fin(5ull << lb), commits(8 * n_layers + 8);
     {   // sponge state, roots and final values: three copies into one pinned area, one synchronisation
@@ -990,64 +1055,13 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     // values it already holds (commit-phase roots, final polynomial, proof-of-work witness).  One flat descriptor array, sized up
     // front: building it is the only host work between the last FRI kernel and the gather.
     t0 = Clock::now();
-    std::vector<uint64_t> indices(fri_.num_queries);
-    for (auto& ix : indices) ix = ch.sample_bits(log_max);
-    const size_t NQ = indices.size(), NL = layer_trees.size();
-    size_t n_desc = 0, n_fix = 8 * NL + 16;
-    for (size_t l = 0; l < NL; l++) n_desc += 1 + layer_trees[l].log_max_height;
-    for (size_t r = 0; r < NR; r++) n_desc += rounds[r].pd->ldes.size() + rounds[r].pd->tree.log_max_height;
-    n_desc *= NQ;
-    n_fix += NQ * (2 + 2 * NL + NR * 2);
-    for (size_t r = 0; r < NR; r++) n_fix += NQ * rounds[r].pd->ldes.size();
-    std::vector<uint32_t> desc;
-    desc.reserve(6 * n_desc + 8);
-    std::vector<std::pair<uint32_t, uint32_t>> fix;  // (position in the tail, value) of the words the host writes
-    fix.reserve(n_fix);
-    uint32_t pos = 0;
-    auto host_word = [&](uint32_t v) { fix.emplace_back(pos++, v); };
-    auto gather = [&](const uint32_t* src, uint64_t stride, uint32_t count, uint32_t kind) {
-        const uint64_t pv = (uint64_t)src;
-        const uint32_t d6[6] = {(uint32_t)pv, (uint32_t)(pv >> 32), (uint32_t)stride, (uint32_t)(stride >> 32), count | (kind << 28), pos};
-        desc.insert(desc.end(), d6, d6 + 6);
-        pos += count;
-    };
-    auto gather_path = [&](const DeviceTree& t, uint64_t idx) {
-        host_word(t.log_max_height);
-        for (unsigned l = 0; l < t.log_max_height; l++) gather(t.layers[l].data + 8 * ((idx >> l) ^ 1), 1, 8, 1);
-    };
-    host_word((uint32_t)commit_phase_commits.size());
-    for (auto& r : commit_phase_commits) for (uint32_t w : r) host_word(w);
-    host_word((uint32_t)NQ);
-    for (size_t q = 0; q < NQ; q++) {
-        const uint64_t index = indices[q];
-        host_word((uint32_t)NL);
-        for (size_t l = 0; l < NL; l++) {
-            const uint64_t idx_i = index >> l, sib = idx_i ^ 1, pair = idx_i >> 1, half = 1ull << (log_max - 1 - l);
-            gather(layer_bufs[l].data + (5 * (sib & 1)) * half + pair, half, 5, 0);
-            gather_path(layer_trees[l], pair);
-        }
-    }
-    for (int k = 0; k < 5; k++) host_word(fpw[k]);
-    host_word(pow_witness);
-    host_word((uint32_t)NQ);
-    for (size_t q = 0; q < NQ; q++) {
-        const uint64_t index = indices[q];
-        host_word((uint32_t)NR);
-        for (size_t r = 0; r < NR; r++) {
-            const DeviceTree& t = rounds[r].pd->tree;
-            const uint64_t idx_r = index >> (log_max - t.log_max_height);
-            host_word((uint32_t)rounds[r].pd->ldes.size());
-            for (auto& lde : rounds[r].pd->ldes) {
-                const unsigned lh = vg::log2_strict_u64(lde.height);
-                host_word((uint32_t)lde.width);
-                gather(lde.data + (idx_r >> (t.log_max_height - lh)), lde.height, (uint32_t)lde.width, 0);
-            }
-            gather_path(t, idx_r);
-        }
-    }
-    const size_t tail_words = pos;
-    DBuf gd(&c, desc), gout(&c, tail_words + 4);
-    vk::launch_gather(c.stream, gd.data, desc.size() / 6, gout.data);
+    std::vector<uint32_t> indices(NQ + 1, 0);
+    for (size_t q = 0; q < NQ; q++) indices[q] = (uint32_t)ch.sample_bits(log_max);
+    for (size_t l = 0; l < NL; l++) for (int w = 0; w < 8; w++) fix[fix_roots_at + 8 * l + w].second = commit_phase_commits[l][w];
+    for (int k = 0; k < 5; k++) fix[fix_final_at + k].second = fpw[k];
+    fix[fix_final_at + 5].second = pow_witness;
+    DBuf idx_dev(&c, indices);
+    vk::launch_gather_q(c.stream, templ_dev.data, (templ.size() - 1) / 8, idx_dev.data, gout.data);
     c.check_launch("query gather");
     res.proof_words.resize(tail_words);
     c.download_small(res.proof_words.data(), gout.data, tail_words * 4);  // through pinned memory

@@ -145,5 +145,7 @@ constexpr int DEV_CHALLENGER_WORDS = 50;
 void launch_fri_challenge(hipStream_t st, const uint32_t* pos_dev, uint32_t* ch_dev, const uint32_t* digest8_dev, uint32_t* beta5_dev, uint32_t* commit8_dev);
 void launch_pow_grind(hipStream_t st, const uint32_t* pos_dev, bool sparse, uint32_t k_pending, uint32_t first, uint32_t count, uint32_t bits, uint32_t* best_dev);
 void launch_gather(hipStream_t st, const uint32_t* desc_dev, uint64_t n_desc, uint32_t* dst);
+// the same from 8-word templates and the query indices (<= 256 queries: the query id is a byte) — open.hip, k_gather_q
+void launch_gather_q(hipStream_t st, const uint32_t* templ_dev, uint64_t n_desc, const uint32_t* indices_dev, uint32_t* dst);
 
 }  // namespace vk

@@ -449,6 +449,35 @@ __global__ void k_gather(const uint32_t* __restrict__ desc, uint64_t n_desc, uin
     }
 }
 
+// The query openings from a TEMPLATE (round 4): everything of a gather descriptor except the query index is known before the FRI commit
+// phase has finished, so the host builds and uploads the template while the GPU runs that phase and ships only the sampled indices afterwards
+// (16 000 descriptors of a C2 proof used to be built between the proof-of-work search and the gather, with the GPU idle).
+// Template = 8 words: [base_lo] [base_hi] [stride_lo] [stride_hi] [count | kind << 28] [dst offset] [query | mode << 8 | shift << 16] [aux]
+//   mode 0: src = base + (index >> shift)                                     a committed row (count = width, stride = LDE height)
+//   mode 1: src = base + 8 * ((index >> shift) ^ 1)                           the sibling digest of a Merkle path level
+//   mode 2: src = base + (index >> (shift + 1)) + (bit shift of index set ? 0 : aux)   the sibling VALUE of a FRI layer in pair layout (aux = 5 * half)
+__global__ void k_gather_q(const uint32_t* __restrict__ templ, uint64_t n_desc, const uint32_t* __restrict__ indices, uint32_t* __restrict__ dst) {
+    uint64_t d = (uint64_t)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);  // 32 lanes per descriptor
+    if (d >= n_desc) return;
+    const uint32_t* e = templ + 8 * d;
+    const uint32_t* base = reinterpret_cast<const uint32_t*>(((uint64_t)e[1] << 32) | e[0]);
+    const uint64_t stride = ((uint64_t)e[3] << 32) | e[2];
+    const uint32_t count = e[4] & 0x0fffffffu, kind = e[4] >> 28;
+    const uint32_t q = e[6] & 0xffu, mode = (e[6] >> 8) & 0xffu, shift = e[6] >> 16;
+    const uint64_t index = indices[q];
+    const uint32_t* src = mode == 0 ? base + (index >> shift) : mode == 1 ? base + 8 * ((index >> shift) ^ 1) : base + (index >> (shift + 1)) + (((index >> shift) & 1) ? 0u : e[7]);
+    uint32_t* o = dst + e[5];
+    for (uint32_t k = threadIdx.x & 31; k < count; k += 32) {
+        uint32_t v = src[(uint64_t)k * stride];
+        o[k] = kind == 0 ? Fp::raw(v).canonical() : v;
+    }
+}
+void launch_gather_q(hipStream_t st, const uint32_t* templ_dev, uint64_t n_desc, const uint32_t* indices_dev, uint32_t* dst) {
+    if (!n_desc) return;
+    ProfScope ps("k_gather", st, 0.0);
+    VK_LAUNCH(k_gather_q, dim3((unsigned)((n_desc + 7) / 8)), dim3(256), 0, st, templ_dev, n_desc, indices_dev, dst);
+}
+
 // ---- Fiat-Shamir on the device for the FRI commit phase: challenger_dev.hpp (the step itself), as a launch of its own here
 __global__ void __launch_bounds__(64) k_fri_challenge(const uint32_t* __restrict__ pos, uint32_t* __restrict__ ch, const uint32_t* __restrict__ digest8,
                                                       uint32_t* __restrict__ beta5, uint32_t* __restrict__ commit8) {
