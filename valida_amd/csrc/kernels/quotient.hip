@@ -504,9 +504,10 @@ void launch_quotient(hipStream_t st, const QuotientArgs& a_in, const DeviceTable
     static const char* names[16] = {"k_quotient.cpu", "k_quotient.program", "k_quotient.mem", "k_quotient.add", "k_quotient.sub", "k_quotient.mul", "k_quotient.div",
                                     "k_quotient.shift", "k_quotient.lt", "k_quotient.com", "k_quotient.bitwise", "k_quotient.output", "k_quotient.range",
                                     "k_quotient.static_data", "k_quotient", "k_quotient"};
-    const char* pname = getenv("VGPU_PROF_QUOTIENT_BY_CHIP") && a.native_chip >= 0 && a.native_chip < 14 ? names[a.native_chip] : "k_quotient";
-    ProfScope ps(pname, st, 4.0 * n * (2.0 * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 10.0));
     static const bool per_point = [] { const char* e = getenv("VGPU_QUOT_PER_POINT"); return !(e && e[0] == '0'); }();
+    const char* pname = getenv("VGPU_PROF_QUOTIENT_BY_CHIP") && a.native_chip >= 0 && a.native_chip < 14 ? names[a.native_chip]
+                        : (per_point && a.native_chip != QuotientArgs::INTERPRET ? "k_quotient_pt" : "k_quotient");  // rocprof's kernel names
+    ProfScope ps(pname, st, 4.0 * n * (2.0 * (a.main_lde.width + a.perm_lde.width + a.prep_lde.width) + 10.0));
     if (a.native_chip != QuotientArgs::INTERPRET && per_point) {
         // thread per point, 512 threads = 256 pairs per workgroup (k_quotient_pt)
         const dim3 grid((unsigned)((n + 255) / 256)), block(512);
