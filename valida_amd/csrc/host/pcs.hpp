@@ -95,37 +95,56 @@ struct DeviceTree {
         layer_len.push_back(maxh);
         const bool pos = c->hash_kind == 1;
         const uint32_t* tab = c->poseidon_tab;
-        bool leaves_in_top = false;
+        bool leaves_in_top = false, leaves_in_mid = false;
         if (pos) {
             if (single) vk::launch_poseidon_leaves_strided(c->stream, tab, c->poseidon_sparse, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
             else vk::launch_poseidon_leaves(c->stream, tab, c->poseidon_sparse, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         } else if (single && vk::keccak_top_takes_leaves(maxh)) leaves_in_top = true;  // the small FRI layers: leaves, levels and challenger step in ONE launch
+        else if (single && maxh / 2 > TOP_FIRST_LEN && vk::keccak_levels_take_leaves(maxh)) leaves_in_mid = true;  // the middle FRI layers: leaves + the layers down to 512 parents
         else if (single) vk::launch_keccak_leaves_strided(c->stream, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
         else vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
-        vk::KeccakTopArgs top{};
+        // mid: the consecutive layers of 256 < parents <= 32768 (at most seven) as ONE launch of 64-parent workgroups; top: the rest in one workgroup
+        vk::KeccakTopArgs top{}, mid{};
+        auto add_level = [&](vk::KeccakTopArgs& g, uint64_t len, const Group* inj) {
+            if (g.levels == 0) { g.prev = layers[layers.size() - 2].data; g.first_len = len; }
+            g.out[g.levels] = layers.back().data;
+            g.cols[g.levels] = inj ? pd + inj->first : nullptr;
+            g.n_elems[g.levels] = inj ? (int)inj->count : 0;
+            g.levels++;
+        };
+        auto flush_mid = [&] {
+            if (!mid.levels) return;
+            mid.block_len = vk::KECCAK_LEVELS_BLOCK_LEN;
+            if (leaves_in_mid) {
+                if (mid.prev != layers[0].data) throw std::logic_error("mmcs: leaf prologue without a launch over the leaf layer");
+                mid.leaf_base = single_view->data; mid.leaf_stride = single_view->stride; mid.leaf_elems = (int)single_view->width; mid.leaf_rows = maxh;
+            }
+            vk::launch_keccak_levels(c->stream, mid);
+            mid.levels = 0;
+        };
         for (uint64_t len = maxh / 2; len >= 1; len /= 2) {
             layers.emplace_back(c, (size_t)len * 8);
             layer_len.push_back(len);
             const Group* inj = (gi < groups.size() && groups[gi].height == len) ? &groups[gi] : nullptr;
             if (inj && before_injection_) { (*before_injection_)(); before_injection_ = nullptr; }
-            // Layers of more than TOP_FIRST_LEN parents are their own launches (spread over the whole GPU); the rest of the tree is one
+            // Layers of more than TOP_FIRST_LEN parents are spread over the whole GPU (the big ones a launch each); the rest of the tree is one
             // single-workgroup launch.  256, not the 1024 a workgroup could take: inside one workgroup a 1024-parent layer puts four
             // waves on each SIMD of ONE CU and costs 27 us (512 parents: 15 us), as a launch of its own across the CUs 9 + 2 us.
             if (len > TOP_FIRST_LEN) {
                 if (pos) vk::launch_poseidon_compress(c->stream, tab, c->poseidon_sparse, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
+                else if (vk::keccak_levels_fused(len)) add_level(mid, len, inj);
                 else vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
                                                 layers.back().data);
             } else {  // the last <= 9 layers go into one launch
-                if (top.levels == 0) { top.prev = layers[layers.size() - 2].data; top.first_len = len; }
-                top.out[top.levels] = layers.back().data;
-                top.cols[top.levels] = inj ? pd + inj->first : nullptr;
-                top.n_elems[top.levels] = inj ? (int)inj->count : 0;
-                top.levels++;
+                flush_mid();
+                add_level(top, len, inj);
             }
             if (inj) gi++;
             if (len == 1) break;
         }
+        flush_mid();
+        if (leaves_in_mid && layers.size() < 2) throw std::logic_error("mmcs: leaf prologue on a tree without parents");
         if (leaves_in_top) {
             if (!top.levels || top.prev != layers[0].data) throw std::logic_error("mmcs: leaf prologue without a top launch over the leaf layer");
             top.leaf_base = single_view->data; top.leaf_stride = single_view->stride; top.leaf_elems = (int)single_view->width; top.leaf_rows = maxh;

@@ -76,12 +76,23 @@ struct KeccakTopArgs {
     uint64_t leaf_stride = 0;
     int leaf_elems = 0;
     uint64_t leaf_rows = 0;  // 0: none; else 2 * first_len
+    // launch_keccak_levels only: parents of the first layer per WORKGROUP (a power of two <= 256 dividing first_len; the grid is
+    // first_len / block_len workgroups, each walks its own sub-tree `levels` <= log2(block_len) + 1 layers down).  0: first_len (one workgroup)
+    uint64_t block_len = 0;
     const uint32_t* ch_pos = nullptr;
     uint32_t* ch_state = nullptr;
     uint32_t* ch_beta5 = nullptr;
     uint32_t* ch_commit8 = nullptr;
 };
 void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a);
+// Several consecutive layers of the latency-bound middle of a tree (256 < parents <= 32768) in ONE launch: a workgroup per 64 parents of the
+// first layer, the digests handed from layer to layer through LDS (merkle.hip: k_keccak_levels_pair).  keccak_levels_fused(len): whether a
+// layer of `len` parents may go into such a launch (lane-pair kernels on, VGPU_KECCAK_LEVELS != 0); keccak_levels_take_leaves(n_rows):
+// whether the launch can also hash the leaves of a single strided matrix of n_rows rows itself (KeccakTopArgs::leaf_*).
+constexpr uint64_t KECCAK_LEVELS_BLOCK_LEN = 64;
+void launch_keccak_levels(hipStream_t st, const KeccakTopArgs& a);
+bool keccak_levels_fused(uint64_t len);
+bool keccak_levels_take_leaves(uint64_t n_rows);
 bool keccak_top_takes_leaves(uint64_t n_rows);  // whether launch_keccak_top can hash the leaves of a tree of n_rows rows itself (KeccakTopArgs::leaf_*)
 // poseidon_mmcs.hip — the same tree with PaddingFreeSponge / TruncatedPermutation over Poseidon-16 (hash kind 1).
 // pos_dev: [480 round constants][16 circulant MDS coefficients], Montgomery (the table the device challenger uses)

@@ -206,6 +206,60 @@ __global__ void __launch_bounds__(1024) k_keccak_top_pair(KeccakTopArgs a) {
     if (a.ch_pos && threadIdx.x < 64) fri_challenge_step((int)threadIdx.x, a.ch_pos, a.ch_state, prev, a.ch_beta5, a.ch_commit8);
 }
 
+// Several layers per launch with the digests handed from layer to layer through LDS (the single-workgroup top of every tree, and the
+// latency-bound middle: one workgroup per block_len parents of the first layer, each walking its own sub-tree down).  Against
+// k_keccak_top_pair / one k_keccak_compress_pair launch per layer: a layer boundary costs an LDS write, `s_waitcnt lgkmcnt(0); s_barrier`
+// and an LDS read instead of global stores drained to L2 + a barrier + global loads (top) or a kernel boundary (middle).  Every digest is
+// still written to its layer in HBM — the openings read them — but nothing waits for those stores before the kernel ends.
+// LDS: X (512 digests: the leaves of the prologue, then the outputs of the odd layers) and Y (256 digests: the outputs of the even layers).
+constexpr int LEVELS_LDS_X = 512, LEVELS_LDS_Y = 256;
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ void __launch_bounds__(1024) k_keccak_levels_pair(KeccakTopArgs a) {
+    __shared__ uint32_t lds[(LEVELS_LDS_X + LEVELS_LDS_Y) * 8];
+    const int h = (int)(threadIdx.x & 1);
+    const uint32_t t = threadIdx.x >> 1;
+    const uint64_t b0 = a.block_len, first = (uint64_t)blockIdx.x * b0;  // this workgroup: parents first .. first + b0 - 1 of the first layer
+    bool in_lds = false;
+    if (a.leaf_rows) {  // the leaves of a single strided matrix: rows 2 * first .. 2 * (first + b0) - 1, one per lane pair
+        if (t < 2 * b0) {
+            uint32_t d[4];
+            const uint64_t row = 2 * first + t;
+            hash_row_pair(StridedCols{a.leaf_base, a.leaf_stride}, a.leaf_elems, row, h, d);
+            store_digest_half(const_cast<uint32_t*>(a.prev) + 8 * row, h, d);
+            store_digest_half(lds + 8 * t, h, d);
+        }
+        lds_barrier();
+        in_lds = true;
+    }
+    for (int l = 0; l < a.levels; l++) {
+        const uint32_t* in = lds + ((l & 1) ? LEVELS_LDS_X * 8 : 0);
+        uint32_t* out = lds + ((l & 1) ? 0 : LEVELS_LDS_X * 8);
+        if (t < (b0 >> l)) {
+            const uint64_t i = (first >> l) + t;
+            uint32_t lf[4], rg[4], d[4];
+            if (in_lds) { load_digest_half(in + 16 * t, h, lf); load_digest_half(in + 16 * t + 8, h, rg); }
+            else { load_digest_half(a.prev + 16 * i, h, lf); load_digest_half(a.prev + 16 * i + 8, h, rg); }
+            compress2_pair(lf, rg, h, d);
+            if (a.n_elems[l] > 0) {
+                uint32_t hr[4], d2[4];
+                hash_row_pair(PtrCols{a.cols[l]}, a.n_elems[l], i, h, hr);
+                compress2_pair(d, hr, h, d2);
+#pragma unroll
+                for (int k = 0; k < 4; k++) d[k] = d2[k];
+            }
+            store_digest_half(a.out[l] + 8 * i, h, d);
+            store_digest_half(out + 8 * t, h, d);
+        }
+        in_lds = true;
+        if (l + 1 < a.levels) lds_barrier();
+    }
+    if (a.ch_pos) {  // one workgroup (the top of a FRI layer tree): the root it has just written, read back from memory by the first wave
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x < 64) fri_challenge_step((int)threadIdx.x, a.ch_pos, a.ch_state, a.out[a.levels - 1], a.ch_beta5, a.ch_commit8);
+    }
+}
+
 // Top of a tree in ONE launch: a single 1024-thread workgroup walks the last `levels` layers
 // (first_len <= 1024 parents down to the root), one barrier per layer, instead of one ~10 us launch per
 // layer — there are ~25 trees per proof (3 commitment rounds + one per FRI layer).
@@ -250,6 +304,35 @@ static double row_perms(int n_elems) { return (double)(n_elems / 34 + 1); }
 static double node_perms(int n_inject) { return n_inject > 0 ? 2.0 + row_perms(n_inject) : 1.0; }
 
 bool keccak_top_takes_leaves(uint64_t n_rows) { return keccak_pairs_enabled() && n_rows >= 2 && n_rows <= 512; }  // 2 threads per row, first_len = n_rows / 2 <= 256
+// VGPU_KECCAK_LEVELS=0: the round-3 launches (k_keccak_top_pair with its layers through HBM, one k_keccak_compress_pair launch per middle layer)
+static bool keccak_levels_enabled() {
+    static const bool on = [] { const char* e = getenv("VGPU_KECCAK_LEVELS"); return !(e && e[0] == '0'); }();
+    return on && keccak_pairs_enabled();
+}
+bool keccak_levels_fused(uint64_t len) { return keccak_levels_enabled() && len >= KECCAK_LEVELS_BLOCK_LEN && len <= KECCAK_PAIR_MAX_NODES; }
+bool keccak_levels_take_leaves(uint64_t n_rows) { return n_rows >= 2 * KECCAK_LEVELS_BLOCK_LEN && keccak_levels_fused(n_rows / 2); }
+
+void launch_keccak_levels(hipStream_t st, const KeccakTopArgs& a0) {
+    KeccakTopArgs a = a0;
+    if (!a.block_len) a.block_len = a.first_len;
+    const uint64_t b0 = a.block_len;
+    if (!keccak_levels_enabled() || !b0 || (b0 & (b0 - 1)) || b0 > (uint64_t)LEVELS_LDS_Y || a.first_len % b0 || a.levels < 1 || a.levels > KECCAK_TOP_MAX_LEVELS ||
+        (b0 >> (a.levels - 1)) == 0 || (a.leaf_rows && a.leaf_rows != 2 * a.first_len) || (a.ch_pos && a.first_len != b0))
+        throw std::logic_error("keccak levels: a launch this kernel does not fit");
+    double bytes = 0, perms = 0;
+    for (int l = 0; l < a.levels; l++) {
+        bytes += (double)(a.first_len >> l) * (96.0 + 4.0 * a.n_elems[l]);
+        perms += (double)(a.first_len >> l) * node_perms(a.n_elems[l]);
+    }
+    if (a.leaf_rows) {
+        bytes += (double)a.leaf_rows * (4.0 * a.leaf_elems + 32.0);
+        perms += (double)a.leaf_rows * row_perms(a.leaf_elems);
+    }
+    unsigned threads = (unsigned)((a.leaf_rows ? 4 : 2) * b0);
+    if (threads < 64) threads = 64;
+    ProfScope ps("k_keccak_levels_pair", st, bytes, perms * KECCAK_VALU_PER_PERM / 64.0);
+    VK_LAUNCH(k_keccak_levels_pair, dim3((unsigned)(a.first_len / b0)), dim3(threads), 0, st, a);
+}
 
 void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
     double bytes = 0, perms = 0;
@@ -263,6 +346,7 @@ void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
         bytes += (double)a.leaf_rows * (4.0 * a.leaf_elems + 32.0);
         perms += (double)a.leaf_rows * row_perms(a.leaf_elems);
     }
+    if (pairs && keccak_levels_enabled() && a.first_len <= (uint64_t)LEVELS_LDS_Y) { launch_keccak_levels(st, a); return; }
     ProfScope ps(pairs ? "k_keccak_top_pair" : "k_keccak_top", st, bytes, perms * KECCAK_VALU_PER_PERM / 64.0);
     if (pairs) { VK_LAUNCH(k_keccak_top_pair, dim3(1), dim3(1024), 0, st, a); return; }
     VK_LAUNCH(k_keccak_top, dim3(1), dim3(1024), 0, st, a);
