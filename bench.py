@@ -197,6 +197,49 @@ def cpu_baseline(log_rows, rc, headline_log_rows, mmcs_poseidon=False):
     return out
 
 
+def sharded_leg_process(args):
+    """`bench.py --sharded-leg` (started by every rank of an N > 1 run AFTER its contract line): rank 0's segment proved ONCE over all the
+    ranks (vgpu_prove_sharded over RCCL / xGMI), the result on stderr.  Its own rendezvous (gloo on VGPU_SHARDED_LEG_PORT, for the
+    communicator id only), its own prover context and communicator with a deadline on every collective."""
+    import datetime
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import valida_amd as va
+
+    rank, local_rank, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"])
+    res = {}
+    try:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="gloo", init_method="tcp://%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ["VGPU_SHARDED_LEG_PORT"]),
+                                rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        if args.workload == "c3":
+            args.log_rows = 22
+        rc = va.poseidon_round_constants()
+        prover = va.Prover(va.Machine.basic(), rc, log_blowup=2 if args.workload == "c3" else 1, device=local_rank,
+                           hash_kind=va.HASH_POSEIDON16 if args.mmcs == "poseidon" else va.HASH_KECCAK256)
+        ids = [va.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        cm = va.Comm(prover, ids[0], rank, world)
+        cm.set_timeout_ms(int(os.environ.get("VGPU_BENCH_COLLECTIVE_TIMEOUT_MS", "60000")))
+        w0 = va.Workload.alu(((1 << args.log_rows) - 8) // 9) if args.workload == "c4" else va.Workload.fib(segment_loop_bound(args.log_rows, 0))
+        m0, p0 = w0.main_traces(), w0.preprocessed()
+        dm, dp = [prover.upload(m) for m in m0], [(c, prover.upload(m)) for c, m in p0]
+        pr = cm.prove_sharded(dm, dp)  # sizes the pools
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pr = cm.prove_sharded(dm, dp)
+        res["ms_per_proof"] = (time.perf_counter() - t0) / 3 * 1e3
+        res["sha256"] = hashlib.sha256(pr.words.tobytes()).hexdigest()
+        if rank == 0:
+            res["same_words_as_the_single_gpu_proof"] = bool(np.array_equal(pr.words, prover.prove(dm, dp).words))
+    except Exception as e:  # noqa: BLE001
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    print("sharded_leg rank %d of %d: %s" % (rank, world, json.dumps(res)), file=sys.stderr, flush=True)
+    os._exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,7 +260,10 @@ def main():
                          "(PaddingFreeSponge / TruncatedPermutation over Poseidon-16), a separate leg with its own roofline")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="SURVEY.md §8 config: c2 = Fibonacci (headline), c3 = Fibonacci 2^22 rows with 4x blowup, c4 = ALU/range-heavy loop")
+    ap.add_argument("--sharded-leg", action="store_true", help=argparse.SUPPRESS)  # internal: the one-proof-over-all-ranks leg of an N > 1 run, in a process of its own
     args = ap.parse_args()
+    if args.sharded_leg:
+        return sharded_leg_process(args)
 
     # Pin the measured configuration before the HIP runtime starts: 3 prover contexts x (main + 1 aux stream) over FOUR hardware
     # queues (the runtime's default; other counts measured worse, DESIGN.md "Measurement").
@@ -692,35 +738,21 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1 and lib_comm is not None and not comm_stuck and os.environ.get("VGPU_BENCH_SHARDED", "1") == "1":
         # After the contract line (nothing below can change it): ONE proof — rank 0's segment — over ALL the ranks (vgpu_prove_sharded over
-        # RCCL / xGMI: row-range shards), reported on stderr.  The first run of this path on real multi-GPU hardware:
-        # a watchdog bounds it and every rank leaves without further collectives.
-        import hashlib
-        import threading
-        res = {}
-
-        def sharded_leg():
-            try:
-                w0 = wl if rank == 0 else va.Workload.fib(segment_loop_bound(args.log_rows, 0)) if args.workload != "c4" else va.Workload.alu(((1 << args.log_rows) - 8) // 9)
-                m0, p0 = w0.main_traces(), w0.preprocessed()
-                dm, dp = [prover.upload(m) for m in m0], [(c, prover.upload(m)) for c, m in p0]
-                pr = lib_comm.prove_sharded(dm, dp)  # sizes the pools
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    pr = lib_comm.prove_sharded(dm, dp)
-                res["ms_per_proof"] = (time.perf_counter() - t0) / 3 * 1e3
-                res["sha256"] = hashlib.sha256(pr.words.tobytes()).hexdigest()
-                if rank == 0:
-                    res["same_words_as_the_single_gpu_proof"] = bool(np.array_equal(pr.words, prover.prove(dm, dp).words))
-            except Exception as e:  # noqa: BLE001
-                res["error"] = "%s: %s" % (type(e).__name__, e)
-
-        th = threading.Thread(target=sharded_leg, daemon=True)
-        th.start()
-        th.join(float(os.environ.get("VGPU_BENCH_SHARDED_TIMEOUT", "180")))
-        if th.is_alive():
-            res["error"] = "still running after the deadline"
-        print("sharded_leg rank %d of %d: %s" % (rank, world, json.dumps(res)), file=sys.stderr, flush=True)
+        # RCCL / xGMI: row-range shards), reported on stderr.  It is the first run of that path on real multi-GPU
+        # hardware, so every rank runs it in a PROCESS OF ITS OWN (`bench.py --sharded-leg`, its own rendezvous on MASTER_PORT + 17, its own
+        # communicator): a crash or a hang there is killed at the deadline and cannot touch this process's exit status.
+        import subprocess
+        dist.barrier(group=coll_group)
+        env = dict(os.environ, VGPU_SHARDED_LEG_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        cmd = [sys.executable, os.path.abspath(__file__), "--sharded-leg", "--log-rows", str(args.log_rows), "--workload", args.workload, "--mmcs", args.mmcs]
+        try:
+            r = subprocess.run(cmd, env=env, timeout=float(os.environ.get("VGPU_BENCH_SHARDED_TIMEOUT", "240")), stdout=subprocess.DEVNULL)
+            if r.returncode != 0:
+                print("sharded_leg rank %d of %d: the leg's process ended with status %d" % (rank, world, r.returncode), file=sys.stderr, flush=True)
+        except subprocess.TimeoutExpired:
+            print("sharded_leg rank %d of %d: still running after the deadline; killed" % (rank, world), file=sys.stderr, flush=True)
+        except Exception as e:  # noqa: BLE001 - an optional leg
+            print("sharded_leg rank %d of %d: %s: %s" % (rank, world, type(e).__name__, e), file=sys.stderr, flush=True)
         sys.stdout.flush()
         os._exit(0)
     if world > 1:
