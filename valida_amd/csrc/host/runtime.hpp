@@ -68,9 +68,12 @@ struct DeviceCtx {
 
     explicit DeviceCtx(int dev) : device(dev) {
         VG_HIP_CHECK(hipSetDevice(dev));
-        VG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // experiment switch (A/B records only; unset in the product): VGPU_STREAM_PRIO="<main>,<aux>" = HIP stream priorities (0 normal, -1 high)
+        int prio_main = 0, prio_aux = 0;
+        if (const char* e = getenv("VGPU_STREAM_PRIO")) (void)sscanf(e, "%d,%d", &prio_main, &prio_aux);
+        VG_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_main));
         for (int i = 0; i < NUM_AUX; i++) {
-            VG_HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+            VG_HIP_CHECK(hipStreamCreateWithPriority(&aux[i], hipStreamNonBlocking, prio_aux));
             VG_HIP_CHECK(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
         }
         VG_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
