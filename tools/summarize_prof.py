@@ -115,6 +115,17 @@ def timeline(db_path, out_txt, header):
         f.write("kernel launches total_us avg_us exclusive_us\n")
         for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             f.write("%-28s %5d %10.1f %8.1f %10.1f\n" % (k, n, t / 1e3, t / 1e3 / n, excl.get(k, 0) / 1e3))
+    # the launch sequence itself (start and duration of every launch of that proof, and the queue it ran on where the view has one)
+    try:
+        cols = [r[1] for r in db.execute("pragma table_info(kernels)").fetchall()]
+        qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+        q = "select name, start, end%s from kernels where start >= ? and start < ? order by start" % ((", " + qcol) if qcol else "")
+        with open(out_txt.replace("_timeline_", "_launch_sequence_"), "w") as f:
+            f.write("# %s\n# every launch of one complete proof: start_us duration_us %s kernel\n" % (header, qcol or "-"))
+            for r in db.execute(q, (seg[0][1], rows[b][1])).fetchall():
+                f.write("%9.1f %8.1f %s %s\n" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3] if qcol else "-", short(r[0])))
+    except Exception as e:  # noqa: BLE001 - an extra
+        print("launch sequence failed:", e)
 
 
 def counters(db_path):
