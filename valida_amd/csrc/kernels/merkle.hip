@@ -85,30 +85,29 @@ __device__ __forceinline__ void store_digest(uint32_t* p, const uint32_t (&d)[8]
 // leaf layer: digests[r] = H(row r)
 template <class Cols>
 __global__ void __launch_bounds__(256) k_keccak_leaves(const Cols cols, int n_elems, uint64_t n_rows, uint32_t* __restrict__ digests) {
-    // grid-stride: the grid may be capped (keccak_grid_cap) so that the kernel leaves wave slots and registers to the kernels of the other proofs in flight
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t d[8];
-        hash_row(cols, n_elems, r, d);
-        store_digest(digests + 8 * r, d);
-    }
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint32_t d[8];
+    hash_row(cols, n_elems, r, d);
+    store_digest(digests + 8 * r, d);
 }
 
 // next[i] = C(prev[2i], prev[2i+1]); if n_elems > 0: next[i] = C(next[i], H(row i of cols))
 __global__ void __launch_bounds__(256) k_keccak_compress(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int n_elems, uint64_t n_out,
                                   uint32_t* __restrict__ next) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t l[8], r[8], d[8];
-        load_digest(prev + 16 * i, l);
-        load_digest(prev + 16 * i + 8, r);
-        compress2(l, r, d);
-        if (n_elems > 0) {
-            uint32_t h[8], d2[8];
-            hash_row(PtrCols{cols}, n_elems, i, h);
-            compress2(d, h, d2);
-            store_digest(next + 8 * i, d2);
-        } else {
-            store_digest(next + 8 * i, d);
-        }
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    uint32_t l[8], r[8], d[8];
+    load_digest(prev + 16 * i, l);
+    load_digest(prev + 16 * i + 8, r);
+    compress2(l, r, d);
+    if (n_elems > 0) {
+        uint32_t h[8], d2[8];
+        hash_row(PtrCols{cols}, n_elems, i, h);
+        compress2(d, h, d2);
+        store_digest(next + 8 * i, d2);
+    } else {
+        store_digest(next + 8 * i, d);
     }
 }
 
@@ -307,11 +306,6 @@ static bool keccak_pairs_enabled() {
     static const bool on = [] { const char* e = getenv("VGPU_KECCAK_PAIRS"); return !(e && e[0] == '0'); }();
     return on;
 }
-// experiment switch: VGPU_KECCAK_BLOCKS_PER_CU=k caps the grids of the throughput-bound kernels at 256 CUs x k workgroups (grid-stride loops)
-static unsigned keccak_grid_cap(unsigned blocks) {
-    static const unsigned cap = [] { const char* e = getenv("VGPU_KECCAK_BLOCKS_PER_CU"); return e ? 256u * (unsigned)atoi(e) : 0u; }();
-    return cap && blocks > cap ? cap : blocks;
-}
 static double row_perms(int n_elems) { return (double)(n_elems / 34 + 1); }
 static double node_perms(int n_inject) { return n_inject > 0 ? 2.0 + row_perms(n_inject) : 1.0; }
 
@@ -372,7 +366,7 @@ void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n
         VK_LAUNCH(k_keccak_leaves_pair<PtrCols>, dim3((unsigned)((2 * n_rows + 255) / 256)), dim3(256), 0, st, PtrCols{cols_dev}, n_elems, n_rows, digests);
         return;
     }
-    VK_LAUNCH(k_keccak_leaves<PtrCols>, dim3(keccak_grid_cap(blocks)), dim3(256), 0, st, PtrCols{cols_dev}, n_elems, n_rows, digests);
+    VK_LAUNCH(k_keccak_leaves<PtrCols>, dim3(blocks), dim3(256), 0, st, PtrCols{cols_dev}, n_elems, n_rows, digests);
 }
 void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
@@ -382,7 +376,7 @@ void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t
         VK_LAUNCH(k_keccak_leaves_pair<StridedCols>, dim3((unsigned)((2 * n_rows + 255) / 256)), dim3(256), 0, st, StridedCols{base, stride}, n_elems, n_rows, digests);
         return;
     }
-    VK_LAUNCH(k_keccak_leaves<StridedCols>, dim3(keccak_grid_cap(blocks)), dim3(256), 0, st, StridedCols{base, stride}, n_elems, n_rows, digests);
+    VK_LAUNCH(k_keccak_leaves<StridedCols>, dim3(blocks), dim3(256), 0, st, StridedCols{base, stride}, n_elems, n_rows, digests);
 }
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
     unsigned blocks = (unsigned)((n_out + 255) / 256);
@@ -392,7 +386,7 @@ void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t
         VK_LAUNCH(k_keccak_compress_pair, dim3((unsigned)((2 * n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
         return;
     }
-    VK_LAUNCH(k_keccak_compress, dim3(keccak_grid_cap(blocks)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
+    VK_LAUNCH(k_keccak_compress, dim3(blocks), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
 }
 
 }  // namespace vk
