@@ -204,11 +204,17 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             if (own[i].empty()) continue;
             if (cin[i].nat) {
                 const DMat& nat = *cin[i].nat;
-                DMat mine(c, nat.height, own[i].size());
-                for (size_t k = 0; k < own[i].size(); k++)
-                    VG_HIP_CHECK(hipMemcpyAsync(mine.data + k * mine.height, nat.data + own[i][k] * nat.height, mine.height * 4, hipMemcpyDeviceToDevice, c->stream));
-                CommitInput ci{&mine, false, false};
-                R.own_lde[i] = coset_lde(c, c->stream, ci, lb, shift);
+                if (own[i].size() == nat.width) {  // every column is this rank's (W = 1): extend the matrix where it lies
+                    CommitInput ci{const_cast<DMat*>(&nat), false, false};
+                    R.own_lde[i] = coset_lde(c, c->stream, ci, lb, shift);
+                } else {
+                    // this rank's columns are every W-th one (owner_of): ONE strided copy gathers them
+                    DMat mine(c, nat.height, own[i].size());
+                    VG_HIP_CHECK(hipMemcpy2DAsync(mine.data, mine.height * 4, nat.data + own[i][0] * nat.height, (size_t)W * nat.height * 4, mine.height * 4, own[i].size(),
+                                                  hipMemcpyDeviceToDevice, c->stream));
+                    CommitInput ci{&mine, false, false};
+                    R.own_lde[i] = coset_lde(c, c->stream, ci, lb, shift);
+                }
             } else if (cin[i].own_bitrev) {
                 if (cin[i].own_bitrev->width != own[i].size() || cin[i].own_bitrev->height != cin[i].height) throw std::logic_error("sharded commit: own-column input of the wrong shape");
                 CommitInput ci{cin[i].own_bitrev, true, true};
@@ -667,6 +673,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 a.K = Ks[i];
                 R.quot_full[i] = DMat(&c, 1ull << log_deg[i], 10);
                 a.out = R.quot_full[i].view();
+                a.out_natural = 1;  // chunk rows in natural order: the quotient round takes the fused LDE like the other two (as in prover.cpp)
                 vk::launch_quotient(c.stream, a, c.tables);
                 continue;
             }
@@ -699,6 +706,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             }
             R.quot_shard[i] = DMat(&c, rows / 2, 10);
             a.out = R.quot_shard[i].view();
+            a.out_natural = 1;  // natural order of THIS range (the sub-coset eq): global natural index eq + Wq m
             vk::launch_quotient(c.stream, a, c.tables);
         }
         c.check_launch("quotient");
@@ -738,14 +746,27 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
             }
             f.all_to_all(plan);
             for (auto& R : rk) R.quot_shard.clear();
+            if (Wq > 1)  // the blocks lie end to end, block r = sub-coset bitrev_Wq(r): interleave them into the global natural order
+                for (int k = 0; k < NH; k++) {
+                    Rank& R = rk[k];
+                    DeviceCtx& c = *R.c;
+                    c.activate();
+                    for (size_t i : big_chips) {
+                        if (R.quot_own[i].empty()) continue;
+                        DMat nat(&c, R.quot_own[i].height, R.quot_own[i].width);
+                        vk::launch_interleave_blocks(c.stream, R.quot_own[i].data, nat.data, chunk_rows(i), logWq, nat.width);
+                        R.quot_own[i] = std::move(nat);  // the old block returns to the pool in stream order
+                    }
+                    c.check_launch("quotient interleave");
+                }
         }
         for (int k = 0; k < NH; k++) {
             Rank& R = rk[k];
             for (size_t i = 0; i < NC; i++) {
                 CommitIn ci;
                 ci.height = 1ull << log_deg[i]; ci.width = 10;
-                if (R.main_rs.mats[i].big) ci.own_bitrev = R.quot_own[i].empty() ? nullptr : &R.quot_own[i];
-                else ci.bitrev_full = &R.quot_full[i];
+                if (R.main_rs.mats[i].big) ci.own_nat = R.quot_own[i].empty() ? nullptr : &R.quot_own[i];
+                else ci.nat = &R.quot_full[i];
                 cin[k].push_back(ci);
             }
         }
@@ -850,9 +871,25 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         for (auto& w : wlist) { w.pool_off = pool.size(); put_min_poly(pool, w.z); }
         pool.push_back(0);
         DBuf pool_dev(&c, pool);
-        for (auto& w : wlist) {
-            w.buf = DBuf(&c, (size_t)vk::bary_buffer_words(w.rows));
-            vk::launch_bary_weights(c.stream, w.rows, pool_dev.data + w.pool_off, w.shift, c.tables, w.buf.data);
+        {  // all weight vectors of this rank in ONE launch (k_bary_weights_batch, as in the single-GPU prover); a job carries its own shift
+            std::vector<uint32_t> bj;
+            uint32_t blocks = 0;
+            double rows = 0;
+            auto put64 = [&](uint64_t v) { bj.push_back((uint32_t)v); bj.push_back((uint32_t)(v >> 32)); };
+            for (auto& w : wlist) {
+                w.buf = DBuf(&c, (size_t)vk::bary_buffer_words(w.rows));
+                bj.push_back(blocks); bj.push_back(w.shift.v);  // a Montgomery word of a non-zero field element is never 0
+                put64(w.rows);
+                put64((uint64_t)(pool_dev.data + w.pool_off));
+                put64((uint64_t)w.buf.data);
+                put64((uint64_t)(vk::bary_weights_has_image(w.rows) ? w.buf.data + 5 * w.rows : nullptr));
+                blocks += vk::bary_weights_blocks(w.rows);
+                rows += (double)w.rows;
+            }
+            if (!wlist.empty()) {
+                DBuf jobs_dev(&c, bj);
+                vk::launch_bary_weights_batch(c.stream, jobs_dev.data, (uint32_t)wlist.size(), blocks, rows, s, c.tables);
+            }
         }
         DBuf out_dev(&c, ow + 4);
         std::vector<DBuf> partials;
@@ -1022,8 +1059,9 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 ly.sharded = false; ly.len = len;
                 ly.t.sharded = false;
                 ly.t.log_total = ly.t.log_local = vg::log2_strict_u64(half);
-                ly.t.tree.build(&c, {vk::DMatView{O.cur.data, half, 10, half}}, false);
-                vk::launch_fri_challenge(c.stream, R.p->pow_pos_.data, D.ch_dev.data, ly.t.tree.layers.back().data, D.betas_dev.data + 5 * D.count, D.commits_dev.data + 8 * D.count);
+                // the challenger step rides on the tree-top launch, as in the single-GPU prover (prover.cpp, FRI commit phase)
+                const DeviceTree::TopChallenger step{R.p->pow_pos_.data, D.ch_dev.data, D.betas_dev.data + 5 * D.count, D.commits_dev.data + 8 * D.count};
+                ly.t.tree.build(&c, {vk::DMatView{O.cur.data, half, 10, half}}, false, nullptr, &step);
                 DBuf next(&c, (size_t)(5 * half));
                 auto it = O.ro.find(lf);
                 vk::launch_fri_fold(c.stream, O.cur.data, len, D.betas_dev.data + 5 * D.count, it != O.ro.end() ? it->second.data : nullptr, c.tables, next.data);

@@ -3,6 +3,7 @@
 // (tests / openings).  Pure data movement: HBM-bound, tiles staged through LDS so both the row-major
 // and the column-major side move full 128/256-byte segments.
 #include "launch.hpp"
+#include <stdexcept>
 
 namespace vk {
 
@@ -93,6 +94,23 @@ __global__ void k_export_rows(DMatView src, uint64_t row0, uint64_t nrows, uint3
         uint64_t r = e % nrows, c = e / nrows;
         dst[r * src.width + c] = src.get(row0 + r, c).canonical();
     }
+}
+
+// Sharded quotient round: a column arrives as Wq blocks of `rows` chunk rows, block r = the rows of the rank that evaluated the sub-coset
+// eq = bitrev_Wq(r), each block in the natural order of its own range; the chunk row of global natural index j = eq + Wq m is row m of that
+// block.  dst = the column in global natural order (what the fused LDE reads).
+__global__ void __launch_bounds__(256) k_interleave_blocks(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t rows, uint32_t log_wq) {
+    const uint64_t n = rows << log_wq, j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t eq = (uint32_t)(j & ((1u << log_wq) - 1u)), r = vg::reverse_bits_len(eq, log_wq);
+    const uint64_t col = blockIdx.y;
+    dst[col * n + j] = src[col * n + (uint64_t)r * rows + (j >> log_wq)];
+}
+void launch_interleave_blocks(hipStream_t st, const uint32_t* src, uint32_t* dst, uint64_t rows, uint32_t log_wq, uint64_t n_cols) {
+    if (!log_wq) throw std::logic_error("interleave: one block is already in natural order");
+    const uint64_t n = rows << log_wq;
+    ProfScope ps("k_interleave_blocks", st, 8.0 * n * n_cols);
+    VK_LAUNCH(k_interleave_blocks, dim3((unsigned)((n + 255) / 256), (unsigned)n_cols), dim3(256), 0, st, src, dst, rows, log_wq);
 }
 
 void launch_ingest(hipStream_t st, const uint32_t* src_dev, DMatView dst, bool bitrev) {

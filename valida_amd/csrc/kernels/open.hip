@@ -85,12 +85,12 @@ __global__ void __launch_bounds__(256) k_bary_weights(uint64_t n, const uint32_t
 // All weight vectors of an opening in ONE launch: a proof needs one per (height, point) — seventeen for the BasicMachine, most of them a handful
 // of blocks — and as launches of their own they sit one after the other at the head of the opening phase (0.27 ms of a lone proof with
 // nothing else on the GPU).  jobs: n_jobs x { first block, n (u64), mg pointer (u64), w pointer (u64), img pointer (u64) }, first blocks ascending.
-struct BaryJob { uint32_t first_block, pad; uint64_t n; const uint32_t* mg; uint32_t* w; uint32_t* img; };
+struct BaryJob { uint32_t first_block, shift; uint64_t n; const uint32_t* mg; uint32_t* w; uint32_t* img; };  // shift (Montgomery): 0 = the launch's shift (the sharded prover's range weights carry their own)
 __global__ void __launch_bounds__(256) k_bary_weights_batch(const BaryJob* __restrict__ jobs, uint32_t n_jobs, uint32_t shift, DeviceTables tb) {
     uint32_t lo = 0, hi = n_jobs - 1;  // the job of this block: the last one whose first block is <= blockIdx.x (block-uniform)
     while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (jobs[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1; }
     const BaryJob j = jobs[lo];
-    bary_weights_block(blockIdx.x - j.first_block, j.n, j.mg, shift, tb, j.w, j.img);
+    bary_weights_block(blockIdx.x - j.first_block, j.n, j.mg, j.shift ? j.shift : shift, tb, j.w, j.img);
 }
 
 // ---- column dot products --------------------------------------------------------------------------
