@@ -253,6 +253,7 @@ def main():
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the latency / PCIe-inclusive / operation-log legs (profiling runs: the process then consists of the warmup and the timed region only)")
+    ap.add_argument("--no-clock-probe", action="store_true", help="do not sample the shader clock over the timed region (A/B of the probe itself)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="experiment: no per-launch HIP events in the timed region (then no per-kernel figures / roofline in the line)")
     ap.add_argument("--mmcs", choices=["keccak", "poseidon"], default="keccak",
@@ -564,7 +565,26 @@ def main():
         dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
     for p_ in provers:
         p_.set_profiling(not args.no_kernel_events, only=dominant)
+    # The shader clock the device sustains under THIS load, sampled over the timed region by one probing wave every 40 ms (libvgpu:
+    # vgpu_shader_clock_probe; rocm-smi is blind here): the rooflines' issue bounds are priced at the guide's 2.4 GHz.
+    clock_samples, clock_stop = [], None
+    if not args.no_clock_probe:
+        import threading
+        clock_stop = threading.Event()
+
+        def sample_clock():
+            try:
+                while not clock_stop.is_set():
+                    clock_samples.append(va.shader_clock_hz(local_rank, 2048))
+                    clock_stop.wait(0.04)
+            except Exception as e:  # noqa: BLE001 - a measurement aid must not cost the line
+                print("bench: clock probe stopped (%s: %s)" % (type(e).__name__, e), file=sys.stderr, flush=True)
+
+        va.shader_clock_hz(local_rank, 4096)  # creates the probe's stream outside the timed region
+        clock_thread = threading.Thread(target=sample_clock, daemon=True)
     fence()
+    if clock_stop is not None:
+        clock_thread.start()
     t0 = time.perf_counter()
     phase = {}
     for p in run_steps(args.steps):
@@ -572,6 +592,9 @@ def main():
             phase[k] = phase.get(k, 0.0) + v
     fence()
     elapsed = time.perf_counter() - t0
+    if clock_stop is not None:
+        clock_stop.set()
+        clock_thread.join(5)
     prof = {}
     for p_ in provers:
         for k, v in p_.profile().items():
@@ -696,6 +719,12 @@ def main():
                 "frac_of_full_rate_peak": proof_instr / (ms_per_step * 1e-3) / mb["full_rate"], "frac_of_half_rate_peak": proof_instr / (ms_per_step * 1e-3) / mb["half_rate"],
                 "note": "instruction counts from the committed PMC pass (SQ_INSTS_VALU per launch) x this run's launches per step; the proof's mix of full- and "
                         "half-rate instructions puts its issue peak between the two"},
+            "shader_clock": None if not clock_samples else {
+                "GHz_mean": sum(clock_samples) / len(clock_samples) / 1e9, "GHz_min": min(clock_samples) / 1e9, "GHz_max": max(clock_samples) / 1e9, "samples": len(clock_samples),
+                "guide_GHz": GUIDE_CLOCK_HZ / 1e9,
+                "roofline_frac_at_the_sustained_clock": None if valu_ops <= 0 else keccak_roofline(prof[name])["frac"] * GUIDE_CLOCK_HZ / (sum(clock_samples) / len(clock_samples)),
+                "how": "one wave of another stream every 40 ms over the timed region: shader cycles of 2048 dependent VALU additions against the 100 MHz wall clock "
+                       "(vgpu_shader_clock_probe); the issue bounds in `roofline` / `valu_roofline` / `proof_valu_roofline` are priced at the guide's clock"},
             "proof_roofline": {"algorithmic_bytes_per_proof": b_alg, "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "phase_ms": {k: v / args.steps for k, v in phase.items()},
             "kernel_ms_per_step": {k: v[1] / table_steps for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])},

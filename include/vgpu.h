@@ -149,6 +149,11 @@ void vgpu_prover_set_prep_cache(vgpu_prover_t* p, uint32_t on);
  * the host and the command processor a little; a throughput measurement times only the kernel it reports a roofline for */
 void vgpu_prover_set_profiling_filter(vgpu_prover_t* p, const char* kernel_name);
 int64_t vgpu_prover_profile(vgpu_prover_t* p, char* out, uint64_t cap);
+/* Measurement aid (bench.py's roofline): the shader clock the device sustains RIGHT NOW.  One wave on a stream of its own runs `iters` dependent
+ * VALU additions and reads the shader-cycle counter and the 100 MHz wall clock before and after: out[0] = shader cycles, out[1] = wall ticks
+ * (clock in Hz = out[0] / out[1] * 1e8).  Blocks the caller for the few tens of microseconds the wave runs; safe beside running proofs (no
+ * allocation, no device-wide synchronisation after the first call).  Needs a HIP device. */
+int32_t vgpu_shader_clock_probe(int32_t device, uint32_t iters, uint64_t out[2]);
 
 /* Page-locked host memory for the matrices a host hands over: vgpu_trace_upload / vgpu_oplog_upload from such a buffer is one DMA at
  * PCIe rate; from ordinary (pageable) memory the runtime stages the copy through its own bounce buffers on the calling thread, which

@@ -1009,3 +1009,11 @@ def test_cached_preprocessed_commitment_follows_the_traces(machine, rc):
     e = proofs[25]
     again = [(c, p.upload(m)) for c, m in e["w"].preprocessed()]  # equal contents, new uploads: a miss, same proof
     assert first_mismatch(p.prove(e["main"], again).words, e["want"]) is None
+
+
+def test_shader_clock_probe_reads_a_plausible_clock():
+    """vgpu_shader_clock_probe (bench.py's measurement aid): one wave, shader cycles against the 100 MHz wall clock."""
+    hz = [va.shader_clock_hz(0, 4096) for _ in range(3)]
+    assert all(0.5e9 < h < 3.0e9 for h in hz), hz
+    with pytest.raises(va.VgpuError):
+        va.shader_clock_hz(0, 0)

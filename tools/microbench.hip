@@ -9,6 +9,7 @@
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench.hip -o build/microbench
 // Run:    build/microbench [rates|copies|all]
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -271,6 +272,22 @@ int main(int argc, char** argv) {
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cu = prop.multiProcessorCount;
     printf("device: %s, %d CUs x 4 SIMDs, clockRate %d kHz\n", prop.gcnArchName, cu, prop.clockRate);
+    if (!strcmp(what, "clock-probe")) {
+        // ONE wave counting its own shader cycles against the 100 MHz wall clock, `n` samples `gap_ms` apart: run it BESIDE another process's
+        // load (bench.py) to read the clock the chip sustains under that load — rocm-smi is blind in this container
+        const int n = argc > 2 ? atoi(argv[2]) : 20, gap_ms = argc > 3 ? atoi(argv[3]) : 300;
+        uint64_t* dc;
+        CHECK(hipMalloc(&dc, 64));
+        for (int i = 0; i < n; i++) {
+            hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, 0, dc, 1 << 16);
+            uint64_t hc[3];
+            CHECK(hipMemcpy(hc, dc, 24, hipMemcpyDeviceToHost));
+            printf("clock-probe %2d: %.3f GHz over %.0f us\n", i, (double)hc[0] / ((double)hc[1] / 1e8) / 1e9, (double)hc[1] / 100.0);
+            fflush(stdout);
+            usleep((useconds_t)gap_ms * 1000);
+        }
+        return 0;
+    }
     if (!strcmp(what, "rates") || !strcmp(what, "all")) {
         uint64_t* dc;
         CHECK(hipMalloc(&dc, 64));

@@ -61,6 +61,8 @@ def lib():
         L.vgpu_proof_debug_perm_trace.restype = ctypes.c_int64
         L.vgpu_proof_debug_quotient.restype = ctypes.c_int64
         L.vgpu_prover_profile.restype = ctypes.c_int64
+        L.vgpu_shader_clock_probe.argtypes = [ctypes.c_int32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
+        L.vgpu_shader_clock_probe.restype = ctypes.c_int32
         for name in ("vgpu_air_constant", "vgpu_air_variable", "vgpu_air_is_first_row", "vgpu_air_is_last_row", "vgpu_air_is_transition", "vgpu_air_add",
                      "vgpu_air_sub", "vgpu_air_mul", "vgpu_air_neg", "vgpu_machine_num_chips", "vgpu_challenger_grind"):
             getattr(L, name).restype = ctypes.c_uint32
@@ -76,6 +78,14 @@ def _check(code):
 def _u32(a):
     a = np.ascontiguousarray(a, dtype=np.uint32)
     return a, a.ctypes.data_as(c_u32p)
+
+
+def shader_clock_hz(device=0, iters=8192):
+    """The shader clock the device sustains right now (vgpu_shader_clock_probe: one wave, a chain of `iters` VALU additions, shader cycles
+    against the 100 MHz wall clock).  Safe beside running proofs; bench.py samples it over its timed region."""
+    out = (ctypes.c_uint64 * 2)()
+    _check(lib().vgpu_shader_clock_probe(ctypes.c_int32(device), ctypes.c_uint32(iters), out))
+    return float(out[0]) / float(out[1]) * 1e8
 
 
 def poseidon_round_constants(seed=0x56414C494441, source="splitmix", **cli_switches):

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cstring>
 #include <future>
+#include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include "host/cbor.hpp"
@@ -305,6 +307,28 @@ void vgpu_prover_set_profiling(vgpu_prover_t* p, uint32_t on) {
     auto& c = p->p->ctx();
     c.profiler.reset();
     c.profiler.enabled = on != 0;
+}
+// One probe state per device, created on first use and kept for the life of the process: a stream of its own and three page-locked words the
+// wave writes straight into — no allocation and no device-wide synchronisation on the calls that run beside proofs.
+int32_t vgpu_shader_clock_probe(int32_t device, uint32_t iters, uint64_t out[2]) {
+    VG_TRY({
+        if (!out || !iters) throw std::invalid_argument("shader_clock_probe: null output or zero iterations");
+        struct Probe { hipStream_t st = nullptr; uint64_t* buf = nullptr; };
+        static std::mutex mu;
+        static std::map<int, Probe> probes;
+        std::lock_guard<std::mutex> lk(mu);
+        VG_HIP_CHECK(hipSetDevice(device));
+        Probe& pr = probes[device];
+        if (!pr.st) {
+            VG_HIP_CHECK(hipStreamCreateWithFlags(&pr.st, hipStreamNonBlocking));
+            VG_HIP_CHECK(hipHostMalloc((void**)&pr.buf, 64));
+        }
+        pr.buf[0] = pr.buf[1] = 0;
+        vk::launch_clock_probe(pr.st, pr.buf, iters);
+        VG_HIP_CHECK(hipStreamSynchronize(pr.st));
+        if (!pr.buf[1]) throw std::runtime_error("hip: the clock probe wrote nothing");
+        out[0] = pr.buf[0]; out[1] = pr.buf[1];
+    })
 }
 void vgpu_prover_set_prep_cache(vgpu_prover_t* p, uint32_t on) { if (p) p->p->set_prep_cache(on != 0); }
 void vgpu_prover_set_profiling_filter(vgpu_prover_t* p, const char* kernel_name) { p->p->ctx().profiler.only = kernel_name ? kernel_name : ""; }

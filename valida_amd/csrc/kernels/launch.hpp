@@ -49,6 +49,7 @@ struct QuotientArgs {
 // layout.hip
 void launch_ingest(hipStream_t st, const uint32_t* src_dev, DMatView dst, bool bitrev);
 void launch_bitrev_rows(hipStream_t st, DMatView src, DMatView dst);
+void launch_clock_probe(hipStream_t st, uint64_t* out3, uint32_t iters);  // out3: page-locked host memory (device-visible); see vgpu_shader_clock_probe
 // n_cols columns of Wq = 2^log_wq blocks of `rows` rows (block r in the natural order of the sub-coset bitrev(r)) -> columns in global natural order
 void launch_interleave_blocks(hipStream_t st, const uint32_t* src, uint32_t* dst, uint64_t rows, uint32_t log_wq, uint64_t n_cols);
 void launch_export_rows(hipStream_t st, DMatView src, uint64_t row0, uint64_t nrows, uint32_t* dst_dev);

@@ -113,6 +113,17 @@ void launch_interleave_blocks(hipStream_t st, const uint32_t* src, uint32_t* dst
     VK_LAUNCH(k_interleave_blocks, dim3((unsigned)((n + 255) / 256), (unsigned)n_cols), dim3(256), 0, st, src, dst, rows, log_wq);
 }
 
+// vgpu_shader_clock_probe: shader cycles (s_memtime) against the constant 100 MHz clock over a chain of dependent VALU additions
+__global__ void k_clock_probe(uint64_t* out, uint32_t iters) {
+    const uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    uint32_t x = threadIdx.x;
+    for (uint32_t i = 0; i < iters; i++) asm volatile("v_add_u32 %0, %0, %0" : "+v"(x));
+    const uint64_t c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = x; }
+}
+// a plain launch: the caller is not a proving thread, the profiler's launch scope (profiler.hpp) belongs to those
+void launch_clock_probe(hipStream_t st, uint64_t* out3, uint32_t iters) { hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, st, out3, iters); }
+
 void launch_ingest(hipStream_t st, const uint32_t* src_dev, DMatView dst, bool bitrev) {
     int log_h = (int)vg::log2_strict_u64(dst.height);
     unsigned blocks = (unsigned)((dst.height + 63) / 64);
