@@ -688,7 +688,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     // WHILE the GPU evaluates the opened values instead of after their download with the GPU idle (a 0.13 ms gap of a lone proof).
     const Ext5 alpha_b = ch.sample_ext();
     struct MatEntry { const DMat* lde; std::vector<std::tuple<uint32_t, Ext5, Ext5>> pts; size_t r, i; };  // (slot, alpha^offset, Y)
-    struct Group { std::vector<Ext5> zs; std::map<PointKey, uint32_t> slot; std::vector<MatEntry> mats; uint64_t num_reduced = 0; };
+    struct Group { std::vector<Ext5> zs; std::map<PointKey, uint32_t> slot; std::vector<MatEntry> mats; uint64_t num_reduced = 0; Ext5 offset = Ext5::one(); };  // offset = alpha^num_reduced
     std::map<unsigned, Group> groups;
     std::vector<Ext5> apow;
     auto prepare_groups = [&]() {  // everything but Y
@@ -708,8 +708,9 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                     auto it = g.slot.find(key);
                     uint32_t slot;
                     if (it == g.slot.end()) { slot = (uint32_t)g.zs.size(); g.slot[key] = slot; g.zs.push_back(z); } else slot = it->second;
-                    me.pts.emplace_back(slot, alpha_b.pow(g.num_reduced), Ext5::zero());
+                    me.pts.emplace_back(slot, g.offset, Ext5::zero());
                     g.num_reduced += lde.width;
+                    if (lde.width) g.offset *= apow[lde.width - 1] * alpha_b;  // alpha^width: two products instead of a square-and-multiply per (matrix, point)
                 }
                 g.mats.push_back(std::move(me));
             }
@@ -724,6 +725,8 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     uint32_t* out_host = nullptr;  // their pinned landing area: read after the opening's one synchronisation (the end of the FRI commit phase)
     {
         std::map<std::pair<unsigned, PointKey>, size_t> wkey;  // distinct (log_n, point) -> weight vector
+        std::map<unsigned, Fp> den_inv;                          // log_n -> 1 / (n s^(n-1))
+        std::map<PointKey, std::vector<Ext5>> zpow2;             // point -> z^(2^k), k = 0 ..
         struct WEntry { unsigned log_n; Ext5 z; size_t pool_off; DBuf buf; };
         std::vector<WEntry> wlist;
         std::vector<uint32_t> pool;
@@ -741,10 +744,15 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                     const size_t scale_off = pool.size();
                     for (int p = 0; p < np; p++) {
                         const Ext5& z = pts[p0 + p];
-                        // scale = (z^n - s^n) / (n s^(n-1))
-                        Ext5 zer = z.exp_power_of_2(ln) - s.exp_power_of_2(ln);
-                        Fp den = Fp::from_canonical((uint32_t)(n % vg::P)) * s.pow(n - 1);
-                        put_ext(pool, zer * den.inv());
+                        // scale = (z^n - s^n) / (n s^(n-1)): the host sits between the transcript and the first launch here with the GPU idle, so
+                        // 1 / (n s^(n-1)) is kept per height and the squarings z^(2^k) per distinct point (zeta serves every chip)
+                        auto dit = den_inv.find(ln);
+                        if (dit == den_inv.end()) dit = den_inv.emplace(ln, (Fp::from_canonical((uint32_t)(n % vg::P)) * s.pow(n - 1)).inv()).first;
+                        std::vector<Ext5>& zp = zpow2[key_of(z)];
+                        if (zp.empty()) zp.push_back(z);
+                        while (zp.size() <= ln) zp.push_back(zp.back().square());
+                        Ext5 zer = zp[ln] - s.exp_power_of_2(ln);
+                        put_ext(pool, zer * dit->second);
                     }
                     for (int p = 0; p < np; p++) {
                         const Ext5& z = pts[p0 + p];

@@ -938,7 +938,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         O.alpha_b = R.ch->sample_ext();
         const Ext5& alpha_b = O.alpha_b;
         struct MatEntry { const uint32_t* data; uint64_t stride; uint64_t width; std::vector<std::tuple<uint32_t, Ext5, Ext5>> pts; };  // (slot, alpha^offset, Y)
-        struct Group { std::vector<Ext5> zs; std::map<SpPointKey, uint32_t> slot; std::vector<MatEntry> mats; uint64_t num_reduced = 0; };
+        struct Group { std::vector<Ext5> zs; std::map<SpPointKey, uint32_t> slot; std::vector<MatEntry> mats; uint64_t num_reduced = 0; Ext5 offset = Ext5::one(); };  // offset = alpha^num_reduced
         std::map<unsigned, Group> groups;
         size_t max_width = 0;
         for (size_t r = 0; r < NR; r++) for (auto& m : round_of(R, r).mats) max_width = std::max<size_t>(max_width, m.width);
@@ -960,8 +960,9 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                     Ext5 Y = Ext5::zero();
                     auto& ys = O.opened[r][i][p];
                     for (size_t col = 0; col < ys.size(); col++) Y += apow[col] * ys[col];
-                    me.pts.emplace_back(slot, alpha_b.pow(g.num_reduced), Y);
+                    me.pts.emplace_back(slot, g.offset, Y);
                     g.num_reduced += m.width;
+                    if (m.width) g.offset *= apow[m.width - 1] * alpha_b;  // alpha^width (as in prover.cpp)
                 }
                 g.mats.push_back(std::move(me));
             }
