@@ -10,4 +10,4 @@ timeout 900 taskset -c 0-15 python tools/mp_loop.py ${1:-30} 4 > "$OUT/r04_mp_lo
 echo "loop rc $?" >> "$OUT/r04_mp_loop.log"
 timeout 1500 python -m pytest tests -m gpu -q -x --durations=25 > "$OUT/r04_pytest_gpu.log" 2>&1
 echo "suite rc $?" >> "$OUT/r04_pytest_gpu.log"
-tail -5 "$OUT/r04_pytest_mp.log" "$OUT/r04_mp_loop.log" "$OUT/r04_pytest_gpu.log"
+tail -n 5 "$OUT/r04_pytest_mp.log" "$OUT/r04_mp_loop.log" "$OUT/r04_pytest_gpu.log"
