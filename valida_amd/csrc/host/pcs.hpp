@@ -43,12 +43,16 @@ struct DeviceTree {
     // tree (Keccak: integer-VALU work) run beside the remaining LDEs (half memory phases) instead of after them.
     // challenger: the FRI commit phase's DuplexChallenger step as an epilogue of the tree-top launch (KeccakTopArgs::ch_*), or null
     struct TopChallenger { const uint32_t* pos; uint32_t* state; uint32_t* beta5; uint32_t* commit8; };
+    // on: the stream the tree's kernels are enqueued on (null = the context's main stream).  A tree built on the auxiliary stream keeps its root
+    // on the device (fetch_root = false) and its pointer table alive in the tree.
     void build(DeviceCtx* c, const std::vector<vk::DMatView>& mats, bool fetch_root = true, const std::function<void()>* before_injection = nullptr,
-               const TopChallenger* challenger = nullptr) {
+               const TopChallenger* challenger = nullptr, hipStream_t on = nullptr) {
         // reset on every exit (a throwing build_impl included): the pointers refer to the caller's stack
-        struct Reset { DeviceTree* t; ~Reset() { t->before_injection_ = nullptr; t->challenger_ = nullptr; } } reset{this};
+        struct Reset { DeviceTree* t; ~Reset() { t->before_injection_ = nullptr; t->challenger_ = nullptr; t->on_ = nullptr; } } reset{this};
         before_injection_ = before_injection;
         challenger_ = challenger;
+        on_ = on;
+        if (on && on != c->stream && fetch_root) throw std::logic_error("mmcs: a tree on another stream leaves its root on the device");
         std::vector<ColMat> cms(mats.size());
         for (size_t i = 0; i < mats.size(); i++) {
             cms[i].height = mats[i].height;
@@ -56,11 +60,13 @@ struct DeviceTree {
         }
         build_impl(c, cms, mats.size() == 1 ? &mats[0] : nullptr, fetch_root);
     }
-    void build_cols(DeviceCtx* c, const std::vector<ColMat>& mats) { before_injection_ = nullptr; challenger_ = nullptr; build_impl(c, mats, nullptr, true); }
+    void build_cols(DeviceCtx* c, const std::vector<ColMat>& mats) { before_injection_ = nullptr; challenger_ = nullptr; on_ = nullptr; build_impl(c, mats, nullptr, true); }
 
   private:
     const std::function<void()>* before_injection_ = nullptr;
     const TopChallenger* challenger_ = nullptr;
+    hipStream_t on_ = nullptr;
+    DBuf ptr_table_;  // the column-pointer table of a tree whose root stays on the device (its kernels may still be queued when build returns)
     // single_view: the tree is over ONE strided matrix (every FRI layer tree): no pointer table, columns are base + k * stride
     void build_impl(DeviceCtx* c, const std::vector<ColMat>& cms, const vk::DMatView* single_view, bool fetch_root) {
         ctx = c;
@@ -81,10 +87,15 @@ struct DeviceTree {
         }
         const bool single = single_view != nullptr;
 
+        const hipStream_t st = on_ ? on_ : c->stream;
         DBuf ptr_buf;
         if (!single) {
             ptr_buf = DBuf(c, ptrs.size() * 2);
             c->upload_async(ptr_buf.data, ptrs.data(), ptrs.size() * 8);
+            if (st != c->stream) {  // the upload travels on the main stream: the kernels on `st` wait for it
+                VG_HIP_CHECK(hipEventRecord(c->rider_ev, c->stream));
+                VG_HIP_CHECK(hipStreamWaitEvent(st, c->rider_ev, 0));
+            }
         }
         const uint32_t* const* pd = (const uint32_t* const*)ptr_buf.data;
 
@@ -97,12 +108,12 @@ struct DeviceTree {
         const uint32_t* tab = c->poseidon_tab;
         bool leaves_in_top = false, leaves_in_mid = false;
         if (pos) {
-            if (single) vk::launch_poseidon_leaves_strided(c->stream, tab, c->poseidon_sparse, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
-            else vk::launch_poseidon_leaves(c->stream, tab, c->poseidon_sparse, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
+            if (single) vk::launch_poseidon_leaves_strided(st, tab, c->poseidon_sparse, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
+            else vk::launch_poseidon_leaves(st, tab, c->poseidon_sparse, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         } else if (single && vk::keccak_top_takes_leaves(maxh)) leaves_in_top = true;  // the small FRI layers: leaves, levels and challenger step in ONE launch
         else if (single && maxh / 2 > TOP_FIRST_LEN && vk::keccak_levels_take_leaves(maxh)) leaves_in_mid = true;  // the middle FRI layers: leaves + the layers down to 512 parents
-        else if (single) vk::launch_keccak_leaves_strided(c->stream, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
-        else vk::launch_keccak_leaves(c->stream, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
+        else if (single) vk::launch_keccak_leaves_strided(st, single_view->data, single_view->stride, (int)single_view->width, maxh, layers[0].data);
+        else vk::launch_keccak_leaves(st, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
         // mid: the consecutive layers of 256 < parents <= 32768 (at most seven) as ONE launch of 64-parent workgroups; top: the rest in one workgroup
         vk::KeccakTopArgs top{}, mid{};
@@ -120,7 +131,7 @@ struct DeviceTree {
                 if (mid.prev != layers[0].data) throw std::logic_error("mmcs: leaf prologue without a launch over the leaf layer");
                 mid.leaf_base = single_view->data; mid.leaf_stride = single_view->stride; mid.leaf_elems = (int)single_view->width; mid.leaf_rows = maxh;
             }
-            vk::launch_keccak_levels(c->stream, mid);
+            vk::launch_keccak_levels(st, mid);
             mid.levels = 0;
         };
         for (uint64_t len = maxh / 2; len >= 1; len /= 2) {
@@ -132,9 +143,9 @@ struct DeviceTree {
             // single-workgroup launch.  256, not the 1024 a workgroup could take: inside one workgroup a 1024-parent layer puts four
             // waves on each SIMD of ONE CU and costs 27 us (512 parents: 15 us), as a launch of its own across the CUs 9 + 2 us.
             if (len > TOP_FIRST_LEN) {
-                if (pos) vk::launch_poseidon_compress(c->stream, tab, c->poseidon_sparse, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
+                if (pos) vk::launch_poseidon_compress(st, tab, c->poseidon_sparse, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
                 else if (vk::keccak_levels_fused(len)) add_level(mid, len, inj);
-                else vk::launch_keccak_compress(c->stream, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
+                else vk::launch_keccak_compress(st, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
                                                 layers.back().data);
             } else {  // the last <= 9 layers go into one launch
                 flush_mid();
@@ -153,11 +164,11 @@ struct DeviceTree {
             if (!top.levels) throw std::logic_error("mmcs: the challenger epilogue needs a tree with at least one parent layer");
             top.ch_pos = challenger_->pos; top.ch_state = challenger_->state; top.ch_beta5 = challenger_->beta5; top.ch_commit8 = challenger_->commit8;
         }
-        if (top.levels) { if (pos) vk::launch_poseidon_top(c->stream, tab, c->poseidon_sparse, top); else vk::launch_keccak_top(c->stream, top); }
+        if (top.levels) { if (pos) vk::launch_poseidon_top(st, tab, c->poseidon_sparse, top); else vk::launch_keccak_top(st, top); }
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
         c->check_launch("mmcs build");
         if (fetch_root) c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished
-        else if (!single) throw std::logic_error("mmcs: a deferred root needs a single-matrix tree (no pointer table to keep alive)");
+        else ptr_table_ = std::move(ptr_buf);  // the kernels may still be queued: the table lives as long as the tree
     }
 
 };
@@ -219,8 +230,15 @@ inline DMat coset_lde(DeviceCtx* c, hipStream_t st, const CommitInput& in, unsig
 }
 
 // pcs.commit_shifted_batches (App. B4): lde_i on (31 / coset_shift_i) * H, bit-reversed rows, one MMCS.
+// A second, independent and SMALL commitment (the preprocessed traces of a proof: range table and program ROM) issued on the auxiliary
+// stream inside another round's commit: its one-tile LDEs and its tree — a chain of single-workgroup, latency-bound launches — run beside
+// that round's big LDE passes instead of in front of them, and its root arrives with that round's own synchronisation.
+struct CommitRider {
+    const std::vector<CommitInput>* mats;
+    std::unique_ptr<ProverData>* out;  // receives the rider's ProverData; its tree.root is valid when commit_batches returns
+};
 inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vector<CommitInput>& mats, const std::vector<Fp>* coset_shifts,
-                                                  const FriParams& fri) {
+                                                  const FriParams& fri, const CommitRider* rider = nullptr) {
     auto pd = std::make_unique<ProverData>();
     Fp g = Fp::from_canonical(vg::GENERATOR);
     // Per-matrix LDE pipelines are independent.  The tallest matrices are extended first, on the main stream; everything else goes to the
@@ -233,6 +251,16 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
     uint64_t maxh = 0;
     for (auto& m : mats) maxh = std::max<uint64_t>(maxh, m.mat->height);
     Section lde_section(c);
+    if (rider) {
+        auto rp = std::make_unique<ProverData>();
+        hipStream_t ax = c->aux[0];
+        for (auto& m : *rider->mats) rp->ldes.push_back(coset_lde(c, ax, m, fri.log_blowup, g));
+        std::vector<vk::DMatView> rviews;
+        for (auto& l : rp->ldes) rviews.push_back(l.view());
+        rp->tree.build(c, rviews, false, nullptr, nullptr, ax);
+        VG_HIP_CHECK(hipMemcpyAsync(c->rider_root_pin, rp->tree.layers.back().data, 32, hipMemcpyDeviceToHost, ax));  // lands before the join below completes
+        *rider->out = std::move(rp);
+    }
     pd->ldes.resize(mats.size());
     for (int pass = 0; pass < 2; pass++)
         for (size_t i = 0; i < mats.size(); i++) {
@@ -252,6 +280,8 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
         lde_section.join();
         pd->tree.build(c, views);
     }
+    // the build above synchronised on the main stream, which had waited for the auxiliary stream at the join: the rider's root has landed
+    if (rider) memcpy((*rider->out)->tree.root, c->rider_root_pin, 32);
     return pd;
 }
 

@@ -368,22 +368,29 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
 
     // ---------------- preprocessed + main commitments (lib.rs:189-225)
     t0 = Clock::now();
+    // The preprocessed commitment is small (range table, program ROM: one-tile LDEs, a tree of single-workgroup launches) and independent of
+    // the main one: it RIDES on the auxiliary stream beside the main round's big LDE passes and its root arrives with the main round's
+    // synchronisation (pcs.hpp: CommitRider) instead of costing a commit and a synchronisation of its own in front of them.  The transcript
+    // order is the reference's: preprocessed root, then main root.  VGPU_PREP_RIDER=0: one after the other (A/B).
+    static const bool prep_rider = [] { const char* e = getenv("VGPU_PREP_RIDER"); return !(e && e[0] == '0'); }();
     ProverData* prep_pd = nullptr;
-    if (!prep_nat.empty()) {
-        if (!prep_hit) {
-            std::vector<CommitInput> in;
-            for (auto& m : prep_nat) in.push_back({&m, false, false});
-            prep_pd_cache_ = commit_batches(&c, in, nullptr, fri_);
-            if (prep_cache_enabled_) prep_key_ = prep_key;  // off: the key stays empty, the next proof recomputes
-        }
-        prep_pd = prep_pd_cache_.get();
-        ch.observe_digest(prep_pd->tree.root);
+    std::vector<CommitInput> prep_in;
+    const bool ride = prep_rider && !prep_nat.empty() && !prep_hit;
+    if (!prep_nat.empty() && !prep_hit) {
+        for (auto& m : prep_nat) prep_in.push_back({&m, false, false});
+        if (!ride) prep_pd_cache_ = commit_batches(&c, prep_in, nullptr, fri_);
     }
     std::unique_ptr<ProverData> main_pd;
     {
         std::vector<CommitInput> in;
         for (auto m : main_nat) in.push_back({const_cast<DMat*>(m), false, false});  // consume = false: never modified
-        main_pd = commit_batches(&c, in, nullptr, fri_);
+        const CommitRider rider{&prep_in, &prep_pd_cache_};
+        main_pd = commit_batches(&c, in, nullptr, fri_, ride ? &rider : nullptr);
+    }
+    if (!prep_nat.empty()) {
+        if (!prep_hit && prep_cache_enabled_) prep_key_ = prep_key;  // off: the key stays empty, the next proof recomputes
+        prep_pd = prep_pd_cache_.get();
+        ch.observe_digest(prep_pd->tree.root);
     }
     ch.observe_digest(main_pd->tree.root);
     tm.commit_main = ms_since(t0);

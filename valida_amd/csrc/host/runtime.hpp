@@ -51,6 +51,10 @@ struct DeviceCtx {
     static constexpr int NUM_AUX = 1;
     hipStream_t aux[NUM_AUX] = {};
     hipEvent_t fork_ev = nullptr, join_ev[NUM_AUX] = {};
+    // a commit that rides on the auxiliary stream beside another round's LDEs (pcs.hpp: CommitRider): the event that orders its pointer-table
+    // upload (main stream) before its kernels (aux), and the page-locked landing area of its root
+    hipEvent_t rider_ev = nullptr;
+    uint32_t* rider_root_pin = nullptr;
     bool in_section = false;
     std::vector<void*> deferred;  // blocks released inside a section return to the pool at the join
     // The pool is shared by the thread that drives a proof (vgpu_prove_async's worker) and by whichever host thread frees a
@@ -77,6 +81,8 @@ struct DeviceCtx {
             VG_HIP_CHECK(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
         }
         VG_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        VG_HIP_CHECK(hipEventCreateWithFlags(&rider_ev, hipEventDisableTiming));
+        VG_HIP_CHECK(hipHostMalloc((void**)&rider_root_pin, 64));
         init_tables();
     }
     // Every C-ABI entry that launches work calls this first: binds the calling thread to this context's
@@ -91,6 +97,8 @@ struct DeviceCtx {
         (void)hipStreamSynchronize(stream);
         for (int i = 0; i < NUM_AUX; i++) { (void)hipStreamSynchronize(aux[i]); (void)hipStreamDestroy(aux[i]); (void)hipEventDestroy(join_ev[i]); }
         (void)hipEventDestroy(fork_ev);
+        if (rider_ev) (void)hipEventDestroy(rider_ev);
+        if (rider_root_pin) (void)hipHostFree(rider_root_pin);
         if (sync_ev) (void)hipEventDestroy(sync_ev);
         for (auto& kv : free_blocks) (void)hipFree(kv.second);
         for (auto& kv : live_blocks) (void)hipFree(kv.first);
