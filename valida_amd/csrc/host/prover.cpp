@@ -728,6 +728,11 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     struct Job { size_t r, i; int p0, np; uint64_t c0, cw; size_t w[2]; size_t scale_off, out_off; };
     std::vector<Job> jobs;
     size_t out_words = 0;
+    // the reduced openings' descriptor pool (built and UPLOADED before the opened-value kernels are enqueued, see below)
+    struct RLaunch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; };
+    std::vector<RLaunch> launches;
+    DBuf reduce_pool_dev;
+    size_t apw_at = 0, ydesc_at = 0, yoff_at = 0, n_y_slots = 0;
     DBuf out_dev;             // the opened values, canonical words, as k_col_dot_finish leaves them
     uint32_t* out_host = nullptr;  // their pinned landing area: read after the opening's one synchronisation (the end of the FRI commit phase)
     {
@@ -801,6 +806,80 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                 // jobs_dev returns to the pool while the launch is queued: safe, the pool hands a block only to work enqueued later on this stream
             }
         }
+        // The descriptors of the reduced openings need nothing the kernels below compute (the one value-dependent part, Y, is formed on the device
+        // by k_open_y): they are built and uploaded HERE, while the weight kernel runs and BEFORE the column-dot launches fork onto the auxiliary
+        // stream — a copy enqueued behind that join waits for the other queue's signal through the runtime (0.08 ms of a lone proof with the GPU idle).
+        prepare_groups();
+        {
+            // Y = sum_col alpha^col y_col per (matrix, point) is the one part that needs the VALUES: its slot in the descriptors stays empty here and
+            // k_open_y fills it on the device (y_slots: where, and from which col_dot outputs)
+            struct YSlot { size_t pool_off, r, i, p; };
+            std::vector<YSlot> y_slots;
+            // one descriptor per (height, chunk of <= MAX_OPEN_POINTS distinct points); later chunks accumulate into the vector
+            std::vector<uint32_t> pool;  // (a pool of its own: the barycentric pool above is already on its way)
+            for (auto& kv : groups) {
+                Group& g = kv.second;
+                for (uint32_t s0 = 0; s0 < g.zs.size() || s0 == 0; s0 += vk::MAX_OPEN_POINTS_PER_LAUNCH) {
+                    const uint32_t s1 = std::min<uint32_t>((uint32_t)g.zs.size(), s0 + vk::MAX_OPEN_POINTS_PER_LAUNCH);
+                    std::vector<const MatEntry*> live;
+                    size_t max_w = 0;
+                    uint64_t total_width = 0;
+                    for (auto& me : g.mats) {
+                        bool any = false;
+                        for (auto& t : me.pts) any |= std::get<0>(t) >= s0 && std::get<0>(t) < s1;
+                        if (any) { live.push_back(&me); max_w = std::max<size_t>(max_w, me.lde->width); total_width += me.lde->width; }
+                    }
+                    launches.push_back({kv.first, pool.size(), s0 != 0, total_width});
+                    pool.push_back((uint32_t)live.size());
+                    pool.push_back(s1 - s0);
+                    pool.push_back((uint32_t)max_w);
+                    for (uint32_t q = s0; q < s1; q++) put_min_poly(pool, g.zs[q]);
+                    for (size_t col = 0; col < max_w; col++) put_ext(pool, apow[col]);
+                    for (auto* me : live) {
+                        put_ptr(pool, me->lde->data);
+                        put_u64(pool, me->lde->height);
+                        pool.push_back((uint32_t)me->lde->width);
+                        uint32_t cnt = 0;
+                        for (auto& t : me->pts) cnt += std::get<0>(t) >= s0 && std::get<0>(t) < s1;
+                        pool.push_back(cnt);
+                        for (size_t pi = 0; pi < me->pts.size(); pi++) {
+                            auto& t = me->pts[pi];
+                            if (std::get<0>(t) >= s0 && std::get<0>(t) < s1) {
+                                pool.push_back(std::get<0>(t) - s0);
+                                put_ext(pool, std::get<1>(t));
+                                y_slots.push_back({pool.size(), me->r, me->i, pi});
+                                put_ext(pool, Ext5::zero());  // Y: written by k_open_y
+                            }
+                        }
+                    }
+                    if (g.zs.size() <= s1) break;
+                }
+            }
+            // Y of every (matrix, point), on the device: its tables ride in the same upload as the reduce descriptors (one host-to-device copy in the
+            // dependent chain, not four)
+            apw_at = pool.size();
+            for (auto& a : apow) put_ext(pool, a);
+            std::vector<uint32_t> ydesc, yoff;
+            for (auto& ys : y_slots) {
+                yoff.push_back((uint32_t)ydesc.size());
+                ydesc.push_back((uint32_t)ys.pool_off);
+                const size_t n_seg_at = ydesc.size();
+                ydesc.push_back(0);
+                for (auto& j : jobs)
+                    if (j.r == ys.r && j.i == ys.i && (size_t)j.p0 <= ys.p && ys.p < (size_t)(j.p0 + j.np)) {
+                        ydesc.push_back((uint32_t)j.out_off); ydesc.push_back((uint32_t)j.np); ydesc.push_back((uint32_t)(ys.p - (size_t)j.p0));
+                        ydesc.push_back((uint32_t)j.c0); ydesc.push_back((uint32_t)j.cw);
+                        ydesc[n_seg_at]++;
+                    }
+            }
+            ydesc_at = pool.size();
+            pool.insert(pool.end(), ydesc.begin(), ydesc.end());
+            yoff_at = pool.size();
+            pool.insert(pool.end(), yoff.begin(), yoff.end());
+            pool.push_back(0);
+            n_y_slots = y_slots.size();
+            reduce_pool_dev = DBuf(&c, pool);
+        }
         out_dev = DBuf(&c, out_words + 4);
         std::vector<DBuf> partials;
         Section open_section(&c);
@@ -826,7 +905,6 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
             }
             out_host = open_pinned_;
         }
-        prepare_groups();  // host work beside the kernels just enqueued
     }
     res.ms_values = ms_since(t0);
 
@@ -835,76 +913,8 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     std::map<unsigned, DBuf> ro;  // log_height -> pair-layout vector
     unsigned log_max = 0;
     {
-        // Y = sum_col alpha^col y_col per (matrix, point) is the one part that needs the VALUES: its slot in the descriptors stays empty here and
-        // k_open_y fills it on the device (y_slots: where, and from which col_dot outputs)
-        struct YSlot { size_t pool_off, r, i, p; };
-        std::vector<YSlot> y_slots;
-        // one descriptor per (height, chunk of <= MAX_OPEN_POINTS distinct points); later chunks accumulate into the vector
-        struct Launch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; };
-        std::vector<Launch> launches;
-        std::vector<uint32_t> pool;
-        for (auto& kv : groups) {
-            Group& g = kv.second;
-            for (uint32_t s0 = 0; s0 < g.zs.size() || s0 == 0; s0 += vk::MAX_OPEN_POINTS_PER_LAUNCH) {
-                const uint32_t s1 = std::min<uint32_t>((uint32_t)g.zs.size(), s0 + vk::MAX_OPEN_POINTS_PER_LAUNCH);
-                std::vector<const MatEntry*> live;
-                size_t max_w = 0;
-                uint64_t total_width = 0;
-                for (auto& me : g.mats) {
-                    bool any = false;
-                    for (auto& t : me.pts) any |= std::get<0>(t) >= s0 && std::get<0>(t) < s1;
-                    if (any) { live.push_back(&me); max_w = std::max<size_t>(max_w, me.lde->width); total_width += me.lde->width; }
-                }
-                launches.push_back({kv.first, pool.size(), s0 != 0, total_width});
-                pool.push_back((uint32_t)live.size());
-                pool.push_back(s1 - s0);
-                pool.push_back((uint32_t)max_w);
-                for (uint32_t q = s0; q < s1; q++) put_min_poly(pool, g.zs[q]);
-                for (size_t col = 0; col < max_w; col++) put_ext(pool, apow[col]);
-                for (auto* me : live) {
-                    put_ptr(pool, me->lde->data);
-                    put_u64(pool, me->lde->height);
-                    pool.push_back((uint32_t)me->lde->width);
-                    uint32_t cnt = 0;
-                    for (auto& t : me->pts) cnt += std::get<0>(t) >= s0 && std::get<0>(t) < s1;
-                    pool.push_back(cnt);
-                    for (size_t pi = 0; pi < me->pts.size(); pi++) {
-                        auto& t = me->pts[pi];
-                        if (std::get<0>(t) >= s0 && std::get<0>(t) < s1) {
-                            pool.push_back(std::get<0>(t) - s0);
-                            put_ext(pool, std::get<1>(t));
-                            y_slots.push_back({pool.size(), me->r, me->i, pi});
-                            put_ext(pool, Ext5::zero());  // Y: written by k_open_y
-                        }
-                    }
-                }
-                if (g.zs.size() <= s1) break;
-            }
-        }
-        // Y of every (matrix, point), on the device: its tables ride in the same upload as the reduce descriptors (one host-to-device copy in the
-        // dependent chain, not four)
-        const size_t apw_at = pool.size();
-        for (auto& a : apow) put_ext(pool, a);
-        std::vector<uint32_t> ydesc, yoff;
-        for (auto& ys : y_slots) {
-            yoff.push_back((uint32_t)ydesc.size());
-            ydesc.push_back((uint32_t)ys.pool_off);
-            const size_t n_seg_at = ydesc.size();
-            ydesc.push_back(0);
-            for (auto& j : jobs)
-                if (j.r == ys.r && j.i == ys.i && (size_t)j.p0 <= ys.p && ys.p < (size_t)(j.p0 + j.np)) {
-                    ydesc.push_back((uint32_t)j.out_off); ydesc.push_back((uint32_t)j.np); ydesc.push_back((uint32_t)(ys.p - (size_t)j.p0));
-                    ydesc.push_back((uint32_t)j.c0); ydesc.push_back((uint32_t)j.cw);
-                    ydesc[n_seg_at]++;
-                }
-        }
-        const size_t ydesc_at = pool.size();
-        pool.insert(pool.end(), ydesc.begin(), ydesc.end());
-        const size_t yoff_at = pool.size();
-        pool.insert(pool.end(), yoff.begin(), yoff.end());
-        pool.push_back(0);
-        DBuf pool_dev(&c, pool);
-        vk::launch_open_y(c.stream, out_dev.data, pool_dev.data + apw_at, pool_dev.data + ydesc_at, pool_dev.data + yoff_at, (uint32_t)y_slots.size(), pool_dev.data);
+        DBuf& pool_dev = reduce_pool_dev;
+        vk::launch_open_y(c.stream, out_dev.data, pool_dev.data + apw_at, pool_dev.data + ydesc_at, pool_dev.data + yoff_at, (uint32_t)n_y_slots, pool_dev.data);
         for (auto& kv : groups) { ro[kv.first] = DBuf(&c, (size_t)(5ull << kv.first)); log_max = std::max(log_max, kv.first); }
         Section reduce_section(&c);
         std::map<unsigned, hipStream_t> stream_of;  // chunks of one height must stay on one stream (they accumulate in order)
