@@ -513,3 +513,18 @@ def test_bench_prices_the_poseidon_kernels_with_the_kernels_own_instruction_mode
     bench = open(os.path.join(ROOT, "bench.py")).read()
     b = re.search(r"POSEIDON_HALF_PER_PERM, POSEIDON_FULL_PER_PERM = (\d+), (\d+)", bench)
     assert (int(b.group(1)), int(b.group(2))) == (int(half), int(full))
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """INTEGRATION.md lists the library's environment switches with the A/B record each one reproduces: a new getenv("VGPU_…") in csrc must
+    come with its row."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for path in glob.glob(os.path.join(root, "valida_amd", "csrc", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.rsplit(".", 1)[-1] in ("hip", "hpp", "cpp", "h"):
+            found |= set(re.findall(r'getenv\("(VGPU_[A-Z0-9_]+)"\)', open(path, errors="replace").read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(v for v in found if v not in doc)
+    assert found and not missing, missing
