@@ -17,6 +17,7 @@ the ranks finish by proving one segment TOGETHER through vgpu_prove_sharded (RCC
 import argparse
 import json
 import os
+import hashlib
 import sys
 import time
 
@@ -26,7 +27,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Fibonacci loop bound giving 17 + 7n = 2^20 - 1 executed cycles.
-SCALAR_PORT_SECONDS = {20: 61.7}  # BENCH_r03.json: cpu_baseline.seconds_per_proof of the scalar oracle on the driver's box
 FIB_N = {22: 599183, 20: 149794, 19: 74895, 18: 37446, 17: 18722, 16: 9359, 14: 2338, 12: 582}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -160,7 +160,7 @@ def roofline_object(name, stat, achieved_gbs, traffic, traffic_src, valu, steps)
                 peak_is=valu.get("peak_is"), hbm=hbm)
 
 
-def cpu_baseline(log_rows, rc, headline_log_rows, mmcs_poseidon=False):
+def cpu_baseline(log_rows, rc, headline_log_rows, mmcs_poseidon=False, scalar_too=False):
     """The oracle (CPU restatement of the reference's algorithm, C++/OpenMP on every host core) timed on the SAME workload the GPU
     is timed on — the headline 2^20-row segment itself by default, one proof, no extrapolation — in its FAST mode (oracle/fast.hpp: AVX2
     8-wide Montgomery BabyBear transforms with precomputed twiddles, a four-way AVX2 Keccak, batch inversions, constraint folding with
@@ -187,10 +187,14 @@ def cpu_baseline(log_rows, rc, headline_log_rows, mmcs_poseidon=False):
         "sample": "oracle in fast mode (C++/OpenMP + AVX2 restatement, not Plonky3; a process of its own) proving ONE fib segment with 2^%d cpu rows (mem 2^%d) in %.1f s on %d host cores"
                   % (log_rows, log_rows + 2, seconds, cores),
         "proof_sha256": got["sha256"],
-        "scalar_port_seconds_per_proof": SCALAR_PORT_SECONDS.get(log_rows),
-        "scalar_port_note": "the same oracle in its scalar `% p` mode (the checker the parity tests use) on this workload, 16 host cores, as measured by the round-3 driver run "
-                            "(BENCH_r03.json); not re-timed in this run",
     }
+    if scalar_too:  # --scalar-baseline: the same oracle in its scalar `% p` mode (the checker the parity tests use), re-timed in THIS run (about a minute)
+        r2 = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(FIB_N[log_rows]), "scalar"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=3600)
+        if r2.returncode == 0:
+            g2 = json.loads(r2.stdout.strip().splitlines()[-1])
+            out["scalar_port"] = {"seconds_per_proof": g2["seconds"], "cores": g2["cores"], "proof_sha256": g2["sha256"], "same_proof_as_fast_mode": g2["sha256"] == got["sha256"]}
+        else:
+            out["scalar_port"] = {"error": r2.stderr[-300:]}
     if log_rows != headline_log_rows:  # a smaller sample was asked for: say so, and give the linear-in-rows estimate separately
         out["note"] = "sample is 2^%d rows, not the 2^%d-row workload of `value`; linear scaling would give %.4f proofs/s" % (
             log_rows, headline_log_rows, 1.0 / (seconds * (1 << (headline_log_rows - log_rows))))
@@ -248,6 +252,7 @@ def main():
     ap.add_argument("--log-rows", type=int, default=20, help="log2 of the padded CPU-chip height (20 = the headline workload)")
     ap.add_argument("--cpu-log-rows", type=int, default=None, help="size of the CPU-baseline proof (default: the workload's own size, capped at 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scalar-baseline", action="store_true", help="also time the oracle's scalar mode in this run (about a minute more); nothing is reported about it otherwise")
     ap.add_argument("--inflight", type=int, default=3,
                     help="proofs in flight per GPU: M prover contexts (own HIP streams and pool), one asynchronous proof outstanding on each "
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
@@ -753,12 +758,17 @@ def main():
                 "copies): what sharding costs, not a speed-up; row_range_inputs = vgpu_prove_sharded_rows_local, the traces themselves sharded; the multi-GPU realisation (vgpu_prove_sharded over RCCL) is unmeasured here")),
             "prover_ms_single_proof_in_flight": single if single is not None else ms_per_step,
             "proof_words": int(p.words.size),
+            "proof_sha256": hashlib.sha256(p.bytes()).hexdigest(),  # the LAST proof of the timed region (the one vgpu_verify checks below)
             "proof_checked_by_vgpu_verify": verified,  # Machine::verify of the library (host) on the last timed proof
             "hbm_pool_peak_bytes": sum(p_.memory()[1] for p_ in provers),
         }
         if not args.no_cpu_baseline and world == 1:
             headline = min(args.log_rows, 20)
-            out["cpu_baseline"] = cb = cpu_baseline(args.cpu_log_rows if args.cpu_log_rows else headline, rc, args.log_rows, mmcs_poseidon=args.mmcs == "poseidon")
+            out["cpu_baseline"] = cb = cpu_baseline(args.cpu_log_rows if args.cpu_log_rows else headline, rc, args.log_rows, mmcs_poseidon=args.mmcs == "poseidon",
+                                                    scalar_too=args.scalar_baseline)
+            # north_star: "bit-identical proof bytes ... in the same run" — the CPU leg proved rank 0's own segment (same loop bound, same constants), so
+            # the two hashes are over the same statement; null when the CPU sample is a smaller segment than the workload
+            out["same_proof_as_cpu_baseline"] = (cb["proof_sha256"] == out["proof_sha256"]) if "note" not in cb and args.workload == "c2" else None
             if "note" not in cb and args.workload == "c2":  # the baseline proved the very workload `value` is quoted on
                 # BASELINE.md publishes no number; its one quantitative target is ">= 20x the CPU baseline timed in the same run" (section 2):
                 # that ratio, against what the baseline IS here (kind "port": scalar restatement, not Plonky3's packed AVX prover)

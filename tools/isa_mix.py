@@ -68,7 +68,8 @@ def main():
                 nm = re.search(r"\.symbol:\s+(\S+)\.kd", blk)
                 if nm:
                     g = lambda k: (re.search(r"\.%s:\s+(\d+)" % k, blk) or [None, "?"])[1]
-                    meta[nm.group(1)] = dict(vgpr=g("vgpr_count"), sgpr=g("sgpr_count"), lds=g("group_segment_fixed_size"), scratch=g("private_segment_fixed_size"))
+                    meta[nm.group(1)] = dict(vgpr=g("vgpr_count"), sgpr=g("sgpr_count"), lds=g("group_segment_fixed_size"), scratch=g("private_segment_fixed_size"),
+                                             sspill=g("sgpr_spill_count"), vspill=g("vgpr_spill_count"), wgmax=g("max_flat_workgroup_size"))
             syms = re.findall(r"^[0-9a-f]+ <(\S+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M)
             dm = demangle([s for s, _ in syms])
             for sym, body in syms:
@@ -97,15 +98,28 @@ def main():
                         if best[0] <= addr <= best[1]:
                             c = classify(mn)
                             loop[c] = loop.get(c, 0) + 1
-                rows.append((base, short(dm.get(sym, sym)), len(ins), cls, loop, meta.get(sym, {})))
-    out = ["# tools/isa_mix.py — static instruction mix of the gfx950 code objects of valida_amd/csrc/kernels/*.hip (hipcc -O3, llvm-objdump -d)",
+                m = dict(meta.get(sym, {}))
+                # SGPRs spilled into VGPR lanes show as v_writelane / v_readlane pairs (the kernel descriptor's sgpr_spill_count counts the spilled registers)
+                m["lanemov"] = sum(1 for _, mn, _ in ins if mn.startswith(("v_writelane", "v_readlane")))
+                # waves per SIMD the register file allows: 512 VGPRs per lane per SIMD, allocated in blocks of 8, at most 8 waves (gfx950; AGPRs unused here);
+                # a workgroup of `wgmax` threads must fit as a whole (wgmax / 64 waves over 4 SIMDs)
+                try:
+                    v = (int(m["vgpr"]) + 7) // 8 * 8
+                    m["waves"] = min(8, 512 // max(v, 8))
+                except (KeyError, ValueError):
+                    m["waves"] = "?"
+                rows.append((base, short(dm.get(sym, sym)), len(ins), cls, loop, m))
+    out = ["# sspill / vspill = the kernel descriptor's sgpr_spill_count / vgpr_spill_count; lanemov = v_writelane + v_readlane instructions (SGPRs parked in VGPR lanes);",
+           "# waves = waves per SIMD the VGPR count allows (512 / round-up-to-8(vgpr), at most 8); scratch = private segment bytes per lane; lds_B = STATIC LDS only (dynamic LDS is set at launch)",
+           "# tools/isa_mix.py — static instruction mix of the gfx950 code objects of valida_amd/csrc/kernels/*.hip (hipcc -O3, llvm-objdump -d)",
            "# VALU classes by issue rate as measured in profiles/r02_microbench.txt; loop = the LARGEST backward-branch loop body of the kernel",
-           "%-14s %-58s %6s | %5s %5s %5s %5s %5s %5s %5s | loop: %5s %5s %5s %5s | %4s %4s %6s %7s" % ("file", "kernel", "instr", "vfull", "vhalf", "mfma", "lds", "vmem", "salu", "sync", "vfull", "vhalf", "lds", "vmem",
-                                                                                                         "vgpr", "sgpr", "lds_B", "scratch")]
+           "%-14s %-58s %6s | %5s %5s %5s %5s %5s %5s %5s | loop: %5s %5s %5s %5s | %4s %4s %6s %7s %6s %6s %7s %5s" % ("file", "kernel", "instr", "vfull", "vhalf", "mfma", "lds", "vmem", "salu", "sync", "vfull", "vhalf", "lds", "vmem",
+                                                                                                         "vgpr", "sgpr", "lds_B", "scratch", "sspill", "vspill", "lanemov", "waves")]
     for base, name, n, cls, loop, m in sorted(rows, key=lambda r: (r[0], -r[2])):
-        out.append("%-14s %-58s %6d | %5d %5d %5d %5d %5d %5d %5d | loop: %5d %5d %5d %5d | %4s %4s %6s %7s" % (
+        out.append("%-14s %-58s %6d | %5d %5d %5d %5d %5d %5d %5d | loop: %5d %5d %5d %5d | %4s %4s %6s %7s %6s %6s %7s %5s" % (
             base, name[:58], n, cls.get("valu_full", 0), cls.get("valu_half", 0), cls.get("mfma", 0), cls.get("lds", 0), cls.get("vmem", 0), cls.get("salu", 0), cls.get("sync", 0),
-            loop.get("valu_full", 0), loop.get("valu_half", 0), loop.get("lds", 0), loop.get("vmem", 0), m.get("vgpr", "?"), m.get("sgpr", "?"), m.get("lds", "?"), m.get("scratch", "?")))
+            loop.get("valu_full", 0), loop.get("valu_half", 0), loop.get("lds", 0), loop.get("vmem", 0), m.get("vgpr", "?"), m.get("sgpr", "?"), m.get("lds", "?"), m.get("scratch", "?"),
+            m.get("sspill", "?"), m.get("vspill", "?"), m.get("lanemov", "?"), m.get("waves", "?")))
     text = "\n".join(out) + "\n"
     if len(sys.argv) > 1:
         open(sys.argv[1], "w").write(text)

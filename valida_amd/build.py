@@ -46,11 +46,17 @@ def _all_headers():
     return out
 
 
+LAST = {"compiled": [], "reused": [], "linked": False}  # what the last build_vgpu() call did (printed by __graft_entry__.build)
+_FORCE = False
+
+
 def _compile(src):
     obj = os.path.join(BUILD, src.replace("/", "_") + ".o")
     path = os.path.join(CSRC, src)
-    if _newer_than(obj, [path] + _all_headers()):
+    if not _FORCE and _newer_than(obj, [path] + _all_headers()):
+        LAST["reused"].append(src)
         return obj
+    LAST["compiled"].append(src)
     cmd = ["hipcc"] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -59,16 +65,23 @@ def _compile(src):
 
 
 def build_vgpu(force=False):
+    """Returns the library's path.  force=True recompiles every source (hipcc --offload-arch=gfx950) and relinks; otherwise objects newer
+    than their source and every header are reused.  LAST records which of the two happened to each source."""
+    global _FORCE
     os.makedirs(BUILD, exist_ok=True)
+    LAST["compiled"], LAST["reused"], LAST["linked"] = [], [], False
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and _newer_than(LIB, srcs + _all_headers()):
+        LAST["reused"] = list(SOURCES)
         return LIB
+    _FORCE = bool(force)
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(_compile, SOURCES))
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]  # librccl.so is dlopen'ed on first use (host/comm.hpp)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
+    LAST["linked"] = True
     return LIB
 
 
