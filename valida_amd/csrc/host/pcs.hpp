@@ -202,9 +202,19 @@ inline DMat coset_lde(DeviceCtx* c, hipStream_t st, const CommitInput& in, unsig
         DMat lde(c, n * b, in.mat->width);
         const vk::LdeTables lt = c->lde_tables((int)k, (int)log_blowup, lde_shift);
         DMat s1, s2;
-        if (k > 12) { s1 = DMat(c, n, in.mat->width); s2 = DMat(c, n * b, in.mat->width); }
-        vk::launch_lde_natural(st, in.mat->view(), lde.view(), (int)log_blowup, c->tables, lt, s1.empty() ? vk::DMatView{nullptr, 0, 0, 0} : s1.view(),
-                               s2.empty() ? vk::DMatView{nullptr, 0, 0, 0} : s2.view());
+        // VGPU_LDE_GROUP_MB=m (experiment, off by default): the three passes run column group after column group, the groups sized so that the two
+        // scratch matrices of one group (S1: n, S2: b n words per column) take about m MiB and are REUSED by every group — passes B and C then
+        // read what the pass before has just written (256 MiB Infinity Cache), and the scratch lines are overwritten before they are written back.
+        static const uint64_t group_mb = [] { const char* e = getenv("VGPU_LDE_GROUP_MB"); return e ? (uint64_t)atoll(e) : 0ull; }();
+        uint64_t gcols = in.mat->width;
+        if (k > 12 && group_mb) gcols = std::max<uint64_t>(1, std::min<uint64_t>(gcols, (group_mb << 20) / (n * 4 * (1 + b))));
+        if (k > 12) { s1 = DMat(c, n, gcols); s2 = DMat(c, n * b, gcols); }
+        for (uint64_t c0 = 0; c0 < in.mat->width; c0 += gcols) {
+            const uint64_t w = std::min<uint64_t>(gcols, in.mat->width - c0);
+            const vk::DMatView nat{in.mat->data + c0 * n, n, w, n}, out{lde.data + c0 * n * b, n * b, w, n * b};
+            vk::launch_lde_natural(st, nat, out, (int)log_blowup, c->tables, lt, s1.empty() ? vk::DMatView{nullptr, 0, 0, 0} : vk::DMatView{s1.data, n, w, n},
+                                   s2.empty() ? vk::DMatView{nullptr, 0, 0, 0} : vk::DMatView{s2.data, n * b, w, n * b});
+        }
         c->check_launch("coset_lde");
         return lde;  // s1 / s2 return to the pool while the kernels may still be queued: safe for the same reason as `coeffs` below
     }
@@ -268,6 +278,14 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
             if (tallest != (pass == 0)) continue;
             Fp shift = coset_shifts ? g * (*coset_shifts)[i].inv() : g;
             hipStream_t st = overlap ? (tallest ? c->stream : c->aux[0]) : c->stream_for(i, mats[i].mat->height);
+#if VGPU_STANDIN_FUSE
+            {  // experiment build: this matrix's share of the row hashes of its height group (a row of W_h elements costs W_h / 34 + 1 permutations)
+                uint64_t wh = 0;
+                for (auto& m2 : mats) if (m2.mat->height == mats[i].mat->height) wh += m2.mat->width;
+                const bool big = (mats[i].mat->height << fri.log_blowup) > 65536 && c->hash_kind == 0;
+                vk::g_standin_perms_per_elem = big && wh ? (double)(wh / 34 + 1) / (double)wh : 0.0;
+            }
+#endif
             pd->ldes[i] = coset_lde(c, st, mats[i], fri.log_blowup, shift);
         }
     std::vector<vk::DMatView> views;

@@ -57,6 +57,36 @@ __device__ __forceinline__ vg::Fp eval_vcol(const uint32_t* __restrict__ w, uint
     }
     return acc;
 }
+// The same with the row given as a 32-bit BYTE offset into every column.  The column's base (data + col * stride) is wave-uniform: the load is a
+// raw BUFFER load — resource = that base in four SGPRs (scalar ALU), the lane's offset one VGPR shared by every load of the point — instead of a
+// 64-bit per-lane address per load (two v_mad_u64_u32 / v_lshl_add_u64 each, and a VGPR pair held per load in flight).  A plain pointer sum does
+// not get there: LLVM re-associates (base + offset) into a per-lane pointer first.  LDE heights are at most 2^27 rows (the field's two-adicity),
+// so the offset is below the resource's 2^31-byte range.
+#ifndef VGPU_QUOT_SADDR
+#define VGPU_QUOT_SADDR 1  // 0: plain pointer arithmetic (A/B builds)
+#endif
+__device__ __forceinline__ uint32_t load_at(const uint32_t* ubase, uint32_t byte_off) {
+#if VGPU_QUOT_SADDR && defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ubase), 0, 0x7fffffff, 0x00020000);  // raw buffer, no swizzle, dword format
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
+#else  // A/B builds, and the host pass of hipcc (which parses device functions without the amdgcn builtins)
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ubase) + byte_off);
+#endif
+}
+__device__ __forceinline__ vg::Fp eval_vcol_at(const uint32_t* __restrict__ w, uint32_t& pos, const uint32_t* main, uint64_t mstride,
+                                               const uint32_t* prep, uint64_t pstride, uint32_t byte_off) {
+    uint32_t nt = w[pos];
+    vg::Fp acc = vg::Fp::raw(w[pos + 1]);
+    pos += 2;
+    for (uint32_t t = 0; t < nt; t++, pos += 2) {
+        uint32_t cw = w[pos];
+        uint32_t col = cw & 0x7fffffffu;
+        vg::Fp v = vg::Fp::raw((cw >> 31) ? load_at(prep + (uint64_t)col * pstride, byte_off) : load_at(main + (uint64_t)col * mstride, byte_off));
+        const uint32_t wt = w[pos + 1];
+        acc += wt == vg::R_MOD_P ? v : v * vg::Fp::raw(wt);
+    }
+    return acc;
+}
 #endif
 
 }  // namespace vk

@@ -46,6 +46,16 @@ struct QuotientArgs {
 };
 
 
+#ifndef VGPU_STANDIN_FUSE
+#define VGPU_STANDIN_FUSE 0
+#endif
+#if VGPU_STANDIN_FUSE
+// EXPERIMENT BUILD ONLY (tools/build_variant.py standin ALL -DVGPU_STANDIN_FUSE=1; profiles/r05_ab_fuse_standin.*): the gate of "fuse the leaf hash into the
+// last LDE pass".  The last pass of every big LDE (k_lde_c, k_ntt_contig) runs, per workgroup, as many Keccak permutations over words of its LDS tile as the
+// rows its elements stand for would cost, and the Merkle launches skip exactly that work (leaf launch of big trees; the row hash of big injecting layers
+// reads a ready digest instead).  The proofs of such a build are WRONG; only its timing is of interest.
+extern thread_local double g_standin_perms_per_elem;  // set by commit_batches before each coset_lde: permutations per LDE element of the matrix being extended (0: none)
+#endif
 // layout.hip
 void launch_ingest(hipStream_t st, const uint32_t* src_dev, DMatView dst, bool bitrev);
 void launch_bitrev_rows(hipStream_t st, DMatView src, DMatView dst);

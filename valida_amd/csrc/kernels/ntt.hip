@@ -20,8 +20,35 @@
 // No MFMA: 31-bit modular butterflies are VALU work.  Measured balance: DESIGN.md "Where the remaining time is".
 #include "launch.hpp"
 #include "butterfly.hpp"
+#if VGPU_STANDIN_FUSE
+#include "keccak.hpp"
+#endif
 
 namespace vk {
+#if VGPU_STANDIN_FUSE
+thread_local double g_standin_perms_per_elem = 0.0;
+static uint32_t* standin_out() {  // 32 bytes per stood-in row hash: as many digest bytes as the real leaf layer
+    static uint32_t* p = [] { void* q = nullptr; (void)hipMalloc(&q, (size_t)1 << 30); return (uint32_t*)q; }();
+    return p;
+}
+// `perms` single-block row hashes per workgroup over the (Montgomery) words of its LDS tile: canonical form, absorb 34 words, permute, squeeze, store 32 bytes
+__device__ __forceinline__ void standin_hashes(const uint32_t* lds, int tile_words, int perms, uint32_t* out, uint64_t wg_linear) {
+    for (int j = threadIdx.x; j < perms; j += blockDim.x) {
+        KState a;
+        kstate_zero(a);
+#pragma unroll
+        for (int kk = 0; kk < 34; kk++) {
+            int idx = kk * (int)blockDim.x + j;
+            idx = idx % tile_words;
+            absorb_word(a, kk, Fp::raw(lds[idx]).canonical());
+        }
+        keccak_f1600<true>(a);
+        uint32_t* o = out + (((wg_linear * (uint64_t)perms + (uint64_t)j) * 8) & (((uint64_t)1 << 28) - 8));
+        reinterpret_cast<uint4*>(o)[0] = make_uint4(a.lo[0], a.hi[0], a.lo[1], a.hi[1]);
+        reinterpret_cast<uint4*>(o)[1] = make_uint4(a.lo[2], a.hi[2], a.lo[3], a.hi[3]);
+    }
+}
+#endif
 
 // Contiguous tiles (T = 1) are stored padded: word i at i + (i >> 4), so the stride-16 accesses of the
 // last round are bank-conflict free.  Strided tiles use element (h, c) at h * LD + c with LD = T + 1.
@@ -328,7 +355,11 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
 // DIF over each contiguous block of N_lo points of `dst` rows [dst_row0, dst_row0 + N).  When the whole
 // transform fits one pass (k_hi == 0) the input is read from `src` and multiplied by shift^i first.
 __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, DeviceTables tb, uint32_t shift_mont,
-                             int from_src) {
+                             int from_src
+#if VGPU_STANDIN_FUSE
+                             , int standin_perms, uint32_t* standin_o
+#endif
+                             ) {
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo;
     const uint32_t* tw = tb.twc;
@@ -351,6 +382,9 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
         if (!from_src && t + gridDim.x < total) prefetch_tile(pre, tile_ptr(t + gridDim.x), n_lo);
         tile_transform<false, true>(lds, tw, k_lo, 0, 0);
         for (int i = threadIdx.x; i < n_lo; i += blockDim.x) out[i] = lds[tile_addr<true>(i, 0, 0)];
+#if VGPU_STANDIN_FUSE
+        if (standin_perms > 0) standin_hashes(lds, n_lo, standin_perms, standin_o, t);
+#endif
         __syncthreads();
     }
 }
@@ -628,7 +662,11 @@ __global__ void __launch_bounds__(1024) k_lde_mid14(DMatView src, DMatView dst, 
 }
 
 // ---- pass C: forward, strided, transposing store: grid = (n_lo / T, columns, cosets) --------------------
-__global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int logT, DeviceTables tb) {
+__global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int logT, DeviceTables tb
+#if VGPU_STANDIN_FUSE
+                        , int standin_perms, uint32_t* standin_o
+#endif
+                        ) {
     extern __shared__ uint32_t lds[];
     const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
     const uint64_t n_lo = 1ull << k_lo, N = 1ull << k, q0 = (uint64_t)strided_tile_of_block(blockIdx.x, gridDim.x) * T;
@@ -666,6 +704,9 @@ __global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int
         const uint32_t qb = __brev((uint32_t)(q0 + c)) >> (32 - k_lo);
         out[(uint64_t)qb * n_hi + p2] = lds[p2 * LD + c];
     }
+#if VGPU_STANDIN_FUSE
+    if (standin_perms > 0) standin_hashes(lds, n_hi * LD, standin_perms, standin_o, ((uint64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+#endif
 }
 
 // ---- host launchers -----------------------------------------------------------------------------------
@@ -750,10 +791,18 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
             VK_LAUNCH(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, cp);
         }
         ProfScope ps("k_ntt_contig", st, pass_bytes);
+#if VGPU_STANDIN_FUSE
+        VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0, (int)((double)(1u << p.k_lo) * g_standin_perms_per_elem + 0.5), standin_out());
+#else
         VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0);
+#endif
     } else {
         ProfScope ps("k_ntt_contig", st, pass_bytes);
+#if VGPU_STANDIN_FUSE
+        VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1, 0, standin_out());
+#else
         VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1);
+#endif
     }
 }
 
@@ -793,7 +842,11 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
     }
     dim3 gc((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)nat.width, 1u << log_blowup);
     ProfScope ps("k_lde_c", st, 2.0 * nw * b);
+#if VGPU_STANDIN_FUSE
+    VK_LAUNCH(k_lde_c, gc, dim3(p.threads_strided), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb, (int)((double)((1u << p.k_hi) << p.logT) * g_standin_perms_per_elem + 0.5), standin_out());
+#else
     VK_LAUNCH(k_lde_c, gc, dim3(p.threads_strided), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb);
+#endif
 }
 
 }  // namespace vk

@@ -98,22 +98,40 @@ __device__ __forceinline__ Ext5 run_program_lds(const QuotientArgs& a, const Poi
 // becomes straight-line VALU code with column loads the compiler schedules and CSEs — no interpretation.
 // assert_zero(c_k) accumulates alpha^(K-1-k) * c_k LAZILY: five v_mad_u64_u32 per constraint into 64-bit limb
 // accumulators, one Montgomery reduction per limb for every four constraints (4 p^2 < 2^64).
+#ifndef VGPU_QUOT_SADDR
+#define VGPU_QUOT_SADDR 1  // 1: column loads as uniform base (SGPR pair: data + col * stride) + the point's 32-bit byte offset (global_load ... v_off, s[base]); 0: 64-bit per-lane addresses (A/B)
+#endif
 struct DeviceFolder {
     using Expr = Fp;
+#if VGPU_QUOT_SADDR
+    const uint32_t* __restrict__ main_p;  // main LDE column 0 (wave-uniform) for the local row / the next row; the point's rows as byte offsets
+    const uint32_t* __restrict__ main_n;
+    uint64_t mstride;
+    const uint32_t* __restrict__ prep_p;
+    const uint32_t* __restrict__ prep_n;
+    uint64_t pstride;
+    uint32_t roff, noff;
+#else
     const uint32_t* __restrict__ main_p;  // main LDE column 0 at this point's local row / next row
     const uint32_t* __restrict__ main_n;
     uint64_t mstride;
     const uint32_t* __restrict__ prep_p;
     const uint32_t* __restrict__ prep_n;
     uint64_t pstride;
+#endif
     Fp first, last, trans;
     const uint32_t* __restrict__ apow;  // alpha powers, 5 words per constraint (wave-uniform: scalar loads)
     uint64_t t[5];
     Ext5 total;
     int k, pending;
     __device__ __forceinline__ Fp constant(uint32_t c) const { return Fp::from_canonical(c); }
+#if VGPU_QUOT_SADDR
+    __device__ __forceinline__ Fp main(int col, bool next) const { return Fp::raw(load_at((next ? main_n : main_p) + (uint64_t)col * mstride, next ? noff : roff)); }
+    __device__ __forceinline__ Fp preprocessed(int col, bool next) const { return Fp::raw(load_at((next ? prep_n : prep_p) + (uint64_t)col * pstride, next ? noff : roff)); }
+#else
     __device__ __forceinline__ Fp main(int col, bool next) const { return Fp::raw((next ? main_n : main_p)[(uint64_t)col * mstride]); }
     __device__ __forceinline__ Fp preprocessed(int col, bool next) const { return Fp::raw((next ? prep_n : prep_p)[(uint64_t)col * pstride]); }
+#endif
     __device__ __forceinline__ Fp is_first_row() const { return first; }
     __device__ __forceinline__ Fp is_last_row() const { return last; }
     __device__ __forceinline__ Fp is_transition() const { return trans; }
@@ -135,8 +153,14 @@ template <int CHIP>
 __device__ __forceinline__ Ext5 run_native(const QuotientArgs& a, const PointCtx& p) {
     if (CHIP < 0) return Ext5::zero();
     DeviceFolder f;
+#if VGPU_QUOT_SADDR
+    f.main_p = a.main_lde.data; f.main_n = a.main_nx; f.mstride = a.main_lde.stride;
+    f.prep_p = a.prep_lde.data; f.prep_n = a.prep_nx; f.pstride = a.prep_lde.stride;
+    f.roff = (uint32_t)p.row * 4u; f.noff = (uint32_t)p.next_row * 4u;  // LDE heights <= 2^27 rows (the field's two-adicity): the byte offset fits 32 bits
+#else
     f.main_p = a.main_lde.data + p.row; f.main_n = a.main_nx + p.next_row; f.mstride = a.main_lde.stride;
     f.prep_p = a.prep_lde.data + p.row; f.prep_n = a.prep_nx + p.next_row; f.pstride = a.prep_lde.stride;
+#endif
     f.first = p.is_first; f.last = p.is_last; f.trans = p.is_trans;
     f.apow = a.consts;
     f.total = Ext5::zero();
@@ -149,6 +173,12 @@ __device__ __forceinline__ Ext5 run_native(const QuotientArgs& a, const PointCtx
 }
 
 // eval_permutation_constraints at one point: M reciprocal constraints + transition/first/last.
+__device__ __forceinline__ Ext5 load_ext_at(const uint32_t* ubase, uint64_t stride, uint32_t byte_off) {
+    Ext5 e;
+#pragma unroll
+    for (int k = 0; k < 5; k++) e.c[k] = Fp::raw(load_at(ubase + (uint64_t)k * stride, byte_off));
+    return e;
+}
 __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const PointCtx& p) {
     const uint32_t* iw = a.iw;
     const uint32_t M = iw[0], maxf = iw[1];
@@ -157,21 +187,22 @@ __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const Po
     const uint32_t* betas = bus + 5 * M;
     const Ext5 cumulative_sum = ext_from_words(betas + 5 * maxf);
     Ext5 acc = Ext5::zero(), rhs = Ext5::zero(), phi_0 = Ext5::zero();
+    const uint32_t roff = (uint32_t)p.row * 4u, noff = (uint32_t)p.next_row * 4u;  // every column base below is wave-uniform: loads are base (SGPRs) + this offset
     for (uint32_t m = 0; m < M; m++) {
         uint32_t pos = iw[2 + m];
         const bool is_send = iw[pos] != 0;
         const uint32_t nf = iw[pos + 1];
         pos += 2;
         uint32_t pos_n = pos;
-        Fp mult_local = eval_vcol(iw, pos, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, p.row);
-        Fp mult_next = eval_vcol(iw, pos_n, a.main_nx, a.main_lde.stride, a.prep_nx, a.prep_lde.stride, p.next_row);
+        Fp mult_local = eval_vcol_at(iw, pos, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, roff);
+        Fp mult_next = eval_vcol_at(iw, pos_n, a.main_nx, a.main_lde.stride, a.prep_nx, a.prep_lde.stride, noff);
         // rlc = alpha_bus + sum_j beta^j f_j: Ext5 x base products accumulated four at a time per limb
         Ext5 rlc = ext_from_words(bus + 5 * m);
         for (uint32_t j0 = 0; j0 < nf; j0 += 4) {
             uint64_t t[5] = {0, 0, 0, 0, 0};
             const uint32_t je = nf - j0 < 4 ? nf - j0 : 4;
             for (uint32_t j = 0; j < je; j++) {
-                Fp f = eval_vcol(iw, pos, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, p.row);
+                Fp f = eval_vcol_at(iw, pos, a.main_lde.data, a.main_lde.stride, a.prep_lde.data, a.prep_lde.stride, roff);
 #pragma unroll
                 for (int c = 0; c < 5; c++) t[c] += (uint64_t)betas[5 * (j0 + j) + c] * f.v;
             }
@@ -179,13 +210,13 @@ __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const Po
             for (int c = 0; c < 5; c++) rlc.c[c] += Fp::raw(vg::monty_reduce_wide(t[c]));
         }
         const uint32_t* pcol = a.perm_lde.data + (uint64_t)(5 * m) * a.perm_lde.stride;
-        Ext5 pl = load_ext(pcol, a.perm_lde.stride, p.row), pn = load_ext(a.perm_nx + (uint64_t)(5 * m) * a.perm_lde.stride, a.perm_lde.stride, p.next_row);
+        Ext5 pl = load_ext_at(pcol, a.perm_lde.stride, roff), pn = load_ext_at(a.perm_nx + (uint64_t)(5 * m) * a.perm_lde.stride, a.perm_lde.stride, noff);
         acc += ext_from_words(apow + 5 * m) * (rlc * pl - Fp::one());  // assert_one_ext(rlc * perm_local[m])
         Ext5 tl = pl * mult_local, tn = pn * mult_next;
         if (is_send) { phi_0 += tl; rhs += tn; } else { phi_0 -= tl; rhs -= tn; }
     }
     const uint32_t* phicol = a.perm_lde.data + (uint64_t)(5 * M) * a.perm_lde.stride;
-    Ext5 phi_local = load_ext(phicol, a.perm_lde.stride, p.row), phi_next = load_ext(a.perm_nx + (uint64_t)(5 * M) * a.perm_lde.stride, a.perm_lde.stride, p.next_row);
+    Ext5 phi_local = load_ext_at(phicol, a.perm_lde.stride, roff), phi_next = load_ext_at(a.perm_nx + (uint64_t)(5 * M) * a.perm_lde.stride, a.perm_lde.stride, noff);
     acc += ext_from_words(apow + 5 * M) * (((phi_next - phi_local) - rhs) * p.is_trans);
     acc += ext_from_words(apow + 5 * (M + 1)) * ((phi_local - phi_0) * p.is_first);
     acc += ext_from_words(apow + 5 * (M + 2)) * ((phi_local - cumulative_sum) * p.is_last);
@@ -289,8 +320,15 @@ __global__ void __launch_bounds__(256) k_quotient(QuotientArgs a, DeviceTables t
 // 0..4) and the odd lane the difference (columns 5..9).  Same successor-closed workgroup tiles as k_quotient — 8 groups x 32 pairs (16 x 16
 // with the natural-order store) — now 512 threads.  One inversion per point instead of one per pair (+37 of some hundreds of products).
 // Values identical to k_quotient's: every parity test runs through it.  VGPU_QUOT_PER_POINT=0 (environment) selects the pair kernel (A/B).
+#ifndef VGPU_QUOT_PT_WAVES
+#define VGPU_QUOT_PT_WAVES 6  // waves per SIMD the register allocation must allow (0: the compiler's choice — 4 for the cpu chip's 105 VGPRs); A/B builds
+#endif
 template <int CHIP>
-__global__ void __launch_bounds__(512) k_quotient_pt(QuotientArgs a, DeviceTables tb) {
+__global__ void __launch_bounds__(512)
+#if VGPU_QUOT_PT_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(VGPU_QUOT_PT_WAVES)))
+#endif
+k_quotient_pt(QuotientArgs a, DeviceTables tb) {
     const uint64_t n = 1ull << a.log_n;
     const uint32_t T = threadIdx.x >> 1, pt = threadIdx.x & 1u;  // the pair's slot in the workgroup, and which of its two points
     uint64_t m = (uint64_t)blockIdx.x * 256 + T;
