@@ -41,6 +41,7 @@ def _worker(rank, world, store, q, fixture, log_min, sabotage, logdir, fabric_ti
     os.environ["GLOO_SOCKET_IFNAME"] = "lo"  # the container's hostname may not resolve; the ranks share this box
     if sabotage is not None and sabotage[1].startswith("failpoint:"):
         os.environ["VGPU_FAILPOINT"] = "%s@%d" % (sabotage[1].split(":", 1)[1], sabotage[0])
+        os.environ["VGPU_TESTING"] = "1"  # the failpoints are honoured only with this second opt-in
     sys.path.insert(0, ROOT)
     stage = "import"
     try:

@@ -714,6 +714,9 @@ class VgpuFabric(ctypes.Structure):
                 ("all_gather", ALL_GATHER), ("all_to_all", ALL_TO_ALL)]
 
 
+_ABANDONED_FABRICS = []  # fabrics whose callbacks the library gave up on at its deadline: a helper thread of the library may still be INSIDE one of their ctypes thunks, so they live as long as the process
+
+
 class Fabric:
     """A caller-supplied fabric from two Python callables (what a Rust host would write against its own transport):
         all_gather(mine: np.uint32[n]) -> np.uint32[world, n]
@@ -797,14 +800,19 @@ class Fabric:
         chips = (ctypes.c_uint32 * max(1, len(preprocessed)))(*[c for c, _ in preprocessed])
         parr = (ctypes.c_void_p * max(1, len(preprocessed)))(*[t._h for _, t in preprocessed])
         h = ctypes.c_void_p()
-        if full_heights is not None:
-            fh = (ctypes.c_uint64 * len(main))(*[int(x) for x in full_heights])
-            _check(lib().vgpu_prove_sharded_rows_fabric(prover._h, ctypes.byref(self.c), arr, ctypes.c_uint32(len(main)), fh, chips, parr, ctypes.c_uint32(len(preprocessed)),
-                                                        ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
+        try:
+            if full_heights is not None:
+                fh = (ctypes.c_uint64 * len(main))(*[int(x) for x in full_heights])
+                _check(lib().vgpu_prove_sharded_rows_fabric(prover._h, ctypes.byref(self.c), arr, ctypes.c_uint32(len(main)), fh, chips, parr, ctypes.c_uint32(len(preprocessed)),
+                                                            ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
+                return Proof(h)
+            _check(lib().vgpu_prove_sharded_fabric(prover._h, ctypes.byref(self.c), arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)),
+                                                   ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
             return Proof(h)
-        _check(lib().vgpu_prove_sharded_fabric(prover._h, ctypes.byref(self.c), arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)),
-                                               ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
-        return Proof(h)
+        except VgpuError:
+            if self.c.timeout_ms:  # the failure may be a callback abandoned at the deadline: its thunks must stay valid
+                _ABANDONED_FABRICS.append(self)
+            raise
 
 
 def prove_sharded_local(provers, main_traces, preprocessed, log_min_sharded=12, uploaded=None):

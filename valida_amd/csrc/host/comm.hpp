@@ -81,6 +81,33 @@ struct Comm {
     // abort the communicator is gone (`comm` null): every later call on it is refused.
     uint32_t timeout_ms = [] { const char* e = getenv("VGPU_COMM_TIMEOUT_MS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();
     hipEvent_t wait_ev = nullptr;
+    // mark_start(s): an event recorded on `s` just BEFORE a collective is enqueued.  wait() first waits for it without a deadline — what the stream
+    // still had queued ahead of the collective (LDE passes, other kernels: local work that finishes whatever the peers do) is not charged to the
+    // collective — and starts the clock there.  What the deadline still covers by design: the time this rank waits for SLOWER peers to
+    // enter the collective.  timeout_ms must therefore exceed the worst compute skew between ranks (first-proof pool sizing included): seconds, not
+    // milliseconds; bench.py uses 120 s.
+    hipEvent_t start_ev = nullptr;
+    bool start_marked = false;
+    void mark_start(hipStream_t s) {
+        if (!start_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&start_ev, hipEventDisableTiming));
+        VG_HIP_CHECK(hipEventRecord(start_ev, s));
+        start_marked = true;
+    }
+    // staging of the RCCL fabric's all-gathers (fabric.hpp: RcclFabric), owned here so that it outlives the per-proof fabric objects
+    uint32_t* fab_dev = nullptr;
+    uint32_t* fab_host = nullptr;
+    size_t fab_cap = 0;
+    void grow_fabric_staging(size_t n) {
+        if (n <= fab_cap) return;
+        VG_HIP_CHECK(hipSetDevice(ctx->device));
+        VG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (fab_dev) { VG_HIP_CHECK(hipFree(fab_dev)); fab_dev = nullptr; }
+        if (fab_host) { VG_HIP_CHECK(hipHostFree(fab_host)); fab_host = nullptr; }
+        fab_cap = 0;
+        VG_HIP_CHECK(hipMalloc((void**)&fab_dev, n * (size_t)(world + 1) * 4));
+        VG_HIP_CHECK(hipHostMalloc((void**)&fab_host, n * (size_t)(world + 1) * 4));
+        fab_cap = n;
+    }
     Comm(DeviceCtx* c, const ncclUniqueId& id, int rank_, int world_) : ctx(c), rank(rank_), world(world_) {
         if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("comm: bad rank / world");
         VG_HIP_CHECK(hipSetDevice(c->device));
@@ -95,6 +122,9 @@ struct Comm {
         if (coll_buf) (void)hipFree(coll_buf);
         if (coll_host) (void)hipHostFree(coll_host);
         if (wait_ev) (void)hipEventDestroy(wait_ev);
+        if (start_ev) (void)hipEventDestroy(start_ev);
+        if (fab_dev) (void)hipFree(fab_dev);
+        if (fab_host) (void)hipHostFree(fab_host);
         if (comm) (void)RcclApi::get().CommDestroy(comm);
     }
     void require_alive() const {
@@ -104,9 +134,10 @@ struct Comm {
     // one: polls an event and RCCL's asynchronous error state; on an error or at the deadline the communicator is ABORTED (its kernels leave
     // the device, the stream drains) and the call throws.
     void wait(hipStream_t s, uint32_t deadline_ms) {
-        if (!deadline_ms) { VG_HIP_CHECK(hipStreamSynchronize(s)); return; }
+        if (!deadline_ms) { start_marked = false; VG_HIP_CHECK(hipStreamSynchronize(s)); return; }
         if (!wait_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&wait_ev, hipEventDisableTiming));
         VG_HIP_CHECK(hipEventRecord(wait_ev, s));
+        if (start_marked) { start_marked = false; VG_HIP_CHECK(hipEventSynchronize(start_ev)); }  // local work queued ahead of the collective: not the collective's time
         const auto t0 = std::chrono::steady_clock::now();
         auto& api = RcclApi::get();
         for (unsigned spin = 0;; spin++) {
@@ -136,6 +167,7 @@ struct Comm {
         memcpy(coll_host, words, n_words * 4);
         uint32_t* recv = coll_buf + COLL_WORDS;
         VG_HIP_CHECK(hipMemcpyAsync(coll_buf, coll_host, n_words * 4, hipMemcpyHostToDevice, coll_stream));
+        mark_start(coll_stream);
         VG_NCCL_CHECK(RcclApi::get().AllGather(coll_buf, recv, n_words, ncclUint32, comm, coll_stream));
         VG_HIP_CHECK(hipMemcpyAsync(coll_host + COLL_WORDS, recv, n_words * (size_t)world * 4, hipMemcpyDeviceToHost, coll_stream));
         wait(coll_stream, timeout_ms);

@@ -46,9 +46,14 @@ struct FabricTransportFailure : std::runtime_error {
 };
 
 // Test-only fault injection (documented in DESIGN.md §7): VGPU_FAILPOINT="<name>@<rank>" makes the named step throw on that rank, once
-// per process.  Names: fabric_stage (inside the all-to-all's staging, before the status round), fabric_finish (after the exchange).
+// per process — honoured only together with VGPU_TESTING=1 (a second, explicit opt-in: a stray variable in a production environment must
+// not be able to fail proofs).  Names: fabric_stage (inside the all-to-all's staging, before the status round), fabric_finish (after the exchange).
 inline bool fabric_failpoint(const char* name, int rank) {
-    static const std::string spec = [] { const char* e = getenv("VGPU_FAILPOINT"); return std::string(e ? e : ""); }();
+    static const std::string spec = [] {
+        const char* t = getenv("VGPU_TESTING");
+        const char* e = getenv("VGPU_FAILPOINT");
+        return std::string(e && t && t[0] == '1' ? e : "");
+    }();
     if (spec.empty()) return false;
     static bool fired = false;
     if (fired || spec != std::string(name) + "@" + std::to_string(rank)) return false;
@@ -152,6 +157,24 @@ struct Fabric {
 
 struct LocalFabric : Fabric {
     explicit LocalFabric(int w) { world = w; for (int r = 0; r < w; r++) hosted.push_back(r); }
+    // Contexts on DIFFERENT devices (vgpu_prove_sharded_local over several GPUs of one process): the strided device-to-device copies below need
+    // peer access between the two devices, which the library never enabled.  Enabled once per ordered pair; a pair the driver cannot
+    // connect is an error here, not a silent slow path.
+    static void ensure_peer_access(int dev, int peer) {
+        if (dev == peer) return;
+        static std::mutex mu;
+        static std::vector<std::pair<int, int>> done;
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& pr : done) if (pr.first == dev && pr.second == peer) return;
+        int can = 0;
+        VG_HIP_CHECK(hipDeviceCanAccessPeer(&can, dev, peer));
+        if (!can) throw std::runtime_error("hip: fabric: device " + std::to_string(dev) + " cannot access device " + std::to_string(peer) + " (no peer path): use one process per GPU (vgpu_prove_sharded)");
+        VG_HIP_CHECK(hipSetDevice(dev));
+        const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) throw std::runtime_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+        done.emplace_back(dev, peer);
+    }
   protected:
     void ag_transport(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
         out.resize((size_t)world * n);
@@ -164,6 +187,7 @@ struct LocalFabric : Fabric {
         for (auto& p : plan) { p.c->activate(); p.c->sync(); }
         for (int r = 0; r < world; r++)
             for (int s = 0; s < world; s++) {
+                ensure_peer_access(plan[s].c->device, plan[r].c->device);
                 VG_HIP_CHECK(hipSetDevice(plan[s].c->device));
                 copy_matching(plan[r].send[(size_t)s], plan[s].recv[(size_t)r], plan[s].c->stream);
             }
@@ -173,29 +197,14 @@ struct LocalFabric : Fabric {
 
 struct RcclFabric : Fabric {
     Comm* comm;
-    // staging of the all-gathers, grown in ag_stage (before the status round): device [send: cap][recv: cap * world], pinned host of the same shape
-    uint32_t* dev = nullptr;
-    uint32_t* host = nullptr;
-    size_t cap = 0;
-    explicit RcclFabric(Comm* c) : comm(c) { world = c->world; hosted.push_back(c->rank); timeout_ms = c->timeout_ms; grow(64); }
-    ~RcclFabric() override {
-        if (dev) (void)hipFree(dev);
-        if (host) (void)hipHostFree(host);
-    }
+    // The staging of the all-gathers lives in the COMMUNICATOR (Comm::fab_*: device [send: cap][recv: cap * world], pinned host of the same shape) and is
+    // grown in ag_stage, before the status round: a fabric is built per vgpu_prove_sharded call and allocates nothing (hipFree synchronises the whole
+    // device: a per-proof allocation stalled every other proof in flight on it).
+    explicit RcclFabric(Comm* c) : comm(c) { world = c->world; hosted.push_back(c->rank); timeout_ms = c->timeout_ms; c->grow_fabric_staging(64); }
     RcclFabric(const RcclFabric&) = delete;
 
   protected:
-    void grow(size_t n) {
-        if (n <= cap) return;
-        VG_HIP_CHECK(hipSetDevice(comm->ctx->device));
-        VG_HIP_CHECK(hipStreamSynchronize(comm->ctx->stream));
-        if (dev) { VG_HIP_CHECK(hipFree(dev)); dev = nullptr; }
-        if (host) { VG_HIP_CHECK(hipHostFree(host)); host = nullptr; }
-        cap = 0;
-        VG_HIP_CHECK(hipMalloc((void**)&dev, n * (size_t)(world + 1) * 4));
-        VG_HIP_CHECK(hipHostMalloc((void**)&host, n * (size_t)(world + 1) * 4));
-        cap = n;
-    }
+    void grow(size_t n) { comm->grow_fabric_staging(n); }
     void ag_stage(size_t n) override { grow(n ? n : 1); }
     void ag_transport(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
         out.resize((size_t)world * n);
@@ -203,8 +212,12 @@ struct RcclFabric : Fabric {
         comm->require_alive();
         DeviceCtx* c = comm->ctx;
         c->activate();
+        uint32_t* const dev = comm->fab_dev;
+        uint32_t* const host = comm->fab_host;
+        const size_t cap = comm->fab_cap;
         memcpy(host, contrib[0], n * 4);
         VG_HIP_CHECK(hipMemcpyAsync(dev, host, n * 4, hipMemcpyHostToDevice, c->stream));
+        comm->mark_start(c->stream);  // the deadline runs from here, not from whatever the stream still had queued
         VG_NCCL_CHECK(RcclApi::get().AllGather(dev, dev + cap, n, ncclUint32, comm->comm, c->stream));
         VG_HIP_CHECK(hipMemcpyAsync(host + cap, dev + cap, (size_t)world * n * 4, hipMemcpyDeviceToHost, c->stream));
         comm->wait(c->stream, timeout_ms);
@@ -242,6 +255,7 @@ struct RcclFabric : Fabric {
             if (sw[(size_t)s]) sp[(size_t)s] = pack_send[(size_t)s].data ? pack_send[(size_t)s].data : p.send[(size_t)s][0].p;
             if (rw[(size_t)s]) rp[(size_t)s] = pack_recv[(size_t)s].data ? pack_recv[(size_t)s].data : p.recv[(size_t)s][0].p;
         }
+        comm->mark_start(p.c->stream);
         comm->all_to_all_words(sp, sw, rp, rw);
         comm->wait(p.c->stream, timeout_ms);
     }

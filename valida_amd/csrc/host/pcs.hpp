@@ -298,8 +298,13 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
         lde_section.join();
         pd->tree.build(c, views);
     }
-    // the build above synchronised on the main stream, which had waited for the auxiliary stream at the join: the rider's root has landed
-    if (rider) memcpy((*rider->out)->tree.root, c->rider_root_pin, 32);
+    // The rider's root: in the default branch the build above synchronised on the main stream AFTER it had waited for the auxiliary stream at the
+    // join; with VGPU_COMMIT_OVERLAP=1 a round of one height joins only after the build's synchronisation — so the auxiliary stream is
+    // synchronised here in its own right (it has long drained: microseconds).
+    if (rider) {
+        VG_HIP_CHECK(hipStreamSynchronize(c->aux[0]));
+        memcpy((*rider->out)->tree.root, c->rider_root_pin, 32);
+    }
     return pd;
 }
 
