@@ -419,133 +419,144 @@ template <class AB> VAIR_HD void eval_chip(int chip, AB& b) {
 
 // ---- interactions (Chip::all_interactions order: local sends, local receives, global sends,
 //      global receives — machine/src/chip.rs:40-63) --------------------------------------------
-inline std::vector<Interaction> chip_interactions(int chip) {
-    using VC = VirtualCol;
-    std::vector<Interaction> out;
-    auto word = [](std::vector<VC>& f, int first) { for (int i = 0; i < 4; i++) f.push_back(VC::single_main(first + i)); };
-    auto alu_receive = [&](VC opcode, int in1, int in2, int outc, VC count) {
-        Interaction r;
-        r.fields.push_back(opcode);
-        word(r.fields, in1); word(r.fields, in2); word(r.fields, outc);
-        r.count = count; r.bus_kind = BusKind::Global; r.bus_index = BUS_GENERAL; r.type = InteractionType::GlobalReceive;
-        return r;
-    };
+// Stated ONCE as a visit over (begin, field*, end(count)) calls, so that two visitors read the same definition: the host collector below
+// (chip_interactions: the vair::Interaction lists the machine description, the permutation-trace kernels and the FFI use) and the device
+// evaluator of the per-point quotient kernel (kernels/quotient.hip), for which every field becomes a column load at a compile-time column.
+// Lin = a VirtualPairCol over main columns as Valida's chips use them: k + sum_i w_i * main[col_i], at most four terms.
+struct Lin {
+    int n;
+    int col[4];
+    uint32_t w[4];
+    uint32_t k;
+};
+VAIR_HD constexpr Lin lin_col(int c) { return Lin{1, {c, 0, 0, 0}, {1, 0, 0, 0}, 0}; }                                      // VirtualPairCol::single_main
+VAIR_HD constexpr Lin lin_const(uint32_t k) { return Lin{0, {0, 0, 0, 0}, {0, 0, 0, 0}, k}; }                               // VirtualPairCol::constant
+VAIR_HD constexpr Lin lin_sum2(int a, int b) { return Lin{2, {a, b, 0, 0}, {1, 1, 0, 0}, 0}; }                              // VirtualPairCol::sum_main
+VAIR_HD constexpr Lin lin_sum3(int a, int b, int c) { return Lin{3, {a, b, c, 0}, {1, 1, 1, 0}, 0}; }
+VAIR_HD constexpr Lin lin_w2(int a, uint32_t wa, int b, uint32_t wb) { return Lin{2, {a, b, 0, 0}, {wa, wb, 0, 0}, 0}; }  // VirtualPairCol::new_main
+VAIR_HD constexpr Lin lin_w3(int a, uint32_t wa, int b, uint32_t wb, int c, uint32_t wc) { return Lin{3, {a, b, c, 0}, {wa, wb, wc, 0}, 0}; }
+VAIR_HD constexpr Lin lin_w4(int a, uint32_t wa, int b, uint32_t wb, int c, uint32_t wc, int d, uint32_t wd) { return Lin{4, {a, b, c, d}, {wa, wb, wc, wd}, 0}; }
+
+// V: void begin(bool is_send, int bus_index); void field(const Lin&); void end(const Lin& count);
+template <class V> VAIR_HD void visit_word(V& v, int first) {
+    for (int i = 0; i < 4; i++) v.field(lin_col(first + i));
+}
+template <class V> VAIR_HD void visit_alu(V& v, bool is_send, const Lin& opcode, int in1, int in2, int outc, const Lin& count) {
+    v.begin(is_send, BUS_GENERAL);
+    v.field(opcode);
+    visit_word(v, in1); visit_word(v, in2); visit_word(v, outc);
+    v.end(count);
+}
+template <class V> VAIR_HD void visit_interactions(int chip, V& v) {
     switch (chip) {
         case CHIP_CPU: {  // cpu/src/lib.rs:99-159
             for (int i = 0; i < 3; i++) {
-                Interaction s;
-                s.fields = {VC::single_main(cpu::ch(i, cpu::CH_IS_READ)), VC::single_main(cpu::CLK),
-                            VC::single_main(cpu::ch(i, cpu::CH_ADDR)), VC::constant_(0)};
-                word(s.fields, cpu::ch(i, cpu::CH_VALUE));
-                s.count = VC::single_main(cpu::ch(i, cpu::CH_USED));
-                s.bus_kind = BusKind::Global; s.bus_index = BUS_MEM; s.type = InteractionType::GlobalSend;
-                out.push_back(s);
+                v.begin(true, BUS_MEM);
+                v.field(lin_col(cpu::ch(i, cpu::CH_IS_READ))); v.field(lin_col(cpu::CLK)); v.field(lin_col(cpu::ch(i, cpu::CH_ADDR))); v.field(lin_const(0));
+                visit_word(v, cpu::ch(i, cpu::CH_VALUE));
+                v.end(lin_col(cpu::ch(i, cpu::CH_USED)));
             }
-            Interaction g;
-            g.fields.push_back(VC::single_main(cpu::OPCODE));
-            for (int i = 0; i < 3; i++) word(g.fields, cpu::ch(i, cpu::CH_VALUE));
-            g.fields.push_back(VC::single_main(cpu::CLK_OR_ZERO));
-            g.count = VC::single_main(cpu::IS_BUS_OP);
-            g.bus_kind = BusKind::Global; g.bus_index = BUS_GENERAL; g.type = InteractionType::GlobalSend;
-            out.push_back(g);
+            v.begin(true, BUS_GENERAL);
+            v.field(lin_col(cpu::OPCODE));
+            for (int i = 0; i < 3; i++) visit_word(v, cpu::ch(i, cpu::CH_VALUE));
+            v.field(lin_col(cpu::CLK_OR_ZERO));
+            v.end(lin_col(cpu::IS_BUS_OP));
             break;
         }
         case CHIP_PROGRAM: break;  // program/src/lib.rs:50-68 (bus commented out)
-        case CHIP_MEM: {  // memory/src/lib.rs:216-233
-            Interaction r;
-            r.fields = {VC::single_main(mem::IS_READ), VC::single_main(mem::CLK), VC::single_main(mem::ADDR), VC::single_main(mem::IS_STATIC_INITIAL)};
-            word(r.fields, mem::VALUE);
-            r.count = VC::sum_main({mem::IS_READ, mem::IS_WRITE});
-            r.bus_kind = BusKind::Global; r.bus_index = BUS_MEM; r.type = InteractionType::GlobalReceive;
-            out.push_back(r);
+        case CHIP_MEM:  // memory/src/lib.rs:216-233
+            v.begin(false, BUS_MEM);
+            v.field(lin_col(mem::IS_READ)); v.field(lin_col(mem::CLK)); v.field(lin_col(mem::ADDR)); v.field(lin_col(mem::IS_STATIC_INITIAL));
+            visit_word(v, mem::VALUE);
+            v.end(lin_sum2(mem::IS_READ, mem::IS_WRITE));
             break;
-        }
         case CHIP_ADD:    // alu_u32/src/add/mod.rs:53-87
         case CHIP_SUB: {  // alu_u32/src/sub/mod.rs:53-87
             const int outc = chip == CHIP_ADD ? (int)add::OUTPUT : (int)sub::OUTPUT, is_real = chip == CHIP_ADD ? (int)add::IS_REAL : (int)sub::IS_REAL;
             for (int i = 0; i < 4; i++) {
-                Interaction s;
-                s.fields = {VC::single_main(outc + i)};
-                s.count = VC::single_main(is_real);
-                s.bus_kind = BusKind::Global; s.bus_index = BUS_RANGE; s.type = InteractionType::GlobalSend;
-                out.push_back(s);
+                v.begin(true, BUS_RANGE);
+                v.field(lin_col(outc + i));
+                v.end(lin_col(is_real));
             }
-            out.push_back(alu_receive(VC::constant_(chip == CHIP_ADD ? OP_ADD32 : OP_SUB32), 0, 4, outc, VC::single_main(is_real)));
+            visit_alu(v, false, lin_const(chip == CHIP_ADD ? OP_ADD32 : OP_SUB32), 0, 4, outc, lin_col(is_real));
             break;
         }
         case CHIP_MUL:  // alu_u32/src/mul/mod.rs:68-96
-            out.push_back(alu_receive(VC::new_main({{mul::IS_MUL, OP_MUL32}, {mul::IS_MULHS, OP_MULHS32}, {mul::IS_MULHU, OP_MULHU32}}, 0),
-                                      mul::INPUT_1, mul::INPUT_2, mul::OUTPUT, VC::sum_main({mul::IS_MUL, mul::IS_MULHS, mul::IS_MULHU})));
+            visit_alu(v, false, lin_w3(mul::IS_MUL, OP_MUL32, mul::IS_MULHS, OP_MULHS32, mul::IS_MULHU, OP_MULHU32), mul::INPUT_1, mul::INPUT_2, mul::OUTPUT,
+                      lin_sum3(mul::IS_MUL, mul::IS_MULHS, mul::IS_MULHU));
             break;
         case CHIP_DIV:  // alu_u32/src/div/mod.rs:55-80
-            out.push_back(alu_receive(VC::new_main({{divc::IS_DIV, OP_DIV32}, {divc::IS_SDIV, OP_SDIV32}}, 0), divc::INPUT_1, divc::INPUT_2,
-                                      divc::OUTPUT, VC::sum_main({divc::IS_DIV, divc::IS_SDIV})));
+            visit_alu(v, false, lin_w2(divc::IS_DIV, OP_DIV32, divc::IS_SDIV, OP_SDIV32), divc::INPUT_1, divc::INPUT_2, divc::OUTPUT, lin_sum2(divc::IS_DIV, divc::IS_SDIV));
             break;
-        case CHIP_SHIFT: {  // alu_u32/src/shift/mod.rs:58-116
-            Interaction s = alu_receive(VC::new_main({{shift::IS_SHL, OP_MUL32}, {shift::IS_SHR, OP_DIV32}, {shift::IS_SRA, OP_SDIV32}}, 0),
-                                        shift::INPUT_1, shift::POWER_OF_TWO, shift::OUTPUT, VC::sum_main({shift::IS_SHL, shift::IS_SHR, shift::IS_SRA}));
-            s.type = InteractionType::GlobalSend;
-            out.push_back(s);
-            out.push_back(alu_receive(VC::new_main({{shift::IS_SHL, OP_SHL32}, {shift::IS_SHR, OP_SHR32}, {shift::IS_SRA, OP_SRA32}}, 0),
-                                      shift::INPUT_1, shift::INPUT_2, shift::OUTPUT, VC::sum_main({shift::IS_SHL, shift::IS_SHR, shift::IS_SRA})));
+        case CHIP_SHIFT:  // alu_u32/src/shift/mod.rs:58-116
+            visit_alu(v, true, lin_w3(shift::IS_SHL, OP_MUL32, shift::IS_SHR, OP_DIV32, shift::IS_SRA, OP_SDIV32), shift::INPUT_1, shift::POWER_OF_TWO, shift::OUTPUT,
+                      lin_sum3(shift::IS_SHL, shift::IS_SHR, shift::IS_SRA));
+            visit_alu(v, false, lin_w3(shift::IS_SHL, OP_SHL32, shift::IS_SHR, OP_SHR32, shift::IS_SRA, OP_SRA32), shift::INPUT_1, shift::INPUT_2, shift::OUTPUT,
+                      lin_sum3(shift::IS_SHL, shift::IS_SHR, shift::IS_SRA));
             break;
-        }
-        case CHIP_LT: {  // alu_u32/src/lt/mod.rs:58-85
-            Interaction r;
-            r.fields.push_back(VC::new_main({{lt::IS_LT, OP_LT32}, {lt::IS_LTE, OP_LTE32}, {lt::IS_SLT, OP_SLT32}, {lt::IS_SLE, OP_SLE32}}, 0));
-            word(r.fields, lt::INPUT_1); word(r.fields, lt::INPUT_2);
-            for (int i = 0; i < 3; i++) r.fields.push_back(VC::constant_(0));
-            r.fields.push_back(VC::single_main(lt::OUTPUT));
-            r.count = VC::single_main(lt::MULTIPLICITY);
-            r.bus_kind = BusKind::Global; r.bus_index = BUS_GENERAL; r.type = InteractionType::GlobalReceive;
-            out.push_back(r);
+        case CHIP_LT:  // alu_u32/src/lt/mod.rs:58-85
+            v.begin(false, BUS_GENERAL);
+            v.field(lin_w4(lt::IS_LT, OP_LT32, lt::IS_LTE, OP_LTE32, lt::IS_SLT, OP_SLT32, lt::IS_SLE, OP_SLE32));
+            visit_word(v, lt::INPUT_1); visit_word(v, lt::INPUT_2);
+            for (int i = 0; i < 3; i++) v.field(lin_const(0));
+            v.field(lin_col(lt::OUTPUT));
+            v.end(lin_col(lt::MULTIPLICITY));
             break;
-        }
-        case CHIP_COM: {  // alu_u32/src/com/mod.rs:56-83
-            Interaction r;
-            r.fields.push_back(VC::new_main({{com::IS_NE, OP_NE32}, {com::IS_EQ, OP_EQ32}}, 0));
-            word(r.fields, com::INPUT_1); word(r.fields, com::INPUT_2);
-            for (int i = 0; i < 3; i++) r.fields.push_back(VC::constant_(0));
-            r.fields.push_back(VC::single_main(com::OUTPUT));
-            r.count = VC::sum_main({com::IS_NE, com::IS_EQ});
-            r.bus_kind = BusKind::Global; r.bus_index = BUS_GENERAL; r.type = InteractionType::GlobalReceive;
-            out.push_back(r);
+        case CHIP_COM:  // alu_u32/src/com/mod.rs:56-83
+            v.begin(false, BUS_GENERAL);
+            v.field(lin_w2(com::IS_NE, OP_NE32, com::IS_EQ, OP_EQ32));
+            visit_word(v, com::INPUT_1); visit_word(v, com::INPUT_2);
+            for (int i = 0; i < 3; i++) v.field(lin_const(0));
+            v.field(lin_col(com::OUTPUT));
+            v.end(lin_sum2(com::IS_NE, com::IS_EQ));
             break;
-        }
         case CHIP_BITWISE:  // alu_u32/src/bitwise/mod.rs:56-82
-            out.push_back(alu_receive(VC::new_main({{bitwise::IS_AND, OP_AND32}, {bitwise::IS_OR, OP_OR32}, {bitwise::IS_XOR, OP_XOR32}}, 0),
-                                      bitwise::INPUT_1, bitwise::INPUT_2, bitwise::OUTPUT,
-                                      VC::sum_main({bitwise::IS_AND, bitwise::IS_OR, bitwise::IS_XOR})));
+            visit_alu(v, false, lin_w3(bitwise::IS_AND, OP_AND32, bitwise::IS_OR, OP_OR32, bitwise::IS_XOR, OP_XOR32), bitwise::INPUT_1, bitwise::INPUT_2, bitwise::OUTPUT,
+                      lin_sum3(bitwise::IS_AND, bitwise::IS_OR, bitwise::IS_XOR));
             break;
-        case CHIP_OUTPUT: {  // output/src/lib.rs:117-136
-            Interaction r;
-            r.fields.push_back(VC::single_main(output::OPCODE));
-            for (int i = 0; i < 12; i++) r.fields.push_back(i == 3 ? VC::single_main(output::VALUE) : VC::constant_(0));
-            r.fields.push_back(VC::single_main(output::CLK));
-            r.count = VC::single_main(output::IS_REAL);
-            r.bus_kind = BusKind::Global; r.bus_index = BUS_GENERAL; r.type = InteractionType::GlobalReceive;
-            out.push_back(r);
+        case CHIP_OUTPUT:  // output/src/lib.rs:117-136
+            v.begin(false, BUS_GENERAL);
+            v.field(lin_col(output::OPCODE));
+            for (int i = 0; i < 12; i++) v.field(i == 3 ? lin_col(output::VALUE) : lin_const(0));
+            v.field(lin_col(output::CLK));
+            v.end(lin_col(output::IS_REAL));
             break;
-        }
-        case CHIP_RANGE: {  // range/src/lib.rs:46-55
-            Interaction r;
-            r.fields = {VC::single_main(range::COUNTER)};
-            r.count = VC::single_main(range::MULT);
-            r.bus_kind = BusKind::Global; r.bus_index = BUS_RANGE; r.type = InteractionType::GlobalReceive;
-            out.push_back(r);
+        case CHIP_RANGE:  // range/src/lib.rs:46-55
+            v.begin(false, BUS_RANGE);
+            v.field(lin_col(range::COUNTER));
+            v.end(lin_col(range::MULT));
             break;
-        }
-        case CHIP_STATIC_DATA: {  // static_data/src/lib.rs:81-96
-            Interaction s;
-            s.fields = {VC::constant_(0), VC::constant_(0), VC::single_main(static_data::ADDR), VC::constant_(1)};
-            word(s.fields, static_data::VALUE);
-            s.count = VC::single_main(static_data::IS_REAL);
-            s.bus_kind = BusKind::Global; s.bus_index = BUS_MEM; s.type = InteractionType::GlobalSend;
-            out.push_back(s);
+        case CHIP_STATIC_DATA:  // static_data/src/lib.rs:81-96
+            v.begin(true, BUS_MEM);
+            v.field(lin_const(0)); v.field(lin_const(0)); v.field(lin_col(static_data::ADDR)); v.field(lin_const(1));
+            visit_word(v, static_data::VALUE);
+            v.end(lin_col(static_data::IS_REAL));
             break;
-        }
+        default: break;
     }
-    return out;
+}
+
+// the host visitor: the Interaction lists (every interaction of the BasicMachine is on a global bus)
+struct InteractionCollector {
+    std::vector<Interaction> out;
+    static VirtualCol to_vcol(const Lin& f) {
+        VirtualCol v;
+        for (int i = 0; i < f.n; i++) v.terms.push_back({false, f.col[i], f.w[i]});
+        v.constant = f.k;
+        return v;
+    }
+    void begin(bool is_send, int bus_index) {
+        Interaction it;
+        it.bus_kind = BusKind::Global; it.bus_index = bus_index; it.type = is_send ? InteractionType::GlobalSend : InteractionType::GlobalReceive;
+        out.push_back(it);
+    }
+    void field(const Lin& f) { out.back().fields.push_back(to_vcol(f)); }
+    void end(const Lin& count) { out.back().count = to_vcol(count); }
+};
+inline std::vector<Interaction> chip_interactions(int chip) {
+    InteractionCollector c;
+    visit_interactions(chip, c);
+    return c.out;
 }
 
 }  // namespace vchips

@@ -442,7 +442,10 @@ __global__ void k_lde_a(DMatView src, DMatView dst, int k, int k_lo, int logT, D
 // ---- pass B: contiguous, persistent blocks over (n_hi x columns) tiles: inverse second half + forward first half of every coset ----
 // src: S1 (or the natural-order input itself when the column is one tile).  dst: S2 (coset t at rows [t N, (t + 1) N)) — or, one-tile
 // columns, the LDE itself (block bitrev(t), rows in committed order).  LDS: two padded tiles (coefficients, work).
-__global__ void k_lde_mid(DMatView src, DMatView dst, int k, int k_lo, int lb, DeviceTables tb, LdeTables lt) {
+// MAXT: the launch's thread count bound.  One-tile columns (heights <= 2^12: every small chip of a proof, 35 launches) run 64..256 threads; bounded at
+// 256 the register allocator keeps everything in registers (the generic bound of 1024 threads capped it at 128 VGPRs: 12 spilled + 105 SGPRs parked in lanes).
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_lde_mid(DMatView src, DMatView dst, int k, int k_lo, int lb, DeviceTables tb, LdeTables lt) {
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo, k_hi = k - k_lo, n_hi = 1 << k_hi, b = 1 << lb;
     uint32_t* A = lds;
@@ -739,7 +742,8 @@ static void set_lds_limit() {
     (void)hipFuncSetAttribute((const void*)k_intt_contig, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_ntt_contig, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_a, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)k_lde_mid, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_mid<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_mid<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_c, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_mid12, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_mid14, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -818,7 +822,7 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
     const double nw = 4.0 * nat.height * nat.width, b = (double)(1u << log_blowup);
     if (p.k_hi == 0) {
         ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
-        VK_LAUNCH(k_lde_mid, gm, dim3(p.threads_contig), lds_mid, st, nat, lde, k, p.k_lo, log_blowup, tb, lt);
+        VK_LAUNCH(k_lde_mid<256>, gm, dim3(p.threads_contig), lds_mid, st, nat, lde, k, p.k_lo, log_blowup, tb, lt);  // k_lo <= 12: at most 256 threads
         return;
     }
     dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)nat.width);
@@ -838,7 +842,8 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
         VK_LAUNCH(k_lde_mid14, gm, dim3(1024), (size_t)padded_words(16384) * 4, st, s1, s2, k, log_blowup, tb, lt);
     } else {
         ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
-        VK_LAUNCH(k_lde_mid, gm, dim3(p.threads_contig), lds_mid, st, s1, s2, k, p.k_lo, log_blowup, tb, lt);
+        if (p.threads_contig <= 256) VK_LAUNCH(k_lde_mid<256>, gm, dim3(p.threads_contig), lds_mid, st, s1, s2, k, p.k_lo, log_blowup, tb, lt);
+        else VK_LAUNCH(k_lde_mid<1024>, gm, dim3(p.threads_contig), lds_mid, st, s1, s2, k, p.k_lo, log_blowup, tb, lt);
     }
     dim3 gc((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)nat.width, 1u << log_blowup);
     ProfScope ps("k_lde_c", st, 2.0 * nw * b);

@@ -223,6 +223,80 @@ __device__ __forceinline__ Ext5 perm_constraints(const QuotientArgs& a, const Po
     return acc;
 }
 
+// ---- the same constraints for the in-tree chips with their interactions COMPILED IN (round 5) ---------------------------------------------
+// perm_constraints above walks the encoded interactions: every column index comes from a scalar load that the column load has to wait for, one
+// at a time — the mem chip (no AIR constraints at all, 48 loads per point) ran at 2.0 TB/s.  The BasicMachine's interactions are static
+// (chips/basic_machine.hpp: visit_interactions, the one definition the host's Interaction lists are collected from as well), so for a native chip
+// the visit is instantiated over this evaluator: every field is a load at a compile-time column, the whole point's loads are the compiler's to
+// hoist and batch, the betas / bus alphas / alpha powers are scalar loads at compile-time offsets.  Same values (exact field arithmetic).
+struct DevicePerm {
+    const QuotientArgs& a;
+    uint32_t roff, noff;
+    const uint32_t* apow;
+    const uint32_t* bus;
+    const uint32_t* betas;
+    Ext5 acc, rhs, phi_0, rlc;
+    uint64_t t[5];
+    int pend, m, j;
+    bool send;
+    __device__ __forceinline__ Fp value(const vchips::Lin& f, bool next) const {
+        Fp v = Fp::from_canonical(f.k);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < f.n) {
+                const Fp x = Fp::raw(load_at((next ? a.main_nx : a.main_lde.data) + (uint64_t)f.col[i] * a.main_lde.stride, next ? noff : roff));
+                v += f.w[i] == 1u ? x : x * Fp::from_canonical(f.w[i]);
+            }
+        return v;
+    }
+    __device__ __forceinline__ void flush() {
+#pragma unroll
+        for (int c = 0; c < 5; c++) { rlc.c[c] += Fp::raw(vg::monty_reduce_wide(t[c])); t[c] = 0; }
+        pend = 0;
+    }
+    __device__ __forceinline__ void begin(bool is_send, int) {
+        send = is_send;
+        rlc = ext_from_words(bus + 5 * m);
+#pragma unroll
+        for (int c = 0; c < 5; c++) t[c] = 0;
+        pend = 0; j = 0;
+    }
+    __device__ __forceinline__ void field(const vchips::Lin& f) {
+        if (!(f.n == 0 && f.k == 0)) {  // a zero field adds nothing to the combination
+            const Fp x = value(f, false);
+#pragma unroll
+            for (int c = 0; c < 5; c++) t[c] += (uint64_t)betas[5 * j + c] * x.v;
+            if (++pend == 4) flush();
+        }
+        j++;
+    }
+    __device__ __forceinline__ void end(const vchips::Lin& count) {
+        if (pend) flush();
+        const Fp mult_local = value(count, false), mult_next = value(count, true);
+        const Ext5 pl = load_ext_at(a.perm_lde.data + (uint64_t)(5 * m) * a.perm_lde.stride, a.perm_lde.stride, roff);
+        const Ext5 pn = load_ext_at(a.perm_nx + (uint64_t)(5 * m) * a.perm_lde.stride, a.perm_lde.stride, noff);
+        acc += ext_from_words(apow + 5 * m) * (rlc * pl - Fp::one());  // assert_one_ext(rlc * perm_local[m])
+        const Ext5 tl = pl * mult_local, tn = pn * mult_next;
+        if (send) { phi_0 += tl; rhs += tn; } else { phi_0 -= tl; rhs -= tn; }
+        m++;
+    }
+};
+template <int CHIP>
+__device__ __forceinline__ Ext5 perm_constraints_native(const QuotientArgs& a, const PointCtx& p) {
+    const uint32_t M = a.iw[0], maxf = a.iw[1];
+    DevicePerm v{a, (uint32_t)p.row * 4u, (uint32_t)p.next_row * 4u, a.consts + 5 * a.n_air_asserts, a.consts + 5 * a.K, a.consts + 5 * a.K + 5 * M,
+                 Ext5::zero(), Ext5::zero(), Ext5::zero(), Ext5::zero(), {0, 0, 0, 0, 0}, 0, 0, 0, false};
+    vchips::visit_interactions(CHIP, v);  // CHIP is a compile-time constant: the visit unrolls into straight-line code; v.m ends at M
+    const Ext5 cumulative_sum = ext_from_words(v.betas + 5 * maxf);
+    const Ext5 phi_local = load_ext_at(a.perm_lde.data + (uint64_t)(5 * v.m) * a.perm_lde.stride, a.perm_lde.stride, v.roff);
+    const Ext5 phi_next = load_ext_at(a.perm_nx + (uint64_t)(5 * v.m) * a.perm_lde.stride, a.perm_lde.stride, v.noff);
+    Ext5 acc = v.acc;
+    acc += ext_from_words(v.apow + 5 * v.m) * (((phi_next - phi_local) - v.rhs) * p.is_trans);
+    acc += ext_from_words(v.apow + 5 * (v.m + 1)) * ((phi_local - v.phi_0) * p.is_first);
+    acc += ext_from_words(v.apow + 5 * (v.m + 2)) * ((phi_local - cumulative_sum) * p.is_last);
+    return acc;
+}
+
 // RFKIND 0: interpreter with an LDS register file, 1: one VGPR bank (<= 32 registers), 2: two banks (<= 64),
 // 3: the chip's eval template compiled natively (CHIP = vchips::ChipId, or -1 for a chip without AIR constraints)
 template <int RFKIND, int CHIP = -1>
@@ -358,8 +432,11 @@ k_quotient_pt(QuotientArgs a, DeviceTables tb) {
     p.is_trans = d1;
     p.is_first = Fp::raw(a.zh[par]) * (inv * d1);
     p.is_last = Fp::raw(a.zh[par]) * (inv * d0);
+#ifndef VGPU_QUOT_PERM_NATIVE
+#define VGPU_QUOT_PERM_NATIVE 1  // 0: the descriptor-driven permutation constraints (A/B builds)
+#endif
     Ext5 q = run_native<CHIP>(a, p);
-    q = (q + perm_constraints(a, p)) * Fp::raw(a.zh_inv[par]);
+    q = (q + (VGPU_QUOT_PERM_NATIVE ? perm_constraints_native<CHIP>(a, p) : perm_constraints(a, p))) * Fp::raw(a.zh_inv[par]);
     Ext5 o;  // the partner lane's value
 #pragma unroll
     for (int c = 0; c < 5; c++) o.c[c] = Fp::raw((uint32_t)__builtin_amdgcn_update_dpp(0, (int)q.c[c].v, 0xB1, 0xF, 0xF, true));
@@ -553,8 +630,9 @@ void launch_quotient(hipStream_t st, const QuotientArgs& a_in, const DeviceTable
 #define VG_NATIVE_PT(C) case vchips::C: VK_LAUNCH((k_quotient_pt<vchips::C>), grid, block, 0, st, a, tb); break;
             VG_NATIVE_PT(CHIP_CPU) VG_NATIVE_PT(CHIP_ADD) VG_NATIVE_PT(CHIP_SUB) VG_NATIVE_PT(CHIP_MUL) VG_NATIVE_PT(CHIP_SHIFT) VG_NATIVE_PT(CHIP_LT)
             VG_NATIVE_PT(CHIP_COM) VG_NATIVE_PT(CHIP_BITWISE) VG_NATIVE_PT(CHIP_OUTPUT) VG_NATIVE_PT(CHIP_STATIC_DATA)
+            VG_NATIVE_PT(CHIP_PROGRAM) VG_NATIVE_PT(CHIP_MEM) VG_NATIVE_PT(CHIP_DIV) VG_NATIVE_PT(CHIP_RANGE)  // no AIR constraints: their interactions alone
 #undef VG_NATIVE_PT
-            default: VK_LAUNCH((k_quotient_pt<-1>), grid, block, 0, st, a, tb); break;
+            default: throw std::logic_error("quotient: a native chip id outside the BasicMachine");
         }
         return;
     }
