@@ -14,6 +14,7 @@
 // Integer-VALU-bound: ~0.8 k instructions per dense round (16 x 16 lazily accumulated products); the 22 partial rounds run in their
 // sparse-matrix form (31 products each, one dense round at the end) with deferred updates in groups of four rounds, the S-boxes on
 // signed Montgomery products: ~9.5 k instructions per permutation (26 k in the plain form, 11.4 k in round 3).
+#include <cstdlib>
 #include "launch.hpp"
 #include "poseidon_perm.hpp"
 #include "challenger_dev.hpp"
@@ -174,6 +175,20 @@ __device__ __forceinline__ void poseidon_node_row(const uint32_t* __restrict__ p
     if (l16 < 8) next[8 * node + l16] = st.canonical();
 }
 
+// A layer of the latency-bound MIDDLE of a tree (256 < parents <= POSEIDON_ROW_MAX_NODES) with one node per 16-lane row (round 5): with a thread per
+// node such a layer is at most a quarter of a wave per SIMD, every wave alone with its ~9 200 dependent instructions (16-19 us per layer, 26 trees
+// x up to 4 such layers per proof); a row finishes its node in ~2 600.  The price is 4.4 x the lane-instructions per permutation, so the
+// threshold stays where the GPU is mostly idle anyway (VGPU_POSEIDON_ROW_MAX: A/B, 0 = off).
+__global__ void __launch_bounds__(256) k_poseidon_compress_row(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int n_elems, uint64_t n_out,
+                                                               PoseidonTab tab, uint32_t* __restrict__ next) {
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, node = t >> 4;
+    if (node >= n_out) return;  // whole rows leave together (256 threads = 16 rows)
+    poseidon_node_row(prev, cols, n_elems, node, (int)(t & 15), tab, m, next);
+}
+
 // the last <= 11 levels of a tree in one launch (one 1024-thread workgroup, a barrier per level), as k_keccak_top
 __global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, PoseidonTab gtab) {
     __shared__ uint32_t s_opt[POPT_WORDS];
@@ -222,6 +237,12 @@ void launch_poseidon_leaves_strided(hipStream_t st, const uint32_t* pos_dev, boo
                        tab_of(pos_dev, sparse), digests);
 }
 void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
+    static const uint64_t row_max = [] { const char* e = getenv("VGPU_POSEIDON_ROW_MAX"); return e ? (uint64_t)atoll(e) : (uint64_t)4096; }();
+    if (VGPU_POSEIDON_ROWS && n_out > 256 && n_out <= row_max) {  // (layers of <= 256 parents belong to k_poseidon_top in a tree; the emulated-source tests launch tiny ones here)
+        ProfScope ps("k_poseidon_compress_row", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * p_node_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
+        VK_LAUNCH(k_poseidon_compress_row, dim3((unsigned)((16 * n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, tab_of(pos_dev, sparse), next);
+        return;
+    }
     ProfScope ps("k_poseidon_compress", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * p_node_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
     VK_LAUNCH(k_poseidon_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, tab_of(pos_dev, sparse), next);
 }
