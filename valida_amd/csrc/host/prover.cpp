@@ -729,7 +729,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     std::vector<Job> jobs;
     size_t out_words = 0;
     // the reduced openings' descriptor pool (built and UPLOADED before the opened-value kernels are enqueued, see below)
-    struct RLaunch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; };
+    struct RLaunch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; int n_points; };
     std::vector<RLaunch> launches;
     DBuf reduce_pool_dev;
     size_t apw_at = 0, ydesc_at = 0, yoff_at = 0, n_y_slots = 0;
@@ -829,7 +829,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                         for (auto& t : me.pts) any |= std::get<0>(t) >= s0 && std::get<0>(t) < s1;
                         if (any) { live.push_back(&me); max_w = std::max<size_t>(max_w, me.lde->width); total_width += me.lde->width; }
                     }
-                    launches.push_back({kv.first, pool.size(), s0 != 0, total_width});
+                    launches.push_back({kv.first, pool.size(), s0 != 0, total_width, (int)(s1 - s0)});
                     pool.push_back((uint32_t)live.size());
                     pool.push_back(s1 - s0);
                     pool.push_back((uint32_t)max_w);
@@ -922,7 +922,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         for (auto& l : launches) {
             const uint64_t L = 1ull << l.lh;
             if (!stream_of.count(l.lh)) stream_of[l.lh] = c.stream_for(grp_idx++, L);
-            vk::launch_reduce_openings(stream_of[l.lh], pool_dev.data + l.off, L, s, c.tables, ro[l.lh].data, l.total_width, l.accumulate);
+            vk::launch_reduce_openings(stream_of[l.lh], pool_dev.data + l.off, L, s, c.tables, ro[l.lh].data, l.total_width, l.accumulate, l.n_points);
         }
         reduce_section.join();
         c.check_launch("reduce openings");

@@ -159,8 +159,9 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
 constexpr int MAX_OPEN_POINTS_PER_LAUNCH = 4;
 // Y of every (matrix, point) written into the reduce descriptors on the device (open.hip, k_open_y)
 void launch_open_y(hipStream_t st, const uint32_t* vals_dev, const uint32_t* apow_dev, const uint32_t* desc_dev, const uint32_t* entry_off_dev, uint32_t n_entries, uint32_t* pool_dev);
+// n_points: the descriptor's number of distinct points (1 .. MAX_OPEN_POINTS_PER_LAUNCH; sizes the 4-rows-per-thread kernel's arrays; anything else = the maximum)
 void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width,
-                            bool accumulate = false);
+                            bool accumulate = false, int n_points = MAX_OPEN_POINTS_PER_LAUNCH);
 // beta5_dev: the folding challenge as 5 Montgomery words in device memory (written by k_fri_challenge)
 void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
 // One DuplexChallenger step on the device: observe the 8-word root at digest8_dev, sample beta into beta5_dev; the root is

@@ -8,7 +8,9 @@
 // Ext5 vectors of length L (reduced openings, FRI layers) live in "pair layout": a column-major
 // (L/2) x 10 matrix whose row r holds f[2r] (columns 0-4) and f[2r+1] (columns 5-9) — exactly the
 // matrix ExtensionMmcs commits for a FRI layer (App. B10), so layer trees hash it without reshaping.
+#include <cstdlib>
 #include <stdexcept>
+#include <type_traits>
 #include <string>
 #include "launch.hpp"
 #include "poseidon_perm.hpp"
@@ -406,6 +408,155 @@ __global__ void __launch_bounds__(256) k_reduce_openings(const uint32_t* __restr
     store_ext(out + (j & 1) * 5 * half, half, j >> 1, ro);
 }
 
+// ---- the same with R = 2 or 4 consecutive rows per thread (round 5) ---------------------------------------------------------------------------
+// Storage rows j0 .. j0 + 3 (j0 a multiple of 4) are the points x, -x, i x, -i x (x = shift w^bitrev(j0), i = the primitive 4th root: consecutive
+// rows differ in the top bits of the natural index), so the rows of a thread share x^2 .. x^5 up to signs and factors i; ONE base-field inversion
+// serves their R x n_points denominators (the thread-per-row kernel pays one per row: a third of its ~900 per-row instructions); every column is
+// read with one 8- or 16-byte load per lane (the narrow, tall matrices — mem's 14 / 10 / 10 columns at 2^23 rows — had four 4-byte loads in flight
+// per thread: 590 us for 1.3 GB).  R = 4 holds 4 x n_points Ext5 sums: 172 VGPRs at three points, two waves per SIMD — R is chosen per launch
+// (launch_reduce_openings).  Same values as k_reduce_openings (exact field arithmetic); heights below 1024 keep the row kernel.
+template <int R> struct RowVec;
+template <> struct RowVec<2> { using T = uint2; static __device__ __forceinline__ void get(const T& v, uint32_t (&e)[2]) { e[0] = v.x; e[1] = v.y; } };
+template <> struct RowVec<4> { using T = uint4; static __device__ __forceinline__ void get(const T& v, uint32_t (&e)[4]) { e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; } };
+template <int NP, int R>
+__global__ void __launch_bounds__(256) k_reduce_openings_rows(const uint32_t* __restrict__ desc, uint64_t L, uint32_t shift, DeviceTables tb, uint32_t* __restrict__ out, int accumulate) {
+    using V = typename RowVec<R>::T;
+    const uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * R;
+    if (j0 >= L) return;
+    const uint32_t n_mats = desc[0], n_points = desc[1], max_w = desc[2];
+    const uint32_t* mg = desc + 3;
+    const uint32_t* apow = mg + 25 * n_points;
+    const uint32_t* md = apow + 5 * max_w;
+    Ext5 S[NP][R];
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+        for (int r = 0; r < R; r++) S[p][r] = Ext5::zero();
+    for (uint32_t mi = 0; mi < n_mats; mi++) {
+        const uint32_t* colp = reinterpret_cast<const uint32_t*>(((uint64_t)md[1] << 32) | md[0]) + j0;
+        const uint64_t stride = ((uint64_t)md[3] << 32) | md[2];
+        const uint32_t width = md[4], npts = md[5];
+        md += 6;
+        Ext5 rr[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) rr[r] = Ext5::zero();
+        auto four_cols = [&](const V& v0, const V& v1, const V& v2, const V& v3, const uint32_t* a0) {
+            uint32_t e0[R], e1[R], e2[R], e3[R];
+            RowVec<R>::get(v0, e0); RowVec<R>::get(v1, e1); RowVec<R>::get(v2, e2); RowVec<R>::get(v3, e3);
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint64_t t = (uint64_t)a0[k] * e0[r] + (uint64_t)a0[5 + k] * e1[r] + (uint64_t)a0[10 + k] * e2[r] + (uint64_t)a0[15 + k] * e3[r];
+                    rr[r].c[k] += Fp::raw(vg::monty_reduce_wide(t));
+                }
+        };
+        uint32_t c = 0;
+        for (; c + 8 <= width; c += 8) {  // eight vector loads in flight
+            V v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const V*>(colp + (uint64_t)(c + u) * stride);
+            four_cols(v[0], v[1], v[2], v[3], apow + 5 * c);
+            four_cols(v[4], v[5], v[6], v[7], apow + 5 * (c + 4));
+        }
+        for (; c + 4 <= width; c += 4) {
+            V v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const V*>(colp + (uint64_t)(c + u) * stride);
+            four_cols(v[0], v[1], v[2], v[3], apow + 5 * c);
+        }
+        for (; c < width; c++) {
+            uint32_t e[R];
+            RowVec<R>::get(*reinterpret_cast<const V*>(colp + (uint64_t)c * stride), e);
+            const Ext5 a = ext_from_words(apow + 5 * c);
+#pragma unroll
+            for (int r = 0; r < R; r++) rr[r] += a * Fp::raw(e[r]);
+        }
+        for (uint32_t q = 0; q < npts; q++, md += 11) {
+            const Ext5 coef = ext_from_words(md + 1), Y = ext_from_words(md + 6);
+            const uint32_t slot = md[0];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const Ext5 t = coef * (Y - rr[r]);
+#pragma unroll
+                for (int p = 0; p < NP; p++) if ((uint32_t)p == slot) S[p][r] += t;
+            }
+        }
+    }
+    // the points of the rows and their powers: x_r = u_r x with u = (1, -1, i, -i); x_r^e = u_r^e x^e
+    const Fp x = Fp::raw(shift) * domain_point(tb, (uint32_t)j0), im = domain_point(tb, 2u);
+    const Fp x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+    Fp pw[R][5];  // [x, x^2, x^3, x^4, x^5] of row r
+    pw[0][0] = x; pw[0][1] = x2; pw[0][2] = x3; pw[0][3] = x4; pw[0][4] = x5;
+    pw[1][0] = -x; pw[1][1] = x2; pw[1][2] = -x3; pw[1][3] = x4; pw[1][4] = -x5;
+    if constexpr (R == 4) {
+        const Fp ix = im * x, ix3 = im * x3, ix5 = im * x5;
+        pw[2][0] = ix; pw[2][1] = -x2; pw[2][2] = -ix3; pw[2][3] = x4; pw[2][4] = ix5;
+        pw[3][0] = -ix; pw[3][1] = -x2; pw[3][2] = ix3; pw[3][3] = x4; pw[3][4] = -ix5;
+    }
+    // denominators m_p(x_r) first (their prefix products feed the ONE inversion); g_p(x_r) is formed only when its product is due, so that the
+    // R x n_points Ext5 values are never alive together
+    Fp mx[NP][R], pre[NP][R];
+    Fp run = Fp::one();
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+        if ((uint32_t)p < n_points) {
+            const uint32_t* q = mg + 25 * p;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint64_t tm = (uint64_t)q[1] * pw[r][0].v + (uint64_t)q[2] * pw[r][1].v + (uint64_t)q[3] * pw[r][2].v + (uint64_t)q[4] * pw[r][3].v;
+                mx[p][r] = Fp::raw(vg::monty_reduce_wide(tm)) + Fp::raw(q[0]) + pw[r][4];  // z is out of the domain: never zero
+                pre[p][r] = run;
+                run = run * mx[p][r];
+            }
+        }
+    Fp inv_run = run.inv();
+    Ext5 ro[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) ro[r] = Ext5::zero();
+    // (instantiated per point: as a loop the body is beyond what `#pragma unroll` accepts, and a rolled loop would index S / mx / pre dynamically)
+    auto point_step = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if ((uint32_t)p < n_points) {
+            const uint32_t* g = mg + 25 * p + 5;
+#pragma unroll
+            for (int r = R - 1; r >= 0; r--) {
+                Ext5 gx;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint64_t tg = (uint64_t)g[5 + k] * pw[r][0].v + (uint64_t)g[10 + k] * pw[r][1].v + (uint64_t)g[15 + k] * pw[r][2].v;
+                    gx.c[k] = Fp::raw(vg::monty_reduce_wide(tg)) + Fp::raw(g[k]);
+                }
+                gx.c[0] += pw[r][3];
+                ro[r] -= (S[p][r] * gx) * (inv_run * pre[p][r]);
+                inv_run = inv_run * mx[p][r];
+            }
+        }
+    };
+    if constexpr (NP > 3) point_step(std::integral_constant<int, 3>{});
+    if constexpr (NP > 2) point_step(std::integral_constant<int, 2>{});
+    if constexpr (NP > 1) point_step(std::integral_constant<int, 1>{});
+    point_step(std::integral_constant<int, 0>{});
+    // pair layout: the even rows -> columns 0..4, the odd rows -> columns 5..9, at index row / 2
+    const uint64_t half = L >> 1, at = j0 >> 1;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        uint32_t* pe = out + (uint64_t)k * half + at;
+        uint32_t* po = out + (uint64_t)(5 + k) * half + at;
+        if constexpr (R == 4) {
+            Fp e0 = ro[0].c[k], e1 = ro[2].c[k], o0 = ro[1].c[k], o1 = ro[3].c[k];
+            if (accumulate) { const uint2 a = *reinterpret_cast<uint2*>(pe), b = *reinterpret_cast<uint2*>(po); e0 += Fp::raw(a.x); e1 += Fp::raw(a.y); o0 += Fp::raw(b.x); o1 += Fp::raw(b.y); }
+            *reinterpret_cast<uint2*>(pe) = make_uint2(e0.v, e1.v);
+            *reinterpret_cast<uint2*>(po) = make_uint2(o0.v, o1.v);
+        } else {
+            Fp e0 = ro[0].c[k], o0 = ro[1].c[k];
+            if (accumulate) { e0 += Fp::raw(*pe); o0 += Fp::raw(*po); }
+            *pe = e0.v;
+            *po = o0.v;
+        }
+    }
+}
+
 // ---- FRI fold ---------------------------------------------------------------------------------------
 // in: (L/2) x 10 pair layout (stride L/2).  out[i] = (f0 + f1)/2 + (beta/2) x_i^{-1} (f0 - f1) [+ add[i]],
 // x_i^{-1} = w_L^{-bitrev(i)} (no coset shift inside FRI), written in pair layout of length L/2.
@@ -593,8 +744,21 @@ void launch_open_y(hipStream_t st, const uint32_t* vals_dev, const uint32_t* apo
     ProfScope ps("k_open_y", st, 0.0);
     VK_LAUNCH(k_open_y, dim3(n_entries), dim3(64), 0, st, vals_dev, apow_dev, desc_dev, entry_off_dev, pool_dev);
 }
-void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width, bool accumulate) {
+void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width, bool accumulate, int n_points) {
     ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + (accumulate ? 10.0 : 5.0)));
+    // VGPU_REDUCE_ROWS = rows per thread: 4, 2 or 1 (1: the thread-per-row kernel everywhere; A/B).  Default: 4 rows for launches of at most two distinct
+    // points, 2 rows for three and four (register budget: see k_reduce_openings_rows)
+    static const int rows_env = [] { const char* e = getenv("VGPU_REDUCE_ROWS"); return e ? atoi(e) : 0; }();
+    if (rows_env != 1 && L >= 1024) {
+        const int np = n_points >= 1 && n_points <= MAX_OPEN_POINTS ? n_points : MAX_OPEN_POINTS;
+        const int R = rows_env == 2 || rows_env == 4 ? rows_env : (np <= 2 ? 4 : 2);
+        const dim3 grid((unsigned)((L / R + 255) / 256)), block(256);
+#define VG_RO(NP_, R_) VK_LAUNCH((k_reduce_openings_rows<NP_, R_>), grid, block, 0, st, desc_dev, L, shift.v, tb, out, accumulate ? 1 : 0)
+        if (R == 4) { switch (np) { case 1: VG_RO(1, 4); break; case 2: VG_RO(2, 4); break; case 3: VG_RO(3, 4); break; default: VG_RO(4, 4); break; } }
+        else { switch (np) { case 1: VG_RO(1, 2); break; case 2: VG_RO(2, 2); break; case 3: VG_RO(3, 2); break; default: VG_RO(4, 2); break; } }
+#undef VG_RO
+        return;
+    }
     VK_LAUNCH(k_reduce_openings, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, desc_dev, L, shift.v, tb, out, accumulate ? 1 : 0);
 }
 void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out) {
