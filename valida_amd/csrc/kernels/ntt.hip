@@ -245,12 +245,13 @@ __global__ void k_intt_contig(DMatView m, int k, int k_lo, DeviceTables tb, uint
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo, k_hi = k - k_lo;
     const uint32_t* tw = tb.itwc;  // compact per-stage tables straight from L1/L2: no LDS copy, more blocks per CU
+    // tiles per column = 2^k_hi: column and tile of a work item by shift and mask (a 64-bit division of wave-uniform values is ~100 scalar instructions and a dozen SGPRs)
     const uint64_t tiles_per_col = m.height >> k_lo, total = tiles_per_col * m.width;
-    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return m.col(cidx) + (t - cidx * tiles_per_col) * n_lo; };
+    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t >> k_hi; return m.col(cidx) + (t & (tiles_per_col - 1)) * n_lo; };
     uint32_t pre[CONTIG_MAX_PER_THREAD];
     if (blockIdx.x < total) prefetch_tile(pre, tile_ptr(blockIdx.x), n_lo);
     for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
-        const uint64_t h = t % tiles_per_col;
+        const uint64_t h = t & (tiles_per_col - 1);
         uint32_t* col = tile_ptr(t);
         commit_tile(pre, lds, n_lo);
         __syncthreads();
@@ -363,8 +364,8 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo;
     const uint32_t* tw = tb.twc;
-    const uint64_t tiles_per_col = src.height >> k_lo, total = tiles_per_col * src.width;
-    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return dst.col(cidx) + dst_row0 + (t - cidx * tiles_per_col) * n_lo; };
+    const uint64_t tiles_per_col = src.height >> k_lo, total = tiles_per_col * src.width;  // 2^(k - k_lo)
+    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t >> (k - k_lo); return dst.col(cidx) + dst_row0 + (t & (tiles_per_col - 1)) * n_lo; };
     Fp cur0 = Fp::one(), step = Fp::one();
     if (from_src) { Fp shift = Fp::raw(shift_mont); cur0 = shift.pow(threadIdx.x); step = shift.pow(blockDim.x); }
     uint32_t pre[CONTIG_MAX_PER_THREAD];
@@ -444,6 +445,9 @@ __global__ void k_lde_a(DMatView src, DMatView dst, int k, int k_lo, int logT, D
 // columns, the LDE itself (block bitrev(t), rows in committed order).  LDS: two padded tiles (coefficients, work).
 // MAXT: the launch's thread count bound.  One-tile columns (heights <= 2^12: every small chip of a proof, 35 launches) run 64..256 threads; bounded at
 // 256 the register allocator keeps everything in registers (the generic bound of 1024 threads capped it at 128 VGPRs: 12 spilled + 105 SGPRs parked in lanes).
+// (What remains: ~110 SGPRs parked in VGPR lanes — the loop-invariant twiddle-table addresses of the run-time round dispatch, hoisted out of the tile
+// loop; fixing the tile size at compile time, 13 instantiations, halves the code and leaves 10-90 of them: not adopted, these launches sit on the
+// auxiliary stream beside the big matrices' passes.)
 template <int MAXT>
 __global__ void __launch_bounds__(MAXT) k_lde_mid(DMatView src, DMatView dst, int k, int k_lo, int lb, DeviceTables tb, LdeTables lt) {
     extern __shared__ uint32_t lds[];
@@ -452,11 +456,11 @@ __global__ void __launch_bounds__(MAXT) k_lde_mid(DMatView src, DMatView dst, in
     uint32_t* W = lds + padded_words(n_lo);
     const uint64_t N = 1ull << k, tiles_per_col = (uint64_t)n_hi, total = tiles_per_col * src.width;
     const uint32_t nmask = (uint32_t)(N - 1);
-    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return src.col(cidx) + (t - cidx * tiles_per_col) * n_lo; };
+    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t >> k_hi; return src.col(cidx) + (t & (tiles_per_col - 1)) * n_lo; };
     uint32_t pre[CONTIG_MAX_PER_THREAD];
     if (blockIdx.x < total) prefetch_tile(pre, tile_ptr(blockIdx.x), n_lo);
     for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
-        const uint64_t cidx = t / tiles_per_col, p = t - cidx * tiles_per_col;
+        const uint64_t cidx = t >> k_hi, p = t & (tiles_per_col - 1);
         commit_tile(pre, A, n_lo);
         __syncthreads();
         if (t + gridDim.x < total) prefetch_tile(pre, tile_ptr(t + gridDim.x), n_lo);
@@ -506,7 +510,7 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
     const int k_hi = k - K_LO, n_hi = 1 << k_hi, b = 1 << lb, tid = threadIdx.x;
     const uint64_t N = 1ull << k, tiles_per_col = (uint64_t)n_hi, total = tiles_per_col * src.width;
     const uint32_t nmask = (uint32_t)(N - 1);
-    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t / tiles_per_col; return src.col(cidx) + (t - cidx * tiles_per_col) * N_LO; };
+    auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t >> k_hi; return src.col(cidx) + (t & (tiles_per_col - 1)) * N_LO; };
 #ifndef VGPU_MID12_TWREG
 #define VGPU_MID12_TWREG 1  // the twiddles of the two outer rounds (stages 9 .. 12: they depend on the thread, not on the tile) held in registers
 #endif
@@ -529,7 +533,7 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
     }
 #endif
     for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
-        const uint64_t cidx = t / tiles_per_col, p = t - cidx * tiles_per_col;
+        const uint64_t cidx = t >> k_hi, p = t & (tiles_per_col - 1);
         Fp x[16];
 #if VGPU_MID12_PREFETCH
 #pragma unroll
@@ -601,11 +605,12 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
 __global__ void __launch_bounds__(1024) k_lde_mid14(DMatView src, DMatView dst, int k, int lb, DeviceTables tb, LdeTables lt) {
     extern __shared__ uint32_t lds[];
     constexpr int K_LO = 14, N_LO = 1 << K_LO, NT = 1024;
+    uint32_t* const coef = lds + (N_LO + (N_LO >> 4));  // second padded tile: the coefficients of the current column tile
     const int k_hi = k - K_LO, n_hi = 1 << k_hi, b = 1 << lb, tid = threadIdx.x;
     const uint64_t N = 1ull << k, tiles_per_col = (uint64_t)n_hi, total = tiles_per_col * src.width;
     const uint32_t nmask = (uint32_t)(N - 1);
     for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
-        const uint64_t cidx = t / tiles_per_col, p = t - cidx * tiles_per_col;
+        const uint64_t cidx = t >> k_hi, p = t & (tiles_per_col - 1);
         const uint32_t* sp = src.col(cidx) + p * N_LO;
         // inverse, stages 14 and 13 (DIF, inverse roots), straight from the global loads
 #pragma unroll
@@ -621,21 +626,28 @@ __global__ void __launch_bounds__(1024) k_lde_mid14(DMatView src, DMatView dst, 
         __syncthreads();
         ntt_round<4, false, true, 8>(lds, tb.itwc, 14, 9, 0, 0);  // stages 12 .. 9
         ntt_round<4, false, true, 4>(lds, tb.itwc, 14, 5, 0, 0);  // stages 8 .. 5
-        Fp x[16];
         {
+            // stages 4 .. 1 on the thread's own 16 positions; the result — N times the coefficient with c_b = bitrev(16 tid + g) — is parked in a second
+            // LDS tile (`coef`, the thread's own slots: no barrier) instead of 16 registers held across the cosets: at 1024 threads the kernel may use
+            // 128 VGPRs and spilled 28 of them to scratch inside the coset loop (profiles/r03_isa_static.txt); the workgroup has the CU's LDS to itself anyway
+            Fp x[16];
             const uint32_t* p0 = lds + 17 * tid;  // positions 16 tid + g
 #pragma unroll
             for (int g = 0; g < 16; g++) x[g] = Fp::raw(p0[g]);
+            butterflies<4, false, true>(x, tb.itwc, 0, 0);
+            uint32_t* c0 = coef + 17 * tid;
+#pragma unroll
+            for (int g = 0; g < 16; g++) c0[g] = x[g].v;
         }
-        butterflies<4, false, true>(x, tb.itwc, 0, 0);  // stages 4 .. 1: N times the coefficient with c_b = bitrev(16 tid + g)
         const uint32_t ca = k_hi ? __brev((uint32_t)p) >> (32 - k_hi) : 0u;
         const Fp step = root_pow(tb, k, (ca * 4096u) & nmask);
         for (int tc = 0; tc < b; tc++) {
             Fp y[16];
             {
                 const uint32_t* fac = lt.fac + (size_t)tc * N_LO + 16 * tid;
+                const uint32_t* c0 = coef + 17 * tid;
 #pragma unroll
-                for (int g = 0; g < 16; g++) y[g] = x[g] * Fp::raw(fac[g]);
+                for (int g = 0; g < 16; g++) y[g] = Fp::raw(c0[g]) * Fp::raw(fac[g]);
             }
             butterflies<4, true, true>(y, tb.twc, 0, 0);  // forward, stages 1 .. 4
             {
@@ -839,7 +851,7 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
         VK_LAUNCH(k_lde_mid12, gm, dim3(256), (size_t)padded_words(4096) * 4, st, s1, s2, k, log_blowup, tb, lt);
     } else if (p.k_lo == 14 && mid12 && mid14) {
         ProfScope ps("k_lde_mid14", st, nw * (1.0 + b));
-        VK_LAUNCH(k_lde_mid14, gm, dim3(1024), (size_t)padded_words(16384) * 4, st, s1, s2, k, log_blowup, tb, lt);
+        VK_LAUNCH(k_lde_mid14, gm, dim3(1024), 2 * (size_t)padded_words(16384) * 4, st, s1, s2, k, log_blowup, tb, lt);  // work tile + coefficient tile: 139 KiB
     } else {
         ProfScope ps("k_lde_mid", st, nw * (1.0 + b));
         if (p.threads_contig <= 256) VK_LAUNCH(k_lde_mid<256>, gm, dim3(p.threads_contig), lds_mid, st, s1, s2, k, p.k_lo, log_blowup, tb, lt);
