@@ -242,7 +242,7 @@ DMat Prover::permutation_trace(int chip, const DMat& main_nat, const DMat* prep_
     pool.push_back(0);
     DBuf pool_dev(&c, pool), scratch(&c, (size_t)vk::perm_scratch_words(main_nat.height));
     DMat perm(&c, main_nat.height, 5 * (M + 1));
-    vk::launch_perm_trace(c.stream, main_nat.view(), prep_nat ? prep_nat->view() : vk::DMatView{nullptr, 0, 0, 0}, iw_dev_[chip].data, pool_dev.data, M, perm.view(), scratch.data);
+    vk::launch_perm_trace(c.stream, main_nat.view(), prep_nat ? prep_nat->view() : vk::DMatView{nullptr, 0, 0, 0}, iw_dev_[chip].data, pool_dev.data, M, perm.view(), scratch.data, fri_.interpret_air ? -2 : machine_.airs[(size_t)chip].native_chip);
     c.check_launch("perm trace");
     if (cumulative_sum) {  // last row of the running-sum column (lib.rs:247-250)
         GatherList gl;
@@ -433,7 +433,7 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             vk::DMatView pv{nullptr, 0, 0, 0};
             if (prep_slot[i] >= 0) pv = prep_nat[prep_slot[i]].view();
             scratch.emplace_back(&c, (size_t)vk::perm_scratch_words(n));
-            vk::launch_perm_trace(c.stream_for(i, n), main_nat[i]->view(), pv, iw_dev_[i].data, pool_dev.data + off[i], M, perm_nat[i].view(), scratch.back().data);
+            vk::launch_perm_trace(c.stream_for(i, n), main_nat[i]->view(), pv, iw_dev_[i].data, pool_dev.data + off[i], M, perm_nat[i].view(), scratch.back().data, fri_.interpret_air ? -2 : machine_.airs[i].native_chip);
             gl.add(perm_nat[i].data + (uint64_t)(5 * M) * n + (n - 1), n, 5, 0);  // cumulative sum = last row, last column (lib.rs:247-250)
         }
         perm_section.join();

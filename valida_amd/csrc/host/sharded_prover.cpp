@@ -501,7 +501,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 pv = R.split[i] ? vk::DMatView{pm.data + (uint64_t)R.rank * n, n, pm.width, pm.height} : pm.view();
             }
             scratch.emplace_back(&c, (size_t)vk::perm_scratch_words(n));
-            vk::launch_perm_trace(c.stream, R.main_nat[i]->view(), pv, R.p->iw_dev_[i].data, pool_dev.data + off[i], M, R.perm_nat[i].view(), scratch.back().data);
+            vk::launch_perm_trace(c.stream, R.main_nat[i]->view(), pv, R.p->iw_dev_[i].data, pool_dev.data + off[i], M, R.perm_nat[i].view(), scratch.back().data, R.p->fri_.interpret_air ? -2 : R.p->machine_.airs[i].native_chip);
             // cumulative sum = last row of the running-sum column (lib.rs:247-250)
             put_ptr(desc, R.perm_nat[i].data + (uint64_t)(5 * M) * n + (n - 1));
             put_u64(desc, n);

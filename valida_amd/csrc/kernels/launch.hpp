@@ -116,8 +116,9 @@ void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, bool sparse, c
 // perm.hip
 uint64_t perm_scratch_words(uint64_t n);
 void launch_add_ext_const(hipStream_t st, uint32_t* data, uint64_t stride, uint64_t n, const uint32_t* off5_dev);  // 5 columns += 5 Montgomery constants
+// native_chip: vchips::ChipId when the AIR is one of the in-tree BasicMachine chips (its interactions are compiled into the kernel), anything else = the encoded walk
 void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,
-                       uint32_t* scratch);
+                       uint32_t* scratch, int native_chip = -2);
 // quotient.hip
 void launch_quotient(hipStream_t st, const QuotientArgs& a, const DeviceTables& tb);
 // Debug check on the trace domain: `a` carries the NATURAL-order traces in main_lde / perm_lde / prep_lde (log_n = log height);

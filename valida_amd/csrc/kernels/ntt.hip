@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(1024) k_lde_mid14(DMatView src, DMatView dst, 
             ntt_round<4, true, true, 8>(lds, tb.twc, 14, 9, 0, 0);  // stages 9 .. 12
             uint32_t* out = dst.col(cidx) + (uint64_t)tc * N + p * N_LO;
             const Fp sg = Fp::raw(lt.sig[(size_t)tc * n_hi + ca]);
-#pragma unroll
+#pragma unroll 1  // (unrolled, the four items' loads and twiddles are hoisted together: 14 VGPRs beyond the 128 a 1024-thread workgroup may use were spilled to scratch)
             for (int j = 0; j < 4; j++) {  // stages 13 and 14, then sigma_t^c_a w_N^(c_a q) and out: q = w + 4096 g
                 const int w = tid + NT * j;
                 Fp y4[4];

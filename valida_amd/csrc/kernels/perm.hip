@@ -7,8 +7,10 @@
 // The reference's row-serial prefix loop (:178-201) becomes a 3-phase block scan (Ext5 addition is five
 // independent base-field additions).  Ext5 inversion is per element (Frobenius norm -> one base pow):
 // identical values to the reference's batch inversion, exact arithmetic.
+#include <cstdlib>
 #include "launch.hpp"
 #include "interactions.hpp"
+#include "../chips/basic_machine.hpp"
 
 namespace vk {
 
@@ -36,6 +38,97 @@ __global__ void __launch_bounds__(256) k_perm_recip(DMatView main, DMatView prep
         delta = is_send ? delta + term : delta - term;
     }
     store_ext(perm.data + (uint64_t)(5 * M) * perm.stride, perm.stride, n, delta);
+}
+
+// ---- the same for the in-tree chips with their interactions COMPILED IN (round 5) ----------------------------------------------------------
+// k_perm_recip walks the encoded interactions (a scalar load in front of every column load) and inverts every interaction's combination on its
+// own: a cpu row costs four Ext5 inversions (~140 base-field products each), an add / sub row five.  The BasicMachine's interactions are static
+// (chips/basic_machine.hpp: visit_interactions), so the visit is instantiated over this collector — every field a load at a compile-time
+// column — and the row's M combinations are inverted TOGETHER (Montgomery's trick in Ext5: 3 (M - 1) products and ONE inversion; a zero
+// stays zero, as batch_multiplicative_inverse_allowing_zero has it).  Same values (exact field arithmetic).  VGPU_PERM_NATIVE=0: the walk (A/B).
+constexpr int PERM_NATIVE_MAX_M = 5;  // add / sub: four range sends and the bus receive
+struct DevicePermRow {
+    const uint32_t* main;
+    uint64_t stride;
+    uint32_t roff;
+    const uint32_t* chal;
+    const uint32_t* betas;
+    Ext5 rl[PERM_NATIVE_MAX_M];
+    Fp mult[PERM_NATIVE_MAX_M];
+    uint32_t snd;  // bit m: interaction m is a send
+    Ext5 rlc;
+    uint64_t t[5];
+    int pend, m, j;
+    __device__ __forceinline__ Fp value(const vchips::Lin& f) const {
+        Fp v = Fp::from_canonical(f.k);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < f.n) {
+                const Fp x = Fp::raw(load_at(main + (uint64_t)f.col[i] * stride, roff));
+                v += f.w[i] == 1u ? x : x * Fp::from_canonical(f.w[i]);
+            }
+        return v;
+    }
+    __device__ __forceinline__ void flush() {
+#pragma unroll
+        for (int c = 0; c < 5; c++) { rlc.c[c] += Fp::raw(vg::monty_reduce_wide(t[c])); t[c] = 0; }
+        pend = 0;
+    }
+    // (the per-interaction slots are written through unrolled compares, never through a run-time index: where the visit's loops are not folded to a
+    // compile-time m the arrays would otherwise move to scratch memory)
+    __device__ __forceinline__ void begin(bool is_send, int) {
+        snd |= (is_send ? 1u : 0u) << m;
+        rlc = ext_from_words(chal + 5 * m);
+#pragma unroll
+        for (int c = 0; c < 5; c++) t[c] = 0;
+        pend = 0; j = 0;
+    }
+    __device__ __forceinline__ void field(const vchips::Lin& f) {
+        if (!(f.n == 0 && f.k == 0)) {
+            const Fp x = value(f);
+#pragma unroll
+            for (int c = 0; c < 5; c++) t[c] += (uint64_t)betas[5 * j + c] * x.v;
+            if (++pend == 4) flush();
+        }
+        j++;
+    }
+    __device__ __forceinline__ void end(const vchips::Lin& count) {
+        if (pend) flush();
+        const Fp cnt = value(count);
+#pragma unroll
+        for (int mm = 0; mm < PERM_NATIVE_MAX_M; mm++) if (mm == m) { rl[mm] = rlc; mult[mm] = cnt; }
+        m++;
+    }
+};
+template <int CHIP>
+__global__ void __launch_bounds__(256) k_perm_recip_native(DMatView main, const uint32_t* __restrict__ iw, const uint32_t* __restrict__ chal, DMatView perm) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= main.height) return;
+    const uint32_t M = iw[0];
+    DevicePermRow v;
+    v.main = main.data; v.stride = main.stride; v.roff = (uint32_t)n * 4u;  // trace heights <= 2^27 rows: the byte offset fits
+    v.chal = chal; v.betas = chal + 5 * M;
+    v.m = 0; v.pend = 0; v.j = 0; v.snd = 0;
+    vchips::visit_interactions(CHIP, v);  // CHIP is a compile-time constant: straight-line code, v.m ends at M <= PERM_NATIVE_MAX_M
+    Ext5 pre[PERM_NATIVE_MAX_M];
+    Ext5 run = Ext5::one();
+#pragma unroll
+    for (int m = 0; m < PERM_NATIVE_MAX_M; m++)
+        if (m < v.m) { pre[m] = run; run = run * (v.rl[m].is_zero() ? Ext5::one() : v.rl[m]); }
+    Ext5 inv = run.inv();  // never zero: zeros were replaced by one
+    Ext5 delta = Ext5::zero();
+#pragma unroll
+    for (int m = PERM_NATIVE_MAX_M - 1; m >= 0; m--)
+        if (m < v.m) {
+            const bool z = v.rl[m].is_zero();
+            Ext5 q = inv * pre[m];
+            inv = inv * (z ? Ext5::one() : v.rl[m]);
+            if (z) q = Ext5::zero();
+            store_ext(perm.data + (uint64_t)(5 * m) * perm.stride, perm.stride, n, q);
+            const Ext5 term = q * v.mult[m];
+            delta = ((v.snd >> m) & 1u) ? delta + term : delta - term;
+        }
+    store_ext(perm.data + (uint64_t)(5 * v.m) * perm.stride, perm.stride, n, delta);
 }
 
 // ---- inclusive prefix sum of a base-field column (blockIdx.y selects the column) ----------------------
@@ -114,10 +207,24 @@ uint64_t perm_scratch_words(uint64_t n) { return 5 * ((n + SCAN_BLOCK - 1) / SCA
 
 // main/prep: natural-order column-major.  perm: n x 5(M+1), natural order.  scratch: >= 5 * ceil(n / SCAN_BLOCK) words.
 void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,
-                       uint32_t* scratch) {
+                       uint32_t* scratch, int native_chip) {
     uint64_t n = main.height;
+    static const bool native_on = [] { const char* e = getenv("VGPU_PERM_NATIVE"); return !(e && e[0] == '0'); }();
     { ProfScope ps("k_perm_recip", st, 4.0 * n * (main.width + perm.width));
-    VK_LAUNCH(k_perm_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, main, prep, iw_dev, chal_dev, perm); }
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    bool done = false;
+    if (native_on && M <= (uint32_t)PERM_NATIVE_MAX_M) {
+        done = true;
+        switch (native_chip) {
+#define VG_PERM_NATIVE(C) case vchips::C: VK_LAUNCH((k_perm_recip_native<vchips::C>), grid, block, 0, st, main, iw_dev, chal_dev, perm); break;
+            VG_PERM_NATIVE(CHIP_CPU) VG_PERM_NATIVE(CHIP_PROGRAM) VG_PERM_NATIVE(CHIP_MEM) VG_PERM_NATIVE(CHIP_ADD) VG_PERM_NATIVE(CHIP_SUB) VG_PERM_NATIVE(CHIP_MUL)
+            VG_PERM_NATIVE(CHIP_DIV) VG_PERM_NATIVE(CHIP_SHIFT) VG_PERM_NATIVE(CHIP_LT) VG_PERM_NATIVE(CHIP_COM) VG_PERM_NATIVE(CHIP_BITWISE) VG_PERM_NATIVE(CHIP_OUTPUT)
+            VG_PERM_NATIVE(CHIP_RANGE) VG_PERM_NATIVE(CHIP_STATIC_DATA)
+#undef VG_PERM_NATIVE
+            default: done = false; break;  // a run-time captured AIR: the descriptor walk
+        }
+    }
+    if (!done) VK_LAUNCH(k_perm_recip, grid, block, 0, st, main, prep, iw_dev, chal_dev, perm); }
     ProfScope ps("k_scan", st, 3.0 * 20.0 * n);
     uint32_t* phi = perm.data + (uint64_t)(5 * M) * perm.stride;
     uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
