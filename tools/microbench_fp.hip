@@ -43,6 +43,21 @@ __device__ __forceinline__ uint32_t mont_c(uint32_t a, uint32_t b) {
     uint32_t m = lo * 0x88000001u, u = __umulhi(m, P);
     return sub_c(hi, u);
 }
+// Shoup / Barrett product by a FIXED factor w with its precomputed quotient wq = floor(w 2^32 / p): q = mulhi(x, wq), r = x w - q p in [0, 2p), one
+// correction — three multiply-class instructions instead of the Montgomery product's four (round 5: is it worth carrying twiddle quotients?)
+__device__ __forceinline__ uint32_t red_c(uint32_t s) {
+    uint32_t t, r; unsigned long long vc;
+    asm("v_subrev_co_u32_e64 %0, %1, %4, %3\n\tv_cndmask_b32_e64 %2, %0, %3, %1" : "=&v"(t), "=&s"(vc), "=v"(r) : "v"(s), "v"(P));
+    return r;
+}
+__device__ __forceinline__ uint32_t shoup_c(uint32_t x, uint32_t w, uint32_t wq) {
+    const uint32_t q = __umulhi(x, wq);
+    return red_c(x * w - q * P);
+}
+__device__ __forceinline__ uint32_t shoup_lazy(uint32_t x, uint32_t w, uint32_t wq) {  // result in [0, 2p)
+    const uint32_t q = __umulhi(x, wq);
+    return x * w - q * P;
+}
 template <int MODE> __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
     uint32_t x[8], y = 123456789u + threadIdx.x;
 #pragma unroll
@@ -56,6 +71,11 @@ template <int MODE> __global__ void __launch_bounds__(256) k(uint32_t* out, int 
             if (MODE == 3) x[i] = mont_c(x[i], y);
             if (MODE == 4) { x[i] = add_v(x[i], y); x[i] = sub_v(x[i], x[(i + 1) & 7]); }
             if (MODE == 5) x[i] = mont_v(x[i], y);
+            if (MODE == 6) x[i] = shoup_c(x[i], y % P, (uint32_t)((((uint64_t)(y % P)) << 32) / P));  // (the factor and its quotient are loop-invariant: hoisted)
+            if (MODE == 7) x[i] = red_c(shoup_lazy(x[i], y % P, (uint32_t)((((uint64_t)(y % P)) << 32) / P)) >> 1);  // lazy product, consumer halves the range (keeps the chain below 2^32)
+            // DIF butterflies on pairs (x[i], x[i ^ 1]): Montgomery against Shoup twiddle products
+            if (MODE == 8 && !(i & 1)) { uint32_t u = x[i], v = x[i + 1]; x[i] = add_c(u, v); x[i + 1] = mont_c(u + (P - v), y); }
+            if (MODE == 9 && !(i & 1)) { uint32_t u = x[i], v = x[i + 1]; x[i] = add_c(u, v); x[i + 1] = shoup_c(u + (P - v), y % P, (uint32_t)((((uint64_t)(y % P)) << 32) / P)); }
         }
     }
     uint32_t acc = 0;
@@ -84,6 +104,9 @@ int main() {
     uint32_t v4, v5;
     double t4 = run<4>(d, iters); hipMemcpy(&v4, d, 4, hipMemcpyDeviceToHost);
     double t5 = run<5>(d, iters); hipMemcpy(&v5, d, 4, hipMemcpyDeviceToHost);
+    double t6 = run<6>(d, iters), t7 = run<7>(d, iters), t8 = run<8>(d, iters), t9 = run<9>(d, iters);
+    printf("product by a fixed factor: Montgomery (carry form) %.3f ns   Shoup + correction %.3f ns (ratio %.3f)   Shoup lazy + halving consumer %.3f ns\n", t3, t6, t6 / t3, t7);
+    printf("DIF butterfly (4 per 8-slot group, so per butterfly x2): Montgomery %.3f ns   Shoup %.3f ns   (ratio %.3f)\n", 2 * t8, 2 * t9, t9 / t8);
     printf("through VCC (VOP2): add+sub pair %.3f ns   Montgomery mul %.3f ns   results %s\n", t4, t5, (v4 == v[0] && v5 == v[2]) ? "equal" : "DIFFER");
     printf("add+sub pair   min-form %.3f ns   carry-form %.3f ns   (ratio %.3f)  results %s\n", t0, t1, t1 / t0, v[0] == v[1] ? "equal" : "DIFFER");
     printf("Montgomery mul min-form %.3f ns   carry-form %.3f ns   (ratio %.3f)  results %s\n", t2, t3, t3 / t2, v[2] == v[3] ? "equal" : "DIFFER");
