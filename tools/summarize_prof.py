@@ -18,9 +18,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# device kernels that the library's profiler (and bench.py's kernel table) files under ANOTHER kernel's name: variants of one launch site
+ALIASES = {"k_reduce_openings_rows": "k_reduce_openings", "k_perm_recip_native": "k_perm_recip"}
+
+
 def short(name):
     m = re.search(r"(k_[a-z0-9_]+)", name)
-    return m.group(1) if m else name.split("(")[0]
+    n = m.group(1) if m else name.split("(")[0]
+    return ALIASES.get(n, n)
 
 
 def db_of(d):
