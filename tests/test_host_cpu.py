@@ -301,10 +301,10 @@ def test_proof_cbor_matches_independent_encoder(flags):
 
 
 def test_committed_bench_line_follows_the_contract():
-    # profiles/r04_bench_full.json is the line bench.py printed on the MI355X in the round's profile session: every field the driver reads is there
+    # profiles/r05_bench_full.json is the line bench.py printed on the MI355X in the round's profile session: every field the driver reads is there
     import json
 
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_bench_full.json")) as f:
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_bench_full.json")) as f:
         d = json.load(f)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
@@ -330,7 +330,10 @@ def test_committed_bench_line_follows_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port", "port-simd") and c["cores"] >= 1 and c["unit"] == "proofs/s" and "sample" in c
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_c2_fib149794.json")) as f:
-        assert c["proof_sha256"] == json.load(f)["proof_sha256"]  # the baseline proved the very segment the fixture pins
+        fixture_sha = json.load(f)["proof_sha256"]
+    assert c["proof_sha256"] == fixture_sha  # the baseline proved the very segment the fixture pins
+    # round 5: the line is self-proving — the GPU proof of the timed region carries its own sha256, equal to the CPU leg's of the same run
+    assert d["proof_sha256"] == fixture_sha and d["same_proof_as_cpu_baseline"] is True and "scalar_port_seconds_per_proof" not in c
     assert "2^20 cpu rows" in c["sample"] and "scaled" not in c["sample"]  # the headline segment itself, no extrapolation
     # no published number exists: vs_baseline is the ratio to the CPU baseline of the SAME run and says so
     assert abs(d["vs_baseline"] - d["value"] / c["value"]) < 1e-6 * d["vs_baseline"] and "kind: port-simd" in d["vs_baseline_is"] and d["vs_baseline"] > 20
