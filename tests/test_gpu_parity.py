@@ -166,6 +166,34 @@ def test_gpu_proof_matches_committed_golden_fixture(prover, name):
     assert hashlib.sha256(proof.bytes()).hexdigest() == g["proof_sha256"]
 
 
+# Every A / B switch of the library that selects ANOTHER kernel for the same step ("Environment switches") must give the oracle's proof as
+# well: the alternatives stay in the tree as the A / B baselines of profiles/r0*_ab_*, and several are the path of run-time captured AIRs or of the
+# sharded prover.  The switches are read once per process, so each setting proves in a process of its own: fib(582) (cpu 2^12, mem 2^14: the big-matrix
+# kernels and the one-tile ones both run; reduced openings above and below the 1024-row threshold) against the committed fixture of the oracle's proof.
+@pytest.mark.parametrize("setting", ["VGPU_REDUCE_ROWS=1", "VGPU_REDUCE_ROWS=2", "VGPU_REDUCE_ROWS=4", "VGPU_PERM_NATIVE=0", "VGPU_QUOT_PER_POINT=0", "VGPU_LDE_GROUP_MB=1",
+                                     "VGPU_LDE_FUSED=0", "VGPU_KECCAK_PAIRS=0", "VGPU_KECCAK_LEVELS=0", "VGPU_QUOT_NATURAL=0"])
+def test_every_ab_switch_gives_the_oracles_proof(setting):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import hashlib, json, sys; sys.path.insert(0, %r); import valida_amd as va\n"
+            "g = json.load(open(%r)); w = va.Workload.fib(g['n']); mt, prep = w.main_traces(), w.preprocessed()\n"
+            "p = va.Prover(va.Machine.basic(), va.poseidon_round_constants(), device=0)\n"
+            "pr = p.prove([p.upload(m) for m in mt], [(c, p.upload(m)) for c, m in prep])\n"
+            "print(json.dumps({'sha': hashlib.sha256(pr.bytes()).hexdigest(), 'commitments': [int(x) for x in pr.words[2:26]]}))\n") % (
+                root, os.path.join(root, "tests", "golden", "fib582_oracle.json"))
+    k, v = setting.split("=")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{k: v}), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    with open(os.path.join(root, "tests", "golden", "fib582_oracle.json")) as f:
+        g = json.load(f)
+    assert got["commitments"] == g["commitments"] and got["sha"] == g["proof_sha256"], setting
+
+
 def test_round_trip_properties_at_scale(prover, rc):
     # size-independent properties at a size the oracle is too slow for in a unit test (cpu 2^16, mem 2^18):
     # the oracle's restated verifier accepts the GPU proof, and a second run reproduces it bit for bit
