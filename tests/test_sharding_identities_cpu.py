@@ -95,7 +95,7 @@ def test_a_fold_of_a_shard_is_the_shard_of_the_fold():
 
 
 def test_model_of_the_ntt_pipeline_without_a_bit_reversal_pass():
-    """tools/ntt_fused_model.py: the pass structure planned for folding k_bitrev_rows into the transforms, as integers mod p,
+    """tools/ntt_fused_model.py: the pass structure planned for folding k_bitrev_rows into the transforms (profiles/HISTORY.md section 8; built in round 3: the fused k_lde_* passes), as integers mod p,
     gives the oracle's committed LDE."""
     import os
     import subprocess

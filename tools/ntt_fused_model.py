@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Executable model (plain integers mod p) of the NEXT NTT pipeline — the row bit-reversal folded into the passes:
+"""Executable model (plain integers mod p) of the NEXT NTT pipeline — the row bit-reversal folded into the passes (profiles/HISTORY.md section 8; built in round 3: the fused k_lde_* passes):
 
   today      bitrev copy -> [inverse: contiguous DIT, strided DIT] -> per coset [forward: strided DIF, contiguous DIF]      1 + 2 + 2b passes
   modelled   [inverse: strided DIF, contiguous DIF (natural store inside the block)] -> per coset [forward: contiguous DIF over the

@@ -17,7 +17,7 @@
 // the twiddles of a round come from per-stage compact tables — read through L1/L2 in the contiguous passes
 // (16-64 KB shared by every block), staged in LDS in the strided passes; the coset powers and four-step twiddles
 // come from small host-prepared / universal root tables instead of per-thread exponentiations.
-// No MFMA: 31-bit modular butterflies are VALU work.  Measured balance: DESIGN.md "Where the remaining time is".
+// No MFMA: 31-bit modular butterflies are VALU work.  Measured balance: DESIGN.md "Measurement".
 #include "launch.hpp"
 #include "butterfly.hpp"
 #if VGPU_STANDIN_FUSE
