@@ -882,17 +882,31 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         }
         out_dev = DBuf(&c, out_words + 4);
         std::vector<DBuf> partials;
+        // the finishes of all column-dot launches in ONE launch behind the join (VGPU_DOT_FINISH_BATCH=0: a finish launch behind every column-dot launch; A/B):
+        // the job table is built and uploaded before the launches fork (a copy enqueued behind the join would wait for the other queue's signal)
+        static const bool finish_batch = [] { const char* e = getenv("VGPU_DOT_FINISH_BATCH"); return !(e && e[0] == '0'); }();
+        std::vector<uint32_t> fin_jobs;
+        uint32_t fin_blocks = 0;
+        for (auto& j : jobs) {
+            const DMat& lde = rounds[j.r].pd->ldes[j.i];
+            const uint64_t n = lde.height >> lb;
+            partials.emplace_back(&c, (size_t)(vk::col_dot_slots(n) * j.cw * j.np * 5));
+            if (finish_batch) fin_blocks = vk::col_dot_finish_job(fin_jobs, fin_blocks, n, j.cw, j.np, partials.back().data, pool_dev.data + j.scale_off, out_dev.data + j.out_off);
+        }
+        DBuf fin_dev;
+        if (finish_batch && !fin_jobs.empty()) fin_dev = DBuf(&c, fin_jobs);
         Section open_section(&c);
         size_t job_idx = 0;
         for (auto& j : jobs) {
             const DMat& lde = rounds[j.r].pd->ldes[j.i];
             const uint64_t n = lde.height >> lb;
-            partials.emplace_back(&c, (size_t)(vk::col_dot_slots(n) * j.cw * j.np * 5));
             vk::DMatView sub{lde.data + j.c0 * lde.height, lde.height, j.cw, lde.height};
-            vk::launch_col_dot(c.stream_for(job_idx++, n), sub, n, j.np, wlist[j.w[0]].buf.data, wlist[j.w[1]].buf.data, partials.back().data,
-                               pool_dev.data + j.scale_off, out_dev.data + j.out_off);
+            vk::launch_col_dot(c.stream_for(job_idx, n), sub, n, j.np, wlist[j.w[0]].buf.data, wlist[j.w[1]].buf.data, partials[job_idx].data,
+                               pool_dev.data + j.scale_off, out_dev.data + j.out_off, !finish_batch);
+            job_idx++;
         }
         open_section.join();
+        if (finish_batch && !fin_jobs.empty()) vk::launch_col_dot_finish_batch(c.stream, fin_dev.data, (uint32_t)jobs.size(), fin_blocks);
         c.check_launch("opened values");
         // the values travel to the host BESIDE the reduced openings and the FRI commit phase (no synchronisation here: k_open_y below reads them
         // on the device); a pinned area of this prover's own, the generic staging buffer is reused by the downloads that follow
@@ -919,9 +933,13 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         Section reduce_section(&c);
         std::map<unsigned, hipStream_t> stream_of;  // chunks of one height must stay on one stream (they accumulate in order)
         size_t grp_idx = 0;
+        // VGPU_REDUCE_SPLIT=1 (experiment): the SECOND tallest height on the auxiliary stream, beside the tallest one's launch instead of behind it
+        static const bool split = [] { const char* e = getenv("VGPU_REDUCE_SPLIT"); return e && e[0] == '1'; }();
+        unsigned second = 0;
+        for (auto& kv : groups) if (kv.first != log_max) second = std::max(second, kv.first);
         for (auto& l : launches) {
             const uint64_t L = 1ull << l.lh;
-            if (!stream_of.count(l.lh)) stream_of[l.lh] = c.stream_for(grp_idx++, L);
+            if (!stream_of.count(l.lh)) stream_of[l.lh] = split && l.lh == second && second >= 16 ? c.aux[0] : c.stream_for(grp_idx++, L);
             vk::launch_reduce_openings(stream_of[l.lh], pool_dev.data + l.off, L, s, c.tables, ro[l.lh].data, l.total_width, l.accumulate, l.n_points);
         }
         reduce_section.join();

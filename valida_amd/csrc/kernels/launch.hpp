@@ -1,5 +1,6 @@
 // Host-callable launchers of the gfx950 kernels (definitions in the .hip files of this directory).
 #pragma once
+#include <vector>
 #include "device_common.hpp"
 #include "profiler.hpp"
 #include "../air/symbolic.hpp"
@@ -153,8 +154,12 @@ bool bary_weights_has_image(uint64_t n);
 uint64_t col_dot_slots(uint64_t n);
 uint64_t bary_buffer_words(uint64_t n);  // words of a weight vector launch_bary_weights fills (launch_col_dot takes such buffers)
 uint64_t col_dot_max_columns(int np);  // widest matrix (view) one k_col_dot launch takes for np points; wider ones are opened in column chunks
+// finish = false: only the partial sums; the caller collects a job per launch (col_dot_finish_job: appends its 12-word image to `jobs`, returns the next first
+// block) and finishes all of them with ONE launch_col_dot_finish_batch behind the launches (jobs_dev = the uploaded images)
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
-                    const uint32_t* scale5_dev, uint32_t* out_dev);
+                    const uint32_t* scale5_dev, uint32_t* out_dev, bool finish = true);
+uint32_t col_dot_finish_job(std::vector<uint32_t>& jobs, uint32_t first_block, uint64_t n, uint64_t width, int np, const uint32_t* partial, const uint32_t* scale5_dev, uint32_t* out_dev);
+void launch_col_dot_finish_batch(hipStream_t st, const uint32_t* jobs_dev, uint32_t n_jobs, uint32_t total_blocks);
 // accumulate: add to the vector already in `out` (a height with more than MAX_OPEN_POINTS_PER_LAUNCH distinct opening points is
 // reduced in several launches)
 constexpr int MAX_OPEN_POINTS_PER_LAUNCH = 4;

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <type_traits>
+#include <vector>
 #include <string>
 #include "launch.hpp"
 #include "poseidon_perm.hpp"
@@ -304,6 +305,27 @@ __global__ void __launch_bounds__(64) k_col_dot_finish(const uint32_t* __restric
     if (threadIdx.x == 0) {
         acc = acc * ext_from_words(scale5 + 5 * p);
         for (int k = 0; k < 5; k++) out[idx * 5 + k] = acc.c[k].canonical();
+    }
+}
+
+// Every finish of an opening in ONE launch (round 5): behind each of a proof's 42 column-dot launches sat a finish launch of width x points waves — 5-15 us
+// each, serialised on its stream, 0.3 ms of a lone proof.  jobs: first blocks ascending; block b of job j = its (column, point) pair b - first_block.
+struct DotFinishJob { uint32_t first_block, np; const uint32_t* partial; uint64_t n_blocks, width; const uint32_t* scale5; uint32_t* out; };
+__global__ void __launch_bounds__(64) k_col_dot_finish_batch(const DotFinishJob* __restrict__ jobs, uint32_t n_jobs) {
+    uint32_t lo = 0, hi = n_jobs - 1;  // the job of this block: the last one whose first block is <= blockIdx.x (block-uniform)
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (jobs[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1; }
+    const DotFinishJob j = jobs[lo];
+    const uint64_t idx = blockIdx.x - j.first_block;  // (col, p)
+    const uint64_t c = idx / j.np;
+    const int p = (int)(idx % j.np);
+    const uint64_t n_out = j.width * j.np * 5;
+    Ext5 acc = Ext5::zero();
+    for (uint64_t b = threadIdx.x; b < j.n_blocks; b += 64) acc += ext_from_words(j.partial + b * n_out + (c * j.np + p) * 5);
+#pragma unroll
+    for (int k = 0; k < 5; k++) acc.c[k] = wave_sum(acc.c[k]);
+    if (threadIdx.x == 0) {
+        acc = acc * ext_from_words(j.scale5 + 5 * p);
+        for (int k = 0; k < 5; k++) j.out[idx * 5 + k] = acc.c[k].canonical();
     }
 }
 
@@ -690,8 +712,21 @@ uint64_t col_dot_slots(uint64_t n) {
 }
 uint64_t col_dot_max_columns(int np) { return (uint64_t)DOT_MAX_PASSES * DOT_THREADS / (5 * (uint64_t)np); }
 // m: LDE (only rows < n are read).  np = 1 or 2 points.  partial: col_dot_slots(n) * width * np * 5 words.
+void launch_col_dot_finish_batch(hipStream_t st, const uint32_t* jobs_dev, uint32_t n_jobs, uint32_t total_blocks) {
+    if (!n_jobs) return;
+    ProfScope ps("k_col_dot_finish", st, 0.0);
+    VK_LAUNCH(k_col_dot_finish_batch, dim3(total_blocks), dim3(64), 0, st, reinterpret_cast<const DotFinishJob*>(jobs_dev), n_jobs);
+}
+uint32_t col_dot_finish_job(std::vector<uint32_t>& jobs, uint32_t first_block, uint64_t n, uint64_t width, int np, const uint32_t* partial, const uint32_t* scale5_dev, uint32_t* out_dev) {
+    auto ptr = [&](const void* q) { const uint64_t v = (uint64_t)q; jobs.push_back((uint32_t)v); jobs.push_back((uint32_t)(v >> 32)); };
+    auto u64 = [&](uint64_t v) { jobs.push_back((uint32_t)v); jobs.push_back((uint32_t)(v >> 32)); };
+    jobs.push_back(first_block); jobs.push_back((uint32_t)np);
+    ptr(partial); u64(col_dot_slots(n)); u64(width); ptr(scale5_dev); ptr(out_dev);
+    static_assert(sizeof(DotFinishJob) == 48, "job image");
+    return first_block + (uint32_t)(width * (uint64_t)np);
+}
 void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32_t* w0, const uint32_t* w1, uint32_t* partial,
-                    const uint32_t* scale5_dev, uint32_t* out_dev) {
+                    const uint32_t* scale5_dev, uint32_t* out_dev, bool finish) {
     if (np < 1 || np > 2 || m.width > col_dot_max_columns(np)) throw std::runtime_error("col_dot: one launch takes 1 or 2 points and at most 1024 / (5 points) columns (the caller chunks)");
     unsigned blocks = (unsigned)col_dot_slots(n);
     const int pk = np * 5;
@@ -702,12 +737,12 @@ void launch_col_dot(hipStream_t st, DMatView m, uint64_t n, int np, const uint32
         const unsigned grid = (unsigned)((items + 3) / 4);
         if (np == 1) VK_LAUNCH(k_col_dot_mfma<1>, dim3(grid), dim3(256), 0, st, m, n, w0 + 5 * n, w1 + 5 * n, chunk, partial);
         else VK_LAUNCH(k_col_dot_mfma<2>, dim3(grid), dim3(256), 0, st, m, n, w0 + 5 * n, w1 + 5 * n, chunk, partial);
-        VK_LAUNCH(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
+        if (finish) VK_LAUNCH(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
         return;
     }
     if (np == 1) VK_LAUNCH(k_col_dot<1>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
     else VK_LAUNCH(k_col_dot<2>, dim3(blocks), dim3(DOT_THREADS), lds, st, m, n, w0, w1, partial);
-    VK_LAUNCH(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
+    if (finish) VK_LAUNCH(k_col_dot_finish, dim3((unsigned)(m.width * np)), dim3(64), 0, st, partial, (uint64_t)blocks, m.width, np, scale5_dev, out_dev);
 }
 // ---- Y = sum_col alpha^col y_col of every (matrix, point) of an opening, on the device (round 4) --------------------------------------
 // k_reduce_openings needs, per (matrix, point), the alpha-weighted sum of the OPENED VALUES of that matrix at that point.  The host used to
