@@ -933,13 +933,10 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         Section reduce_section(&c);
         std::map<unsigned, hipStream_t> stream_of;  // chunks of one height must stay on one stream (they accumulate in order)
         size_t grp_idx = 0;
-        // VGPU_REDUCE_SPLIT=1 (experiment): the SECOND tallest height on the auxiliary stream, beside the tallest one's launch instead of behind it
-        static const bool split = [] { const char* e = getenv("VGPU_REDUCE_SPLIT"); return e && e[0] == '1'; }();
-        unsigned second = 0;
-        for (auto& kv : groups) if (kv.first != log_max) second = std::max(second, kv.first);
+        // (the second tallest height on the auxiliary stream, beside the tallest one's launch instead of behind it, was measured: no gain — profiles/r05_ab_latency.txt)
         for (auto& l : launches) {
             const uint64_t L = 1ull << l.lh;
-            if (!stream_of.count(l.lh)) stream_of[l.lh] = split && l.lh == second && second >= 16 ? c.aux[0] : c.stream_for(grp_idx++, L);
+            if (!stream_of.count(l.lh)) stream_of[l.lh] = c.stream_for(grp_idx++, L);
             vk::launch_reduce_openings(stream_of[l.lh], pool_dev.data + l.off, L, s, c.tables, ro[l.lh].data, l.total_width, l.accumulate, l.n_points);
         }
         reduce_section.join();
