@@ -171,7 +171,7 @@ def test_gpu_proof_matches_committed_golden_fixture(prover, name):
 # sharded prover.  The switches are read once per process, so each setting proves in a process of its own: fib(582) (cpu 2^12, mem 2^14: the big-matrix
 # kernels and the one-tile ones both run; reduced openings above and below the 1024-row threshold) against the committed fixture of the oracle's proof.
 @pytest.mark.parametrize("setting", ["VGPU_REDUCE_ROWS=1", "VGPU_REDUCE_ROWS=2", "VGPU_REDUCE_ROWS=4", "VGPU_PERM_NATIVE=0", "VGPU_QUOT_PER_POINT=0", "VGPU_LDE_GROUP_MB=1",
-                                     "VGPU_LDE_FUSED=0", "VGPU_KECCAK_PAIRS=0", "VGPU_KECCAK_LEVELS=0", "VGPU_QUOT_NATURAL=0"])
+                                     "VGPU_LDE_FUSED=0", "VGPU_KECCAK_PAIRS=0", "VGPU_KECCAK_LEVELS=0", "VGPU_QUOT_NATURAL=0", "VGPU_DOT_FINISH_BATCH=0"])
 def test_every_ab_switch_gives_the_oracles_proof(setting):
     import json
     import os
