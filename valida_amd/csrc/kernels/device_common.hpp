@@ -25,6 +25,49 @@ struct DMatView {
     __device__ __forceinline__ uint32_t* col(uint64_t c) const { return data + c * stride; }
 };
 
+// Loads / stores at a WAVE-UNIFORM base plus a 32-bit per-lane BYTE offset, as raw buffer accesses: the base travels in four SGPRs (scalar ALU), the
+// lane's offset is one VGPR that many accesses share — instead of a 64-bit per-lane address per access (two v_mad_u64_u32 / v_lshl_add_u64 each, and a
+// VGPR pair held per access in flight).  A plain pointer sum does not get there: LLVM re-associates (base + offset) into a per-lane pointer first.
+// The offset must stay below the resource's 2^31 bytes.  VGPU_QUOT_SADDR=0 (A/B builds) and the host pass / hipemu: plain pointer arithmetic.
+#ifndef VGPU_QUOT_SADDR
+#define VGPU_QUOT_SADDR 1
+#endif
+__device__ __forceinline__ uint32_t load_at(const uint32_t* ubase, uint32_t byte_off) {
+#if VGPU_QUOT_SADDR && defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ubase), 0, 0x7fffffff, 0x00020000);  // raw buffer, no swizzle, dword format
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
+#else
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ubase) + byte_off);
+#endif
+}
+__device__ __forceinline__ void store_at(uint32_t* ubase, uint32_t byte_off, uint32_t v) {
+#if VGPU_QUOT_SADDR && defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(ubase, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)byte_off, 0, 0);
+#else
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ubase) + byte_off) = v;
+#endif
+}
+
+// The same with a wave-uniform BYTE offset beside the base (the buffer instruction's scalar offset operand: one SGPR per distinct offset, the four-SGPR
+// resource shared by all accesses of a column)
+__device__ __forceinline__ uint32_t load_at(const uint32_t* ubase, uint32_t byte_off, uint32_t uniform_off) {
+#if VGPU_QUOT_SADDR && defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ubase), 0, 0x7fffffff, 0x00020000);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)uniform_off, 0);
+#else
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ubase) + byte_off + uniform_off);
+#endif
+}
+__device__ __forceinline__ void store_at(uint32_t* ubase, uint32_t byte_off, uint32_t uniform_off, uint32_t v) {
+#if VGPU_QUOT_SADDR && defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(ubase, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)byte_off, (int)uniform_off, 0);
+#else
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ubase) + byte_off + uniform_off) = v;
+#endif
+}
+
 // Per-context constant tables (filled once by DeviceTables::init):
 //   roots[i]     = primitive 2^i-th root of unity w_{2^i} (Montgomery), i = 0..27
 //   inv_roots[i] = its inverse

@@ -41,6 +41,9 @@ inline std::vector<uint32_t> encode_interactions(const std::vector<vair::Interac
 }
 
 #if defined(__HIPCC__)
+}  // namespace vk
+#include "device_common.hpp"  // load_at
+namespace vk {
 // Evaluate the vcol at `*pos` on one row; advances *pos past it.  `main`/`prep` are column-major views
 // (data, stride) and `row` the storage row.
 __device__ __forceinline__ vg::Fp eval_vcol(const uint32_t* __restrict__ w, uint32_t& pos, const uint32_t* main, uint64_t mstride,
@@ -57,22 +60,8 @@ __device__ __forceinline__ vg::Fp eval_vcol(const uint32_t* __restrict__ w, uint
     }
     return acc;
 }
-// The same with the row given as a 32-bit BYTE offset into every column.  The column's base (data + col * stride) is wave-uniform: the load is a
-// raw BUFFER load — resource = that base in four SGPRs (scalar ALU), the lane's offset one VGPR shared by every load of the point — instead of a
-// 64-bit per-lane address per load (two v_mad_u64_u32 / v_lshl_add_u64 each, and a VGPR pair held per load in flight).  A plain pointer sum does
-// not get there: LLVM re-associates (base + offset) into a per-lane pointer first.  LDE heights are at most 2^27 rows (the field's two-adicity),
-// so the offset is below the resource's 2^31-byte range.
-#ifndef VGPU_QUOT_SADDR
-#define VGPU_QUOT_SADDR 1  // 0: plain pointer arithmetic (A/B builds)
-#endif
-__device__ __forceinline__ uint32_t load_at(const uint32_t* ubase, uint32_t byte_off) {
-#if VGPU_QUOT_SADDR && defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ubase), 0, 0x7fffffff, 0x00020000);  // raw buffer, no swizzle, dword format
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
-#else  // A/B builds, and the host pass of hipcc (which parses device functions without the amdgcn builtins)
-    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ubase) + byte_off);
-#endif
-}
+// The same with the row given as a 32-bit BYTE offset into every column: the column's base (data + col * stride) is wave-uniform, the load a raw buffer
+// load (device_common.hpp: load_at).  LDE heights are at most 2^27 rows (the field's two-adicity), so the offset is below the resource's 2^31-byte range.
 __device__ __forceinline__ vg::Fp eval_vcol_at(const uint32_t* __restrict__ w, uint32_t& pos, const uint32_t* main, uint64_t mstride,
                                                const uint32_t* prep, uint64_t pstride, uint32_t byte_off) {
     uint32_t nt = w[pos];

@@ -407,16 +407,102 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
 // and 3 launches per matrix instead of 3 + 2 b.  A column of at most 2^12 rows is one tile: k_lde_mid alone (one launch instead of 2 + b).
 // Correctness of the index arithmetic is checked on the CPU by running these kernels under tools/hipemu (tests/test_ntt_emu_cpu.py).
 
+// ---- the two hot strided tile shapes (2^8 rows x 64 columns: heights 2^20; 2^10 rows x 16 columns: 2^22 .. 2^24), 512 threads x 32 elements -------
+// The generic load / store loops of passes A and C spend ~30 VALU instructions per ELEMENT on addresses (row = e >> logT, its bit reversal, a 64-bit
+// multiply-add per global address, the LDS address) against 48 for the element's four butterflies (PMC: 2517 instructions per thread of k_lde_c, 1536
+// of them butterflies).  For these shapes a thread's 32 elements are (row h0 + HSTEP u, column c) resp. (row p2, column c0 + CSTEP i) with h0, c, p2, c0
+// fixed per thread: every global address is a WAVE-UNIFORM base (scalar ALU: the part that depends on u / i, bit reversals of compile-time numbers)
+// plus ONE per-thread byte offset (load_at / store_at: raw buffer accesses), every LDS address the thread's base plus an immediate.
+// (round 5; VGPU_STRIDED_IO=0 keeps the generic loops: A/B builds)
+#ifndef VGPU_STRIDED_IO
+#define VGPU_STRIDED_IO 1
+#endif
+// keeps a wave-uniform value as the running SGPR it is written as (the unrolled loop would otherwise become 32 hoisted constants x n_lo)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VGPU_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#else
+#define VGPU_OPAQUE_S(x) ((void)0)
+#endif
+__host__ __device__ constexpr uint32_t brev_c(uint32_t x, int bits) { uint32_t r = 0; for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i); return r; }
+template <int K_HI, int LOGT> struct StridedShape {
+    static constexpr int NT = 512, T = 1 << LOGT, LD = T + 1, NH = 1 << K_HI, LH = 9 - LOGT /* log2 rows per sweep of the 512 threads */, HSTEP = 1 << LH, U = NH >> LH;
+    static_assert(U == 32 && (K_HI - LH) == 5, "512 threads x 32 elements");
+};
+// global (row-strided source) -> LDS tile.  SRC_BITREV: tile row h lives in source block bitrev_{K_HI}(h) (pass C reads S2); else in block h (pass A).
+// col0 = the tile's first word of the column (wave-uniform); blocks are n_lo words apart.
+template <int K_HI, int LOGT, bool SRC_BITREV>
+__device__ __forceinline__ void strided_tile_load(const uint32_t* col0, uint32_t n_lo, uint32_t* lds) {
+    using S = StridedShape<K_HI, LOGT>;
+    const uint32_t tid = threadIdx.x, c = tid & (S::T - 1), h0 = tid >> LOGT;  // h = h0 + HSTEP u
+    const uint32_t blk0 = SRC_BITREV ? (__brev(h0) >> (32 - S::LH)) << 5 : h0;  // the thread's part of the source block index
+    const uint32_t voff = (blk0 * n_lo + c) * 4u;
+    uint32_t* l0 = lds + h0 * S::LD + c;
+    const uint32_t step = (uint32_t)S::HSTEP * n_lo * 4u;
+    uint32_t run = 0;  // natural source: the scalar offset as a running sum (32 independent multiples of n_lo would all be hoisted into SGPRs and overflow them)
+#pragma unroll
+    for (int u0 = 0; u0 < S::U; u0 += 8) {  // eight loads in flight
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t u = (uint32_t)(u0 + k);
+            if (SRC_BITREV) v[k] = load_at(col0, voff, brev_c(u, 5) * n_lo * 4u);  // byte offsets below 2^31: at most 2^10 blocks of 2^14 words
+            else { v[k] = load_at(col0, voff, run); run += step; VGPU_OPAQUE_S(run); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) l0[(u0 + k) * S::HSTEP * S::LD] = v[k];
+    }
+}
+// LDS tile -> global, same element map as the load (pass A: tile row h -> block h of S1)
+template <int K_HI, int LOGT>
+__device__ __forceinline__ void strided_tile_store(uint32_t* col0, uint32_t n_lo, const uint32_t* lds) {
+    using S = StridedShape<K_HI, LOGT>;
+    const uint32_t tid = threadIdx.x, c = tid & (S::T - 1), h0 = tid >> LOGT;
+    const uint32_t voff = (h0 * n_lo + c) * 4u;
+    const uint32_t* l0 = lds + h0 * S::LD + c;
+    const uint32_t step = (uint32_t)S::HSTEP * n_lo * 4u;
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < S::U; u++) { store_at(col0, voff, run, l0[u * S::HSTEP * S::LD]); run += step; VGPU_OPAQUE_S(run); }
+}
+// pass C's transposing store: tile element (p2, c) -> out[bitrev_{k_lo}(q0 + c) n_hi + p2], q0 = tile T.  Thread tid takes e = tid + 512 i:
+//   K_HI = 8:  p2 = tid & 255, c = (tid >> 8) + 2 i;   K_HI = 10: p2 = tid + 512 (i & 1), c = i >> 1 (wave-uniform)
+// bitrev_{k_lo}(q0 + c) = bitrev_{k_lo - LOGT}(tile) + (bitrev_LOGT(c) << (k_lo - LOGT)): the tile's part and the i-dependent part are scalar.
+template <int K_HI, int LOGT>
+__device__ __forceinline__ void strided_tile_store_transposed(uint32_t* out_col, uint32_t tile, int k_lo, const uint32_t* lds) {
+    using S = StridedShape<K_HI, LOGT>;
+    const uint32_t tid = threadIdx.x, kq = (uint32_t)(k_lo - LOGT);
+    const uint32_t qb_tile = kq ? __brev(tile) >> (32 - kq) : 0u;
+    if (K_HI == 8) {
+        const uint32_t p2 = tid & 255u, c0 = tid >> 8;  // c = c0 + 2 i: bitrev6(c) = (c0 << 5) | bitrev5(i)
+        uint32_t* base = out_col + ((uint64_t)qb_tile << K_HI);
+        const uint32_t voff = ((((c0 << 5) << kq) << K_HI) + p2) * 4u;
+        const uint32_t* l0 = lds + p2 * S::LD + c0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) store_at(base, voff, ((brev_c((uint32_t)i, 5) << kq) << K_HI) * 4u, l0[2 * i]);  // an LDE column is at most 2^27 words: offsets below 2^29 bytes
+    } else {
+        uint32_t* base = out_col + ((uint64_t)qb_tile << K_HI);
+        const uint32_t* l0 = lds + tid * S::LD;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const uint32_t c = (uint32_t)(i >> 1), half = (uint32_t)(i & 1);
+            store_at(base, (tid + 512u * half) * 4u, ((brev_c(c, LOGT) << kq) << K_HI) * 4u, l0[512 * half * S::LD + c]);
+        }
+    }
+}
+
 // ---- pass A: inverse, strided, natural input: grid = (n_lo / T, columns) -------------------------------
-__global__ void k_lde_a(DMatView src, DMatView dst, int k, int k_lo, int logT, DeviceTables tb) {
+// FK_HI / FLOGT: one of the two hot tile shapes fixed at compile time (8 / 6, 10 / 4: 512 threads), or 0 / 0 = any shape (run-time k_hi, logT)
+template <int FK_HI, int FLOGT>
+__global__ void __launch_bounds__(FK_HI ? 512 : 1024) k_lde_a(DMatView src, DMatView dst, int k, int k_lo, int logT_arg, DeviceTables tb) {
     extern __shared__ uint32_t lds[];
-    const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
+    const int k_hi = FK_HI ? FK_HI : k - k_lo, logT = FK_HI ? FLOGT : logT_arg, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
     const uint64_t n_lo = 1ull << k_lo, r0 = (uint64_t)strided_tile_of_block(blockIdx.x, gridDim.x) * T;
     uint32_t* tw = lds + n_hi * LD;
     const uint32_t* in = src.col(blockIdx.y) + r0;
     uint32_t* out = dst.col(blockIdx.y) + r0;
     const int total = n_hi << logT;
-    {
+    if constexpr (FK_HI != 0) strided_tile_load<FK_HI, FLOGT, false>(in, (uint32_t)n_lo, lds);
+    else {
         int e = threadIdx.x;
         for (; e + 7 * (int)blockDim.x < total; e += 8 * blockDim.x) {  // eight independent loads in flight per thread
             uint32_t v[8];
@@ -429,7 +515,8 @@ __global__ void k_lde_a(DMatView src, DMatView dst, int k, int k_lo, int logT, D
     }
     stage_twiddles(tw, tb.itwc, k_hi);
     __syncthreads();
-    strided_tile_transform<false>(lds, tw, k_hi, logT, LD);  // DIF with inverse roots: row p holds c_a = bitrev(p)
+    if constexpr (FK_HI != 0) strided_transform<false, FK_HI, FLOGT>(lds, tw);  // DIF with inverse roots: row p holds c_a = bitrev(p)
+    else tile_transform<false, false>(lds, tw, k_hi, logT, LD);
     for (int p = threadIdx.x; p < n_hi; p += blockDim.x) {  // times w_N^-(c_a i_lo): thread per row, running product over the T consecutive i_lo
         const uint32_t ca = __brev((uint32_t)p) >> (32 - k_hi);  // k_hi >= 1 in this kernel
         const Fp base = inv_root_pow(tb, k, ca);
@@ -437,7 +524,9 @@ __global__ void k_lde_a(DMatView src, DMatView dst, int k, int k_lo, int logT, D
         for (int c = 0; c < T; c++) { lds[p * LD + c] = (Fp::raw(lds[p * LD + c]) * cur).v; cur *= base; }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; out[(uint64_t)h * n_lo + c] = lds[h * LD + c]; }
+    if constexpr (FK_HI != 0) strided_tile_store<FK_HI, FLOGT>(out, (uint32_t)n_lo, lds);
+    else
+        for (int e = threadIdx.x; e < total; e += blockDim.x) { int c = e & (T - 1), h = e >> logT; out[(uint64_t)h * n_lo + c] = lds[h * LD + c]; }
 }
 
 // ---- pass B: contiguous, persistent blocks over (n_hi x columns) tiles: inverse second half + forward first half of every coset ----
@@ -677,20 +766,22 @@ __global__ void __launch_bounds__(1024) k_lde_mid14(DMatView src, DMatView dst, 
 }
 
 // ---- pass C: forward, strided, transposing store: grid = (n_lo / T, columns, cosets) --------------------
-__global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int logT, DeviceTables tb
+template <int FK_HI, int FLOGT>  // as k_lde_a
+__global__ void __launch_bounds__(FK_HI ? 512 : 1024) k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int logT_arg, DeviceTables tb
 #if VGPU_STANDIN_FUSE
                         , int standin_perms, uint32_t* standin_o
 #endif
                         ) {
     extern __shared__ uint32_t lds[];
-    const int k_hi = k - k_lo, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
+    const int k_hi = FK_HI ? FK_HI : k - k_lo, logT = FK_HI ? FLOGT : logT_arg, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
     const uint64_t n_lo = 1ull << k_lo, N = 1ull << k, q0 = (uint64_t)strided_tile_of_block(blockIdx.x, gridDim.x) * T;
     const uint32_t tc = blockIdx.z, blk = lb ? __brev(tc) >> (32 - lb) : 0u;
     uint32_t* tw = lds + n_hi * LD;
     const uint32_t* in = src.col(blockIdx.y) + (uint64_t)tc * N + q0;
     uint32_t* out = dst.col(blockIdx.y) + (uint64_t)blk * N;
     const int total = n_hi << logT;
-    {
+    if constexpr (FK_HI != 0) strided_tile_load<FK_HI, FLOGT, true>(in, (uint32_t)n_lo, lds);
+    else {
         // tile row h (= c_a) lives in block bitrev(h) of S2
         int e = threadIdx.x;
         for (; e + 7 * (int)blockDim.x < total; e += 8 * blockDim.x) {
@@ -712,8 +803,12 @@ __global__ void k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int
     }
     stage_twiddles(tw, tb.twc, k_hi);
     __syncthreads();
-    strided_tile_transform<false>(lds, tw, k_hi, logT, LD);  // DIF with forward roots: row p'' holds f_a = bitrev(p'')
+    if constexpr (FK_HI != 0) strided_transform<false, FK_HI, FLOGT>(lds, tw);  // DIF with forward roots: row p'' holds f_a = bitrev(p'')
+    else tile_transform<false, false>(lds, tw, k_hi, logT, LD);
     // element (p'', q0 + c) -> out[bitrev_{k_lo}(q0 + c) n_hi + p'']: n_hi consecutive words per c (LDS read with the odd stride LD: conflict-free)
+    const uint32_t tile = strided_tile_of_block(blockIdx.x, gridDim.x);
+    if constexpr (FK_HI != 0) strided_tile_store_transposed<FK_HI, FLOGT>(out, tile, k_lo, lds);
+    else
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int p2 = e & (n_hi - 1), c = e >> k_hi;
         const uint32_t qb = __brev((uint32_t)(q0 + c)) >> (32 - k_lo);
@@ -753,10 +848,14 @@ static void set_lds_limit() {
     (void)hipFuncSetAttribute((const void*)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_intt_contig, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_ntt_contig, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)k_lde_a, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_a<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_a<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_a<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_mid<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_mid<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)k_lde_c, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_c<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_c<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)k_lde_c<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_mid12, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void*)k_lde_mid14, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     done = true;
@@ -840,7 +939,10 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
     dim3 gs((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)nat.width);
     {
         ProfScope ps("k_lde_a", st, 2.0 * nw);
-        VK_LAUNCH(k_lde_a, gs, dim3(p.threads_strided), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
+        const int shape = VGPU_STRIDED_IO && VGPU_STRIDED_FIXED && p.threads_strided == 512 ? (p.k_hi == 8 && p.logT == 6 ? 8 : (p.k_hi == 10 && p.logT == 4 ? 10 : 0)) : 0;
+        if (shape == 8) VK_LAUNCH((k_lde_a<8, 6>), gs, dim3(512), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
+        else if (shape == 10) VK_LAUNCH((k_lde_a<10, 4>), gs, dim3(512), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
+        else VK_LAUNCH((k_lde_a<0, 0>), gs, dim3(p.threads_strided), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
     }
     static const bool mid12 = [] { const char* e = getenv("VGPU_LDE_MID12"); return !(e && e[0] == '0'); }();
     static const bool mid14 = [] { const char* e = getenv("VGPU_LDE_MID14"); return !(e && e[0] == '0'); }();
@@ -859,11 +961,16 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
     }
     dim3 gc((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)nat.width, 1u << log_blowup);
     ProfScope ps("k_lde_c", st, 2.0 * nw * b);
+    const int shape_c = VGPU_STRIDED_IO && VGPU_STRIDED_FIXED && p.threads_strided == 512 ? (p.k_hi == 8 && p.logT == 6 ? 8 : (p.k_hi == 10 && p.logT == 4 ? 10 : 0)) : 0;
 #if VGPU_STANDIN_FUSE
-    VK_LAUNCH(k_lde_c, gc, dim3(p.threads_strided), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb, (int)((double)((1u << p.k_hi) << p.logT) * g_standin_perms_per_elem + 0.5), standin_out());
+#define VG_LDE_C(A, B, THREADS) VK_LAUNCH((k_lde_c<A, B>), gc, dim3(THREADS), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb, (int)((double)((1u << p.k_hi) << p.logT) * g_standin_perms_per_elem + 0.5), standin_out())
 #else
-    VK_LAUNCH(k_lde_c, gc, dim3(p.threads_strided), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb);
+#define VG_LDE_C(A, B, THREADS) VK_LAUNCH((k_lde_c<A, B>), gc, dim3(THREADS), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb)
 #endif
+    if (shape_c == 8) VG_LDE_C(8, 6, 512);
+    else if (shape_c == 10) VG_LDE_C(10, 4, 512);
+    else VG_LDE_C(0, 0, p.threads_strided);
+#undef VG_LDE_C
 }
 
 }  // namespace vk
