@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, session 12: the GPU_MAX_HW_QUEUES x in-flight corners round 4's sweep left out (6 x 3, 8 x 3, 8 x 4, 3 x 3, 2 x 3), final code, alternating.
+# Round 5, session 12: GPU_MAX_HW_QUEUES x in-flight corners that round 4's sweep left out, final code, alternating (first run: 4x3 6x3 8x3 8x4 3x3 2x3 into r5s12; this list: the second run, r5s12b).
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r5s12b; mkdir -p "$OUT"; export TMPDIR=/tmp
 echo "# queues in-flight proofs/s ms/step" > "$OUT/sweep.txt"
