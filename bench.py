@@ -160,6 +160,27 @@ def roofline_object(name, stat, achieved_gbs, traffic, traffic_src, valu, steps)
                 peak_is=valu.get("peak_is"), hbm=hbm)
 
 
+def sustained_object(sus, world, kernel, valu_roofline, b_alg):
+    """The bench line's `sustained`: proofs/s and ms per step over the long region, its mean shader clock, and the dominant kernel's live
+    roofline of that region — at the guide's 2.4 GHz (a bound whatever the clock does) and at the region's own measured clock (what the
+    kernel makes of the cycles it was given)."""
+    ms_step = sus["seconds"] / sus["steps"] * 1e3
+    clk = sum(sus["clock"]) / len(sus["clock"]) if sus["clock"] else None
+    out = {"proofs_per_s": world * sus["steps"] / sus["seconds"], "ms_per_step": ms_step, "seconds": sus["seconds"], "steps": sus["steps"],
+           "shader_clock_GHz": None if clk is None else clk / 1e9,
+           "shader_clock_GHz_min_max": None if clk is None else [min(sus["clock"]) / 1e9, max(sus["clock"]) / 1e9],
+           "proof_hbm_frac": b_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    st = sus["prof"].get(kernel)
+    if st and st[1] > 0:
+        out["roofline"] = {"kernel": kernel, "avg_launch_ms": st[1] / st[0], "hbm_achieved_GBs": st[2] / (st[1] * 1e-3) / 1e9,
+                           "hbm_frac": st[2] / (st[1] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        v = valu_roofline(st) if st[3] > 0 else None
+        if v:
+            out["roofline"].update({"bound": "valu", "achieved": v["achieved"], "unit": v["unit"], "peak_at_guide_clock": v["peak"], "frac_at_guide_clock": v["frac"],
+                                    "frac_at_measured_clock": None if clk is None else v["frac"] * GUIDE_CLOCK_HZ / clk})
+    return out
+
+
 def cpu_baseline(log_rows, rc, headline_log_rows, mmcs_poseidon=False, scalar_too=False):
     """The oracle (CPU restatement of the reference's algorithm, C++/OpenMP on every host core) timed on the SAME workload the GPU
     is timed on — the headline 2^20-row segment itself by default, one proof, no extrapolation — in its FAST mode (oracle/fast.hpp: AVX2
@@ -244,6 +265,54 @@ def sharded_leg_process(args):
     os._exit(0)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started the way the N = 1 line is started (no launcher, no WORLD_SIZE): this process becomes the launcher —
+    N copies of this very command line, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), rank 0's
+    stdout (the ONE JSON line) passed through, the first failing rank's status returned after the others were ended.  The
+    `python -m torch.distributed.run ... bench.py --gpus N` form sets WORLD_SIZE itself and never comes here."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+    status, deadline = 0, time.time() + float(os.environ.get("VGPU_BENCH_SPAWN_TIMEOUT", "3000"))
+    alive = list(procs)
+    while alive and status == 0:
+        time.sleep(0.2)
+        for p_ in list(alive):
+            rc_ = p_.poll()
+            if rc_ is not None:
+                alive.remove(p_)
+                if rc_ != 0:
+                    status = rc_ if rc_ > 0 else 128 - rc_
+                    print("bench.py: rank %d ended with status %d; ending the other ranks" % (procs.index(p_), rc_), file=sys.stderr, flush=True)
+        if time.time() > deadline:
+            status = 124
+            print("bench.py: ranks still running at the launcher's deadline; ending them", file=sys.stderr, flush=True)
+    for p_ in alive:  # exact process groups this launcher started, never a pattern
+        try:
+            os.killpg(p_.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+    for p_ in alive:
+        try:
+            p_.wait(10)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p_.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+    sys.exit(status)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +327,8 @@ def main():
                          "(one proof's latency-bound FRI/Merkle-top tail overlaps the next proof's throughput-bound commits)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the latency / PCIe-inclusive / operation-log legs (profiling runs: the process then consists of the warmup and the timed region only)")
+    ap.add_argument("--sustained-seconds", type=float, default=6.0,
+                    help="length of the SUSTAINED region run right after the contract's K steps (same loop, same fences; reported as `sustained`, never as `value`); 0 = skip")
     ap.add_argument("--no-clock-probe", action="store_true", help="do not sample the shader clock over the timed region (A/B of the probe itself)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="experiment: no per-launch HIP events in the timed region (then no per-kernel figures / roofline in the line)")
@@ -270,6 +341,8 @@ def main():
     args = ap.parse_args()
     if args.sharded_leg:
         return sharded_leg_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     # Pin the measured configuration before the HIP runtime starts: 3 prover contexts x (main + 1 aux stream) over FOUR hardware
     # queues (the runtime's default; other counts measured worse, DESIGN.md "Measurement").
@@ -283,13 +356,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if world != args.gpus and rank == 0:  # a launcher's WORLD_SIZE wins: the line's n_gpus is the number of ranks that ran
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; running with %d ranks" % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if os.environ.get("VGPU_BENCH_TEST_EXIT_RANK") == str(rank) and world > 1:  # test hook: this rank dies before the rendezvous (tests/test_gpu_parity.py)
+        sys.exit(7)
     # test hooks (a 1-GPU box exercising the N > 1 control flow): every rank on one device, gloo instead of RCCL
     backend = os.environ.get("VGPU_BENCH_BACKEND", "nccl")
     if "VGPU_BENCH_DEVICE" in os.environ:
@@ -568,43 +640,68 @@ def main():
     dominant = max((prof1 or table).items(), key=lambda kv: kv[1][1])[0]
     if dominant not in table:
         dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
-    for p_ in provers:
-        p_.set_profiling(not args.no_kernel_events, only=dominant)
-    # The shader clock the device sustains under THIS load, sampled over the timed region by one probing wave every 40 ms (libvgpu:
-    # vgpu_shader_clock_probe; rocm-smi is blind here): the rooflines' issue bounds are priced at the guide's 2.4 GHz.
-    clock_samples, clock_stop = [], None
+    # The shader clock the device sustains under THIS load, sampled over a timed region by one probing wave every 40 ms (libvgpu:
+    # vgpu_shader_clock_probe; rocm-smi is blind here): the rooflines' issue bounds are priced at the guide's 2.4 GHz AND at this clock.
+    import threading
+
     if not args.no_clock_probe:
-        import threading
-        clock_stop = threading.Event()
+        va.shader_clock_hz(local_rank, 4096)  # creates the probe's stream outside the timed regions
 
-        def sample_clock():
-            try:
-                while not clock_stop.is_set():
-                    clock_samples.append(va.shader_clock_hz(local_rank, 2048))
-                    clock_stop.wait(0.04)
-            except Exception as e:  # noqa: BLE001 - a measurement aid must not cost the line
-                print("bench: clock probe stopped (%s: %s)" % (type(e).__name__, e), file=sys.stderr, flush=True)
+    def timed_region(k):
+        """EXACTLY k steps between two fences; returns (seconds, phase sums, per-kernel profile of the region, clock samples, last proof)."""
+        samples, stop, th = [], None, None
+        if not args.no_clock_probe:
+            stop = threading.Event()
 
-        va.shader_clock_hz(local_rank, 4096)  # creates the probe's stream outside the timed region
-        clock_thread = threading.Thread(target=sample_clock, daemon=True)
-    fence()
-    if clock_stop is not None:
-        clock_thread.start()
-    t0 = time.perf_counter()
-    phase = {}
-    for p in run_steps(args.steps):
-        for k, v in p.phase_ms.items():
-            phase[k] = phase.get(k, 0.0) + v
-    fence()
-    elapsed = time.perf_counter() - t0
-    if clock_stop is not None:
-        clock_stop.set()
-        clock_thread.join(5)
-    prof = {}
+            def sample_clock():
+                try:
+                    while not stop.is_set():
+                        samples.append(va.shader_clock_hz(local_rank, 2048))
+                        stop.wait(0.04)
+                except Exception as e:  # noqa: BLE001 - a measurement aid must not cost the line
+                    print("bench: clock probe stopped (%s: %s)" % (type(e).__name__, e), file=sys.stderr, flush=True)
+
+            th = threading.Thread(target=sample_clock, daemon=True)
+        for p_ in provers:  # events on the dominant kernel's launches only; resets the accumulators
+            p_.set_profiling(not args.no_kernel_events, only=dominant)
+        fence()
+        if th is not None:
+            th.start()
+        t0_ = time.perf_counter()
+        phase_, last = {}, None
+        for last in run_steps(k):
+            for k_, v in last.phase_ms.items():
+                phase_[k_] = phase_.get(k_, 0.0) + v
+        fence()
+        dt = time.perf_counter() - t0_
+        if stop is not None:
+            stop.set()
+            th.join(5)
+        prof_ = {}
+        for p_ in provers:
+            for k_, v in p_.profile().items():
+                a = prof_.get(k_, (0, 0.0, 0.0, 0.0))
+                prof_[k_] = (a[0] + v[0], a[1] + v[1], a[2] + v[2], a[3] + v[3])
+        return dt, phase_, prof_, samples, last
+
+    elapsed, phase, prof, clock_samples, p = timed_region(args.steps)  # THE contract region: W warmup steps done above, exactly K steps here
+    # The SUSTAINED figure: the same loop for >= --sustained-seconds right behind the contract region (round-5 verdict: a 0.3 s burst runs at
+    # 2.35-2.4 GHz, the device settles at 2.2 GHz after a few seconds of this load; a production prover lives in the second regime).
+    sustained = None
+    if args.sustained_seconds > 0:
+        s_steps = max(args.steps, int(np.ceil(args.sustained_seconds / (elapsed / args.steps))))
+        s_steps = -(-s_steps // len(provers)) * len(provers)
+        if world > 1:  # every rank must run the same number of steps (one collective per step)
+            ns = torch.tensor([s_steps], dtype=torch.int64, device=coll_device)
+            dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=coll_group)
+            s_steps = int(ns.item())
+        s_elapsed, _, s_prof, s_clock, _ = timed_region(s_steps)
+        if world > 1:
+            tm = torch.tensor([s_elapsed], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX, group=coll_group)
+            s_elapsed = float(tm.item())
+        sustained = {"steps": s_steps, "seconds": s_elapsed, "prof": s_prof, "clock": s_clock}
     for p_ in provers:
-        for k, v in p_.profile().items():
-            a = prof.get(k, (0, 0.0, 0.0, 0.0))
-            prof[k] = (a[0] + v[0], a[1] + v[1], a[2] + v[2], a[3] + v[3])
         p_.set_profiling(False)
 
     # the last proof of the timed region through the library's own Machine::verify (host code; never inside a timed region)
@@ -619,10 +716,19 @@ def main():
     except Exception as e:  # noqa: BLE001 - reporting only
         verified = {"accepted": False, "reason": "%s: %s" % (type(e).__name__, e)}
 
+    rank_devices = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=coll_group)
         elapsed = float(tmax.item())
+        # which device every rank ran on (the line must show one rank per GPU, or say that it was a one-device stand-in)
+        try:
+            props = torch.cuda.get_device_properties(local_rank)
+            mine = {"rank": rank, "device": local_rank, "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+        except Exception as e:  # noqa: BLE001 - reporting only
+            mine = {"rank": rank, "device": local_rank, "error": str(e)}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine, group=ctl if ctl is not None else coll_group)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -703,6 +809,13 @@ def main():
                 "parallelism": ("segments: one independent proof per GPU + all-gather of 3 roots per proof via " + comm_note) if world > 1 else "single GPU",
                 "proofs_in_flight_per_gpu": len(provers),
                 "comm_stuck": bool(comm_stuck),  # true: the library's RCCL bring-up timed out somewhere and the job's collectives ran over gloo
+                # N > 1: what the collective saw in the LAST step — rows of the gathered root table (one per rank), how many of them differ
+                # (segments differ by loop bound, so every rank's roots are its own), and the device each rank ran on
+                "collective": None if world == 1 else {
+                    "backend": backend, "route": comm_note, "ranks_in_last_allgather": None if all_roots[0] is None else int(all_roots[0].shape[0]),
+                    "distinct_root_sets": None if all_roots[0] is None else len({tuple(int(x) for x in r) for r in all_roots[0]}),
+                    "rank_devices": rank_devices,
+                    "distinct_devices": None if not rank_devices else len({(d.get("device"), d.get("uuid")) for d in rank_devices})},
             },
             "roofline": roofline_object(name, prof[name], achieved, traffic, traffic_src, keccak_roofline(prof[name]) if valu_ops > 0 else None, args.steps),
             # The dominant kernel is Keccak-f[1600] over Merkle nodes: 32-bit integer VALU work, ~4200 instructions per 96 B moved, so
@@ -721,15 +834,22 @@ def main():
                 "issue_bound_full_rate": GUIDE_SIMDS * GUIDE_CLOCK_HZ / GUIDE_FULL_CYCLES,
                 "frac_of_issue_bound_full_rate": proof_instr / (ms_per_step * 1e-3) / (GUIDE_SIMDS * GUIDE_CLOCK_HZ / GUIDE_FULL_CYCLES),
                 "frac_of_issue_bound_half_rate": proof_instr / (ms_per_step * 1e-3) / (GUIDE_SIMDS * GUIDE_CLOCK_HZ / GUIDE_HALF_CYCLES),
+                "frac_of_issue_bound_full_rate_at_measured_clock": None if not clock_samples else proof_instr / (ms_per_step * 1e-3) / (GUIDE_SIMDS * (sum(clock_samples) / len(clock_samples)) / GUIDE_FULL_CYCLES),
+                "sustained_frac_of_issue_bound_full_rate": None if not sustained else proof_instr / (sustained["seconds"] / sustained["steps"]) / (GUIDE_SIMDS * GUIDE_CLOCK_HZ / GUIDE_FULL_CYCLES),
+                "sustained_frac_of_issue_bound_full_rate_at_measured_clock": None if not sustained or not sustained["clock"] else
+                    proof_instr / (sustained["seconds"] / sustained["steps"]) / (GUIDE_SIMDS * (sum(sustained["clock"]) / len(sustained["clock"])) / GUIDE_FULL_CYCLES),
                 "frac_of_full_rate_peak": proof_instr / (ms_per_step * 1e-3) / mb["full_rate"], "frac_of_half_rate_peak": proof_instr / (ms_per_step * 1e-3) / mb["half_rate"],
                 "note": "instruction counts from the committed PMC pass (SQ_INSTS_VALU per launch) x this run's launches per step; the proof's mix of full- and "
                         "half-rate instructions puts its issue peak between the two"},
             "shader_clock": None if not clock_samples else {
                 "GHz_mean": sum(clock_samples) / len(clock_samples) / 1e9, "GHz_min": min(clock_samples) / 1e9, "GHz_max": max(clock_samples) / 1e9, "samples": len(clock_samples),
                 "guide_GHz": GUIDE_CLOCK_HZ / 1e9,
-                "roofline_frac_at_the_sustained_clock": None if valu_ops <= 0 else keccak_roofline(prof[name])["frac"] * GUIDE_CLOCK_HZ / (sum(clock_samples) / len(clock_samples)),
+                "roofline_frac_at_the_measured_clock": None if valu_ops <= 0 else keccak_roofline(prof[name])["frac"] * GUIDE_CLOCK_HZ / (sum(clock_samples) / len(clock_samples)),
                 "how": "one wave of another stream every 40 ms over the timed region: shader cycles of 2048 dependent VALU additions against the 100 MHz wall clock "
                        "(vgpu_shader_clock_probe); the issue bounds in `roofline` / `valu_roofline` / `proof_valu_roofline` are priced at the guide's clock"},
+            # >= --sustained-seconds of the same loop right behind the contract region: what a prover that never stops delivers (the device's clock
+            # management settles below the burst clock); the dominant kernel's roofline of THAT region priced at the guide's clock and at its own
+            "sustained": None if not sustained else sustained_object(sustained, world, name, keccak_roofline, b_alg),
             "proof_roofline": {"algorithmic_bytes_per_proof": b_alg, "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9, "frac_of_hbm_peak": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "phase_ms": {k: v / args.steps for k, v in phase.items()},
             "kernel_ms_per_step": {k: v[1] / table_steps for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])},

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B builds of ONE kernel file: compile it with extra -D flags and link it with the current objects of everything else into
-build/variants/<name>/libvgpu.so (picked up through VGPU_LIB_PATH; tools/gpu_ab*.sh alternate libraries inside one GPU session).
+build/variants/<name>/libvgpu.so (picked up through VGPU_LIB_PATH; tools/gpu_session.sh alternates candidates "label=LIB:build/variants/<name>/libvgpu.so" inside one GPU session).
 
     python tools/build_variant.py <name> kernels/ntt.hip|ALL -DVGPU_MID12_WAVES=4 [-D...]
 """

@@ -809,8 +809,11 @@ class Fabric:
             _check(lib().vgpu_prove_sharded_fabric(prover._h, ctypes.byref(self.c), arr, ctypes.c_uint32(len(main)), chips, parr, ctypes.c_uint32(len(preprocessed)),
                                                    ctypes.c_uint32(log_min_sharded), ctypes.byref(h)))
             return Proof(h)
-        except VgpuError:
-            if self.c.timeout_ms:  # the failure may be a callback abandoned at the deadline: its thunks must stay valid
+        except VgpuError as e:
+            # only a callback ABANDONED at the deadline (VGPU_ERR_FABRIC with the library's "callback is abandoned", csrc/host/fabric.hpp) leaves a library
+            # thread inside one of this object's thunks: those must stay valid for the life of the process.  Argument errors, dead peers and failpoints
+            # leave nothing behind, and a host that retries must not pin every Fabric it ever made.
+            if self.c.timeout_ms and e.code == -6 and "callback is abandoned" in str(e) and not any(f is self for f in _ABANDONED_FABRICS):
                 _ABANDONED_FABRICS.append(self)
             raise
 

@@ -77,10 +77,16 @@ def build_vgpu(force=False):
     _FORCE = bool(force)
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(_compile, SOURCES))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]  # librccl.so is dlopen'ed on first use (host/comm.hpp)
+    # linked beside the library and renamed onto it: a process that has the old libvgpu.so mapped keeps its (unlinked) file instead of seeing the
+    # linker rewrite the pages under it; librccl.so is dlopen'ed on first use (host/comm.hpp)
+    tmp = os.path.join(BUILD, "libvgpu.%d.so" % os.getpid())
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
         raise RuntimeError("link failed:\n" + r.stderr)
+    os.replace(tmp, LIB)
     LAST["linked"] = True
     return LIB
 

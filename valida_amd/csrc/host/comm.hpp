@@ -88,10 +88,13 @@ struct Comm {
     // milliseconds; bench.py uses 120 s.
     hipEvent_t start_ev = nullptr;
     bool start_marked = false;
+    hipStream_t start_stream = nullptr;  // the stream the mark was recorded on: a mark left behind by an enqueue that threw is never applied to another stream's wait
     void mark_start(hipStream_t s) {
         if (!start_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&start_ev, hipEventDisableTiming));
+        start_marked = false;
         VG_HIP_CHECK(hipEventRecord(start_ev, s));
         start_marked = true;
+        start_stream = s;
     }
     // staging of the RCCL fabric's all-gathers (fabric.hpp: RcclFabric), owned here so that it outlives the per-proof fabric objects
     uint32_t* fab_dev = nullptr;
@@ -137,7 +140,11 @@ struct Comm {
         if (!deadline_ms) { start_marked = false; VG_HIP_CHECK(hipStreamSynchronize(s)); return; }
         if (!wait_ev) VG_HIP_CHECK(hipEventCreateWithFlags(&wait_ev, hipEventDisableTiming));
         VG_HIP_CHECK(hipEventRecord(wait_ev, s));
-        if (start_marked) { start_marked = false; VG_HIP_CHECK(hipEventSynchronize(start_ev)); }  // local work queued ahead of the collective: not the collective's time
+        // local work queued ahead of the collective is not the collective's time.  Only a mark of THIS stream counts (one recorded earlier on the same
+        // stream by an enqueue that then threw lies before everything waited for here: harmless); any other stale mark is dropped.
+        const bool mine = start_marked && start_stream == s;
+        start_marked = false;
+        if (mine) VG_HIP_CHECK(hipEventSynchronize(start_ev));
         const auto t0 = std::chrono::steady_clock::now();
         auto& api = RcclApi::get();
         for (unsigned spin = 0;; spin++) {

@@ -28,7 +28,9 @@
 // segfault, OOM kill — can therefore cost the survivors at most timeout_ms, not a hang.
 // LocalFabric drives all ranks from one thread: nothing to agree on, nothing to time out.
 #pragma once
+#include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -157,23 +159,58 @@ struct Fabric {
 
 struct LocalFabric : Fabric {
     explicit LocalFabric(int w) { world = w; for (int r = 0; r < w; r++) hosted.push_back(r); }
+    ~LocalFabric() override { if (stage_host) (void)hipHostFree(stage_host); }
     // Contexts on DIFFERENT devices (vgpu_prove_sharded_local over several GPUs of one process): the strided device-to-device copies below need
-    // peer access between the two devices, which the library never enabled.  Enabled once per ordered pair; a pair the driver cannot
-    // connect is an error here, not a silent slow path.
-    static void ensure_peer_access(int dev, int peer) {
-        if (dev == peer) return;
-        static std::mutex mu;
-        static std::vector<std::pair<int, int>> done;
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto& pr : done) if (pr.first == dev && pr.second == peer) return;
-        int can = 0;
-        VG_HIP_CHECK(hipDeviceCanAccessPeer(&can, dev, peer));
-        if (!can) throw std::runtime_error("hip: fabric: device " + std::to_string(dev) + " cannot access device " + std::to_string(peer) + " (no peer path): use one process per GPU (vgpu_prove_sharded)");
-        VG_HIP_CHECK(hipSetDevice(dev));
-        const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) throw std::runtime_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
-        (void)hipGetLastError();
-        done.emplace_back(dev, peer);
+    // peer access between the two devices.  Decided ONCE per fabric (first all-to-all), outside the copy loops: every ordered pair of distinct
+    // devices is either connected (hipDeviceEnablePeerAccess; process-wide, so "already enabled" is fine) or marked STAGED — its copies go
+    // through page-locked host memory, with one warning on stderr (a slow path that says so; one process per GPU, vgpu_prove_sharded, avoids it).
+  private:
+    bool peers_ready = false;
+    std::vector<std::pair<int, int>> staged_pairs;  // (reader device, owner device) without a peer path
+    uint32_t* stage_host = nullptr;
+    size_t stage_words = 0;
+    void prepare_peers(const std::vector<A2A>& plan) {
+        if (peers_ready) return;
+        std::vector<int> devs;
+        for (auto& p : plan) if (std::find(devs.begin(), devs.end(), p.c->device) == devs.end()) devs.push_back(p.c->device);
+        for (int dev : devs)
+            for (int peer : devs) {
+                if (dev == peer) continue;
+                int can = 0;
+                VG_HIP_CHECK(hipDeviceCanAccessPeer(&can, dev, peer));
+                if (can) {
+                    VG_HIP_CHECK(hipSetDevice(dev));
+                    const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) throw std::runtime_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                    (void)hipGetLastError();
+                } else {
+                    staged_pairs.emplace_back(dev, peer);
+                    fprintf(stderr, "vgpu: fabric: device %d has no peer path to device %d: exchanges between them are staged through host memory (slow); "
+                                    "one process per GPU (vgpu_prove_sharded) uses RCCL instead\n", dev, peer);
+                }
+            }
+        peers_ready = true;
+    }
+    bool staged(int reader, int owner) const {
+        return reader != owner && std::find(staged_pairs.begin(), staged_pairs.end(), std::make_pair(reader, owner)) != staged_pairs.end();
+    }
+    void copy_staged(const std::vector<Seg>& from, int from_dev, const std::vector<Seg>& to, int to_dev) {
+        if (from.size() != to.size()) throw std::logic_error("fabric: send / receive segment lists disagree");
+        for (size_t k = 0; k < from.size(); k++) {
+            if (from[k].run != to[k].run || from[k].n_runs != to[k].n_runs) throw std::logic_error("fabric: send / receive segments of different shapes");
+            if (from[k].words() > stage_words) {
+                if (stage_host) VG_HIP_CHECK(hipHostFree(stage_host));
+                stage_host = nullptr;
+                stage_words = from[k].words();
+                VG_HIP_CHECK(hipHostMalloc((void**)&stage_host, stage_words * 4, hipHostMallocPortable));
+            }
+            VG_HIP_CHECK(hipSetDevice(from_dev));
+            copy_seg(stage_host, from[k].run, from[k].p, from[k].pitch, from[k], hipMemcpyDeviceToHost, nullptr);
+            VG_HIP_CHECK(hipStreamSynchronize(nullptr));
+            VG_HIP_CHECK(hipSetDevice(to_dev));
+            copy_seg(to[k].p, to[k].pitch, stage_host, from[k].run, from[k], hipMemcpyHostToDevice, nullptr);
+            VG_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
     }
   protected:
     void ag_transport(const std::vector<const uint32_t*>& contrib, size_t n, std::vector<uint32_t>& out) override {
@@ -181,13 +218,14 @@ struct LocalFabric : Fabric {
         for (int r = 0; r < world; r++) if (n) memcpy(out.data() + (size_t)r * n, contrib[r], n * 4);
     }
     void a2a_transport(std::vector<A2A>& plan) override {
+        prepare_peers(plan);
         // every context's queued work first: the blocks to be sent must be complete, and a receive buffer fresh from a context's pool
         // may still be read by kernels that context enqueued before the block was recycled (the pool orders reuse on the context's OWN
         // stream only; the copies below run outside it)
         for (auto& p : plan) { p.c->activate(); p.c->sync(); }
         for (int r = 0; r < world; r++)
             for (int s = 0; s < world; s++) {
-                ensure_peer_access(plan[s].c->device, plan[r].c->device);
+                if (staged(plan[s].c->device, plan[r].c->device)) { copy_staged(plan[r].send[(size_t)s], plan[r].c->device, plan[s].recv[(size_t)r], plan[s].c->device); continue; }
                 VG_HIP_CHECK(hipSetDevice(plan[s].c->device));
                 copy_matching(plan[r].send[(size_t)s], plan[s].recv[(size_t)r], plan[s].c->stream);
             }

@@ -201,20 +201,12 @@ inline DMat coset_lde(DeviceCtx* c, hipStream_t st, const CommitInput& in, unsig
     if (!in.rows_bitrev && fused) {
         DMat lde(c, n * b, in.mat->width);
         const vk::LdeTables lt = c->lde_tables((int)k, (int)log_blowup, lde_shift);
+        // scratch of passes A -> MID (S1: n rows) and MID -> C (S2: b n rows).  (Column groups sized for the Infinity Cache with the scratch reused were
+        // measured in round 5 and sped up no pass at any size: profiles/r05_ab_session1_standin_groups_quotient.txt.)
         DMat s1, s2;
-        // VGPU_LDE_GROUP_MB=m (experiment, off by default): the three passes run column group after column group, the groups sized so that the two
-        // scratch matrices of one group (S1: n, S2: b n words per column) take about m MiB and are REUSED by every group — passes B and C then
-        // read what the pass before has just written (256 MiB Infinity Cache), and the scratch lines are overwritten before they are written back.
-        static const uint64_t group_mb = [] { const char* e = getenv("VGPU_LDE_GROUP_MB"); return e ? (uint64_t)atoll(e) : 0ull; }();
-        uint64_t gcols = in.mat->width;
-        if (k > 12 && group_mb) gcols = std::max<uint64_t>(1, std::min<uint64_t>(gcols, (group_mb << 20) / (n * 4 * (1 + b))));
-        if (k > 12) { s1 = DMat(c, n, gcols); s2 = DMat(c, n * b, gcols); }
-        for (uint64_t c0 = 0; c0 < in.mat->width; c0 += gcols) {
-            const uint64_t w = std::min<uint64_t>(gcols, in.mat->width - c0);
-            const vk::DMatView nat{in.mat->data + c0 * n, n, w, n}, out{lde.data + c0 * n * b, n * b, w, n * b};
-            vk::launch_lde_natural(st, nat, out, (int)log_blowup, c->tables, lt, s1.empty() ? vk::DMatView{nullptr, 0, 0, 0} : vk::DMatView{s1.data, n, w, n},
-                                   s2.empty() ? vk::DMatView{nullptr, 0, 0, 0} : vk::DMatView{s2.data, n * b, w, n * b});
-        }
+        if (k > 12) { s1 = DMat(c, n, in.mat->width); s2 = DMat(c, n * b, in.mat->width); }
+        vk::launch_lde_natural(st, in.mat->view(), lde.view(), (int)log_blowup, c->tables, lt, s1.empty() ? vk::DMatView{nullptr, 0, 0, 0} : s1.view(),
+                               s2.empty() ? vk::DMatView{nullptr, 0, 0, 0} : s2.view());
         c->check_launch("coset_lde");
         return lde;  // s1 / s2 return to the pool while the kernels may still be queued: safe for the same reason as `coeffs` below
     }
@@ -251,13 +243,9 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
                                                   const FriParams& fri, const CommitRider* rider = nullptr) {
     auto pd = std::make_unique<ProverData>();
     Fp g = Fp::from_canonical(vg::GENERATOR);
-    // Per-matrix LDE pipelines are independent.  The tallest matrices are extended first, on the main stream; everything else goes to the
-    // auxiliary stream and is only joined when the tree reaches the first layer that injects shorter rows: the leaf hashes and the first
-    // compression layers (pure integer-VALU work) overlap the remaining LDEs.  MEASURED (profiles/r03_ab_commit_overlap.json, one session):
-    // no gain — a lone proof 21.99 vs 22.03 ms (the overlapped kernels just stretch: both sides are issue-bound), three in flight
-    // 56.5 / 57.6 vs 57.8 proofs/s — so it stays OFF (VGPU_COMMIT_OVERLAP=1 turns it on); the default keeps the small matrices on the
-    // auxiliary stream and joins before the tree.
-    static const bool overlap = [] { const char* e = getenv("VGPU_COMMIT_OVERLAP"); return e && e[0] == '1'; }();
+    // Per-matrix LDE pipelines are independent: the tallest matrices are extended first, on the main stream, the small ones on the auxiliary
+    // stream, joined before the tree.  (Building the tree's first layers beside the remaining LDEs was measured in round 3 and bought nothing —
+    // both sides are issue-bound, profiles/r03_ab_commit_overlap.json — and is gone.)
     uint64_t maxh = 0;
     for (auto& m : mats) maxh = std::max<uint64_t>(maxh, m.mat->height);
     Section lde_section(c);
@@ -277,30 +265,15 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
             const bool tallest = mats[i].mat->height == maxh;
             if (tallest != (pass == 0)) continue;
             Fp shift = coset_shifts ? g * (*coset_shifts)[i].inv() : g;
-            hipStream_t st = overlap ? (tallest ? c->stream : c->aux[0]) : c->stream_for(i, mats[i].mat->height);
-#if VGPU_STANDIN_FUSE
-            {  // experiment build: this matrix's share of the row hashes of its height group (a row of W_h elements costs W_h / 34 + 1 permutations)
-                uint64_t wh = 0;
-                for (auto& m2 : mats) if (m2.mat->height == mats[i].mat->height) wh += m2.mat->width;
-                const bool big = (mats[i].mat->height << fri.log_blowup) > 65536 && c->hash_kind == 0;
-                vk::g_standin_perms_per_elem = big && wh ? (double)(wh / 34 + 1) / (double)wh : 0.0;
-            }
-#endif
+            hipStream_t st = c->stream_for(i, mats[i].mat->height);
             pd->ldes[i] = coset_lde(c, st, mats[i], fri.log_blowup, shift);
         }
     std::vector<vk::DMatView> views;
     for (auto& l : pd->ldes) views.push_back(l.view());
-    if (overlap) {
-        const std::function<void()> join = [&] { lde_section.join(); };
-        pd->tree.build(c, views, true, &join);
-        lde_section.join();  // a round of one height never injects
-    } else {
-        lde_section.join();
-        pd->tree.build(c, views);
-    }
-    // The rider's root: in the default branch the build above synchronised on the main stream AFTER it had waited for the auxiliary stream at the
-    // join; with VGPU_COMMIT_OVERLAP=1 a round of one height joins only after the build's synchronisation — so the auxiliary stream is
-    // synchronised here in its own right (it has long drained: microseconds).
+    lde_section.join();
+    pd->tree.build(c, views);
+    // The rider's root: the build above synchronised on the main stream AFTER it had waited for the auxiliary stream at the join; the auxiliary
+    // stream is still synchronised here in its own right (it has long drained: microseconds).
     if (rider) {
         VG_HIP_CHECK(hipStreamSynchronize(c->aux[0]));
         memcpy((*rider->out)->tree.root, c->rider_root_pin, 32);

@@ -15,7 +15,11 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
     : ctx_(new DeviceCtx(device)), machine_(machine), fri_(fri), perm16_(poseidon_rc480) {
     for (auto& a : machine_.airs) {
         if (a.log_quotient_degree < 1 || a.log_quotient_degree > 3) throw std::invalid_argument("chip " + a.name + ": log_quotient_degree must be 1..3");
-        if (a.log_quotient_degree != 1 && a.native_chip >= -1) throw std::invalid_argument("chip " + a.name + ": the compiled chip kernels assume log_quotient_degree = 1");
+        // native_chip: a BasicMachine ChipId (0..13: eval and interactions compiled into the kernels) or -2 (captured AIR: interpreted program + encoded
+        // interactions).  Nothing else — in particular not -1, which only exists INSIDE the launchers as the template argument "no AIR constraints" that
+        // program / mem / div / range map to — so that what is accepted does not depend on which quotient kernel a switch selects.
+        if (a.native_chip != -2 && (a.native_chip < 0 || a.native_chip >= 14)) throw std::invalid_argument("chip " + a.name + ": native_chip must be a BasicMachine chip id (0..13) or -2 (captured AIR)");
+        if (a.log_quotient_degree != 1 && a.native_chip >= 0) throw std::invalid_argument("chip " + a.name + ": the compiled chip kernels assume log_quotient_degree = 1");
         if (fri_.log_blowup < a.log_quotient_degree)
             throw std::invalid_argument("chip " + a.name + ": log_blowup must be >= log_quotient_degree (the quotient domain must lie inside the committed LDE)");
         std::vector<uint32_t> pw(a.program.instrs.size() * 2 + 2, 0);
@@ -31,7 +35,6 @@ Prover::Prover(int device, const MachineDesc& machine, const uint32_t* poseidon_
     ctx_->hash_kind = fri_.hash_kind;
     ctx_->poseidon_tab = pow_pos_.data;
     ctx_->poseidon_sparse = sparse;
-    { const char* e = getenv("VGPU_PREP_CACHE"); prep_cache_enabled_ = e && e[0] == '1'; }
 }
 
 // challenger.grind(bits) with the search on the device; canonical rule = smallest witness.
@@ -371,15 +374,12 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
     // The preprocessed commitment is small (range table, program ROM: one-tile LDEs, a tree of single-workgroup launches) and independent of
     // the main one: it RIDES on the auxiliary stream beside the main round's big LDE passes and its root arrives with the main round's
     // synchronisation (pcs.hpp: CommitRider) instead of costing a commit and a synchronisation of its own in front of them.  The transcript
-    // order is the reference's: preprocessed root, then main root.  VGPU_PREP_RIDER=0: one after the other (A/B).
-    static const bool prep_rider = [] { const char* e = getenv("VGPU_PREP_RIDER"); return !(e && e[0] == '0'); }();
+    // order is the reference's: preprocessed root, then main root.  (One after the other: +0.3 ms per lone proof, profiles/r04_ab_latency.json.)
     ProverData* prep_pd = nullptr;
     std::vector<CommitInput> prep_in;
-    const bool ride = prep_rider && !prep_nat.empty() && !prep_hit;
-    if (!prep_nat.empty() && !prep_hit) {
+    const bool ride = !prep_nat.empty() && !prep_hit;
+    if (ride)
         for (auto& m : prep_nat) prep_in.push_back({&m, false, false});
-        if (!ride) prep_pd_cache_ = commit_batches(&c, prep_in, nullptr, fri_);
-    }
     std::unique_ptr<ProverData> main_pd;
     {
         std::vector<CommitInput> in;
@@ -555,7 +555,6 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
         }
         DBuf pool_dev(&c, pool);
         Section quotient_section(&c);
-        static const bool quot_natural = [] { const char* e = getenv("VGPU_QUOT_NATURAL"); return !(e && e[0] == '0'); }();
         for (size_t i = 0; i < NC; i++) {
             auto& air = machine_.airs[i];
             vk::QuotientArgs a{};
@@ -565,8 +564,8 @@ std::vector<uint32_t> Prover::prove(const std::vector<const DeviceTrace*>& main,
             quot[i] = DMat(&c, 1ull << log_deg[i], 5ull << air.log_quotient_degree);
             a.out = quot[i].view();
             // chunk rows in natural order (staged through LDS into 64-byte runs): the quotient round then takes the fused LDE like the other
-            // two; higher quotient degrees (k_quotient_general) keep the bit-reversed positions.  VGPU_QUOT_NATURAL=0: bit-reversed everywhere.
-            a.out_natural = quot_natural && air.log_quotient_degree == 1 ? 1 : 0;
+            // two; higher quotient degrees (k_quotient_general) keep the bit-reversed positions and the unfused passes.
+            a.out_natural = air.log_quotient_degree == 1 ? 1 : 0;
             quot_is_natural[i] = a.out_natural != 0;
             vk::launch_quotient(c.stream_for(i, 1ull << log_deg[i]), a, c.tables);
             quot_shifts[i] = s.exp_power_of_2(air.log_quotient_degree);  // lib.rs:593-596
@@ -729,7 +728,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     std::vector<Job> jobs;
     size_t out_words = 0;
     // the reduced openings' descriptor pool (built and UPLOADED before the opened-value kernels are enqueued, see below)
-    struct RLaunch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; int n_points; };
+    struct RLaunch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; int n_points; bool vec_ok; };
     std::vector<RLaunch> launches;
     DBuf reduce_pool_dev;
     size_t apw_at = 0, ydesc_at = 0, yoff_at = 0, n_y_slots = 0;
@@ -824,12 +823,13 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
                     std::vector<const MatEntry*> live;
                     size_t max_w = 0;
                     uint64_t total_width = 0;
+                    bool vec_ok = true;
                     for (auto& me : g.mats) {
                         bool any = false;
                         for (auto& t : me.pts) any |= std::get<0>(t) >= s0 && std::get<0>(t) < s1;
-                        if (any) { live.push_back(&me); max_w = std::max<size_t>(max_w, me.lde->width); total_width += me.lde->width; }
+                        if (any) { live.push_back(&me); max_w = std::max<size_t>(max_w, me.lde->width); total_width += me.lde->width; vec_ok &= vk::reduce_vec_ok(me.lde->data, me.lde->height); }
                     }
-                    launches.push_back({kv.first, pool.size(), s0 != 0, total_width, (int)(s1 - s0)});
+                    launches.push_back({kv.first, pool.size(), s0 != 0, total_width, (int)(s1 - s0), vec_ok});
                     pool.push_back((uint32_t)live.size());
                     pool.push_back(s1 - s0);
                     pool.push_back((uint32_t)max_w);
@@ -882,19 +882,19 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         }
         out_dev = DBuf(&c, out_words + 4);
         std::vector<DBuf> partials;
-        // the finishes of all column-dot launches in ONE launch behind the join (VGPU_DOT_FINISH_BATCH=0: a finish launch behind every column-dot launch; A/B):
-        // the job table is built and uploaded before the launches fork (a copy enqueued behind the join would wait for the other queue's signal)
-        static const bool finish_batch = [] { const char* e = getenv("VGPU_DOT_FINISH_BATCH"); return !(e && e[0] == '0'); }();
+        // the finishes of all column-dot launches in ONE launch behind the join (a finish launch behind every column-dot launch: +0.15 ms per lone proof,
+        // profiles/r05_ab_latency.txt; the sharded prover's single-stream openings keep that form): the job table is built and uploaded before the launches
+        // fork (a copy enqueued behind the join would wait for the other queue's signal)
         std::vector<uint32_t> fin_jobs;
         uint32_t fin_blocks = 0;
         for (auto& j : jobs) {
             const DMat& lde = rounds[j.r].pd->ldes[j.i];
             const uint64_t n = lde.height >> lb;
             partials.emplace_back(&c, (size_t)(vk::col_dot_slots(n) * j.cw * j.np * 5));
-            if (finish_batch) fin_blocks = vk::col_dot_finish_job(fin_jobs, fin_blocks, n, j.cw, j.np, partials.back().data, pool_dev.data + j.scale_off, out_dev.data + j.out_off);
+            fin_blocks = vk::col_dot_finish_job(fin_jobs, fin_blocks, n, j.cw, j.np, partials.back().data, pool_dev.data + j.scale_off, out_dev.data + j.out_off);
         }
         DBuf fin_dev;
-        if (finish_batch && !fin_jobs.empty()) fin_dev = DBuf(&c, fin_jobs);
+        if (!fin_jobs.empty()) fin_dev = DBuf(&c, fin_jobs);
         Section open_section(&c);
         size_t job_idx = 0;
         for (auto& j : jobs) {
@@ -902,11 +902,11 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
             const uint64_t n = lde.height >> lb;
             vk::DMatView sub{lde.data + j.c0 * lde.height, lde.height, j.cw, lde.height};
             vk::launch_col_dot(c.stream_for(job_idx, n), sub, n, j.np, wlist[j.w[0]].buf.data, wlist[j.w[1]].buf.data, partials[job_idx].data,
-                               pool_dev.data + j.scale_off, out_dev.data + j.out_off, !finish_batch);
+                               pool_dev.data + j.scale_off, out_dev.data + j.out_off, false);
             job_idx++;
         }
         open_section.join();
-        if (finish_batch && !fin_jobs.empty()) vk::launch_col_dot_finish_batch(c.stream, fin_dev.data, (uint32_t)jobs.size(), fin_blocks);
+        if (!fin_jobs.empty()) vk::launch_col_dot_finish_batch(c.stream, fin_dev.data, (uint32_t)jobs.size(), fin_blocks);
         c.check_launch("opened values");
         // the values travel to the host BESIDE the reduced openings and the FRI commit phase (no synchronisation here: k_open_y below reads them
         // on the device); a pinned area of this prover's own, the generic staging buffer is reused by the downloads that follow
@@ -937,7 +937,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
         for (auto& l : launches) {
             const uint64_t L = 1ull << l.lh;
             if (!stream_of.count(l.lh)) stream_of[l.lh] = c.stream_for(grp_idx++, L);
-            vk::launch_reduce_openings(stream_of[l.lh], pool_dev.data + l.off, L, s, c.tables, ro[l.lh].data, l.total_width, l.accumulate, l.n_points);
+            vk::launch_reduce_openings(stream_of[l.lh], pool_dev.data + l.off, L, s, c.tables, ro[l.lh].data, l.total_width, l.accumulate, l.n_points, l.vec_ok);
         }
         reduce_section.join();
         c.check_launch("reduce openings");

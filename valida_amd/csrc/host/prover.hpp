@@ -119,8 +119,7 @@ class Prover {
     Poseidon16 perm16_;
     // The commitment to the PREPROCESSED traces (program ROM, range table: basic/src/lib.rs:189-201) depends on the machine and the program only,
     // not on the witness.  OPTIONAL (off by default: Machine::prove recomputes it in every call, and so does this prover — the bench's timed
-    // region included): with set_prep_cache(true) (C ABI vgpu_prover_set_prep_cache, or VGPU_PREP_CACHE=1 in the environment when the prover is
-    // created) it is computed for the first proof that hands in a given set of preprocessed DeviceTraces and reused while the same traces (by
+    // region included): with set_prep_cache(true) (C ABI vgpu_prover_set_prep_cache) it is computed for the first proof that hands in a given set of preprocessed DeviceTraces and reused while the same traces (by
     // uid) come back — their working-layout copies, LDEs and tree stay on the device: one synchronisation point, the small LDE / tree
     // launches and their ingest less per proof (about 0.2 ms of a lone proof); the root is observed as ever.
     bool prep_cache_enabled_ = false;

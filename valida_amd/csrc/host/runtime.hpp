@@ -70,39 +70,12 @@ struct DeviceCtx {
     hipStream_t upload_stream = nullptr;
     hipEvent_t upload_ev = nullptr;
 
-    // experiment switch (A/B records only; unset in the product): VGPU_QUEUE_MAP="q,q,q,..." = the hardware queue wanted for each stream the
-    // contexts of this process create, in creation order (main, aux, main, aux, ...).  The runtime hands streams to its GPU_MAX_HW_QUEUES
-    // queues in turn; idle filler streams (never destroyed) are created in front of a stream until the turn is the wanted queue's.
-    static void pad_streams_to_mapped_queue() {
-        const char* e = getenv("VGPU_QUEUE_MAP");
-        if (!e) return;
-        static std::mutex mu;
-        static int created = 0, seq = 0;
-        std::lock_guard<std::mutex> lk(mu);
-        const char* q = getenv("GPU_MAX_HW_QUEUES");
-        const int nq = q ? atoi(q) : 4;
-        int want = -1, idx = 0;
-        for (const char* p = e; *p; idx++) {
-            const int v = atoi(p);
-            if (idx == seq) { want = v; break; }
-            while (*p && *p != ',') p++;
-            if (*p == ',') p++;
-        }
-        seq++;
-        if (want < 0 || nq <= 0) { created++; return; }
-        while (created % nq != want % nq) { hipStream_t filler; VG_HIP_CHECK(hipStreamCreateWithFlags(&filler, hipStreamNonBlocking)); created++; }
-        created++;
-    }
     explicit DeviceCtx(int dev) : device(dev) {
         VG_HIP_CHECK(hipSetDevice(dev));
-        // experiment switch (A/B records only; unset in the product): VGPU_STREAM_PRIO="<main>,<aux>" = HIP stream priorities (0 normal, -1 high)
-        int prio_main = 0, prio_aux = 0;
-        if (const char* e = getenv("VGPU_STREAM_PRIO")) (void)sscanf(e, "%d,%d", &prio_main, &prio_aux);
-        pad_streams_to_mapped_queue();
-        VG_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_main));
+        // stream priorities and stream-to-queue arrangements were measured in round 5 (profiles/r04_stream_priorities.txt, r05_queue_arrangements.txt): the runtime's defaults are the optimum
+        VG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (int i = 0; i < NUM_AUX; i++) {
-            pad_streams_to_mapped_queue();
-            VG_HIP_CHECK(hipStreamCreateWithPriority(&aux[i], hipStreamNonBlocking, prio_aux));
+            VG_HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
             VG_HIP_CHECK(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
         }
         VG_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));

@@ -967,7 +967,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 g.mats.push_back(std::move(me));
             }
         }
-        struct Launch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; int n_points; };
+        struct Launch { unsigned lh; size_t off; bool accumulate; uint64_t total_width; int n_points; bool vec_ok; };
         std::vector<Launch> launches;
         std::vector<uint32_t> pool;
         for (auto& kv : groups) {
@@ -977,12 +977,13 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
                 std::vector<const MatEntry*> live;
                 size_t max_w = 0;
                 uint64_t total_width = 0;
+                bool vec_ok = true;
                 for (auto& me : g.mats) {
                     bool any = false;
                     for (auto& t : me.pts) any |= std::get<0>(t) >= s0 && std::get<0>(t) < s1;
-                    if (any) { live.push_back(&me); max_w = std::max<size_t>(max_w, me.width); total_width += me.width; }
+                    if (any) { live.push_back(&me); max_w = std::max<size_t>(max_w, me.width); total_width += me.width; vec_ok &= vk::reduce_vec_ok(me.data, me.stride); }
                 }
-                launches.push_back({kv.first, pool.size(), s0 != 0, total_width, (int)(s1 - s0)});
+                launches.push_back({kv.first, pool.size(), s0 != 0, total_width, (int)(s1 - s0), vec_ok});
                 pool.push_back((uint32_t)live.size());
                 pool.push_back(s1 - s0);
                 pool.push_back((uint32_t)max_w);
@@ -1010,7 +1011,7 @@ std::vector<uint32_t> ShardedProof::run_impl(Fabric& f, const std::vector<Prover
         for (auto& l : launches) {
             const uint64_t L = 1ull << l.lh;
             const bool big = L >= min_big;
-            vk::launch_reduce_openings(c.stream, pool_dev.data + l.off, big ? L / W : L, big ? s * rho_of(R, l.lh) : s, c.tables, O.ro[l.lh].data, l.total_width, l.accumulate, l.n_points);
+            vk::launch_reduce_openings(c.stream, pool_dev.data + l.off, big ? L / W : L, big ? s * rho_of(R, l.lh) : s, c.tables, O.ro[l.lh].data, l.total_width, l.accumulate, l.n_points, l.vec_ok);
         }
         c.check_launch("reduce openings");  // pool_dev is released in stream order
     }

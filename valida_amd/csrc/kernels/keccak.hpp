@@ -173,11 +173,8 @@ __device__ __forceinline__ void keccak_last_round_digest(KState& a, uint32_t rc_
 // non-final blocks of a wide row).  The first round is peeled so compile-time-zero lanes fold.
 template <bool DIGEST_ONLY> __device__ __forceinline__ void keccak_f1600(KState& a) {
     keccak_round(a, 0x00000001u, 0x00000000u);
-#ifndef VK_KECCAK_EXP_SKIP_ROUNDS
-#define VK_KECCAK_EXP_SKIP_ROUNDS 0  // > 0: EXPERIMENT builds only (wrong digests): that many of the 22 middle rounds left out — how much of the step is this permutation's VALU issue? (profiles/r05_ab_valu_sensitivity.txt)
-#endif
 #pragma unroll 2
-    for (int round = 1; round < 23 - VK_KECCAK_EXP_SKIP_ROUNDS; round++) {
+    for (int round = 1; round < 23; round++) {
         if (VK_KECCAK_PIN == 2) keccak_round_rows(a, KECCAK_RC_LO[round], KECCAK_RC_HI[round]);
         else keccak_round(a, KECCAK_RC_LO[round], KECCAK_RC_HI[round]);
     }

@@ -47,16 +47,6 @@ struct QuotientArgs {
 };
 
 
-#ifndef VGPU_STANDIN_FUSE
-#define VGPU_STANDIN_FUSE 0
-#endif
-#if VGPU_STANDIN_FUSE
-// EXPERIMENT BUILD ONLY (tools/build_variant.py standin ALL -DVGPU_STANDIN_FUSE=1; profiles/r05_ab_fuse_standin.*): the gate of "fuse the leaf hash into the
-// last LDE pass".  The last pass of every big LDE (k_lde_c, k_ntt_contig) runs, per workgroup, as many Keccak permutations over words of its LDS tile as the
-// rows its elements stand for would cost, and the Merkle launches skip exactly that work (leaf launch of big trees; the row hash of big injecting layers
-// reads a ready digest instead).  The proofs of such a build are WRONG; only its timing is of interest.
-extern thread_local double g_standin_perms_per_elem;  // set by commit_batches before each coset_lde: permutations per LDE element of the matrix being extended (0: none)
-#endif
 // layout.hip
 void launch_ingest(hipStream_t st, const uint32_t* src_dev, DMatView dst, bool bitrev);
 void launch_bitrev_rows(hipStream_t st, DMatView src, DMatView dst);
@@ -166,8 +156,12 @@ constexpr int MAX_OPEN_POINTS_PER_LAUNCH = 4;
 // Y of every (matrix, point) written into the reduce descriptors on the device (open.hip, k_open_y)
 void launch_open_y(hipStream_t st, const uint32_t* vals_dev, const uint32_t* apow_dev, const uint32_t* desc_dev, const uint32_t* entry_off_dev, uint32_t n_entries, uint32_t* pool_dev);
 // n_points: the descriptor's number of distinct points (1 .. MAX_OPEN_POINTS_PER_LAUNCH; sizes the 4-rows-per-thread kernel's arrays; anything else = the maximum)
+// vec_ok: the caller's word that every matrix of the descriptor has a 16-byte-aligned base and a column stride that is a multiple of 4 words
+// (reduce_vec_ok below, evaluated where the descriptor is built — the pointers live in device memory here).  The R-rows-per-thread kernel reads the
+// columns with 8- / 16-byte loads and needs that, `out` 16-byte aligned and L a power of two >= 1024; anything else takes the thread-per-row kernel.
+inline bool reduce_vec_ok(const void* col0, uint64_t stride_words) { return ((uintptr_t)col0 & 15) == 0 && (stride_words & 3) == 0; }
 void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width,
-                            bool accumulate = false, int n_points = MAX_OPEN_POINTS_PER_LAUNCH);
+                            bool accumulate, int n_points, bool vec_ok);
 // beta5_dev: the folding challenge as 5 Montgomery words in device memory (written by k_fri_challenge)
 void launch_fri_fold(hipStream_t st, const uint32_t* in, uint64_t L, const uint32_t* beta5_dev, const uint32_t* add, const DeviceTables& tb, uint32_t* out);
 // One DuplexChallenger step on the device: observe the 8-word root at digest8_dev, sample beta into beta5_dev; the root is

@@ -101,15 +101,6 @@ __global__ void __launch_bounds__(256) k_keccak_compress(const uint32_t* __restr
     load_digest(prev + 16 * i, l);
     load_digest(prev + 16 * i + 8, r);
     compress2(l, r, d);
-#if VGPU_STANDIN_FUSE
-    if (n_elems < 0) {  // experiment build: the injected row's hash comes ready-made from the LDE pass (here: whatever lies in the output slot)
-        uint32_t h[8], d2[8];
-        load_digest(next + 8 * i, h);
-        compress2(d, h, d2);
-        store_digest(next + 8 * i, d2);
-        return;
-    }
-#endif
     if (n_elems > 0) {
         uint32_t h[8], d2[8];
         hash_row(PtrCols{cols}, n_elems, i, h);
@@ -368,9 +359,6 @@ void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
 }
 
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
-#if VGPU_STANDIN_FUSE
-    if (n_rows > 2 * KECCAK_PAIR_MAX_NODES) return;  // experiment build: hashed by the stand-in inside the last LDE pass
-#endif
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
     const bool pairs = keccak_pairs_enabled() && n_rows <= KECCAK_PAIR_MAX_NODES;
     ProfScope ps(pairs ? "k_keccak_leaves_pair" : "k_keccak_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * row_perms(n_elems) * KECCAK_VALU_PER_PERM / 64.0);
@@ -398,9 +386,6 @@ void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t
         VK_LAUNCH(k_keccak_compress_pair, dim3((unsigned)((2 * n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
         return;
     }
-#if VGPU_STANDIN_FUSE
-    if (n_elems > 0 && n_out > 2 * KECCAK_PAIR_MAX_NODES) n_elems = -1;  // the row hash of a big injecting layer: stood in for inside the LDE pass
-#endif
     VK_LAUNCH(k_keccak_compress, dim3(blocks), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, next);
 }
 

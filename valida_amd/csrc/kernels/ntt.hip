@@ -20,35 +20,8 @@
 // No MFMA: 31-bit modular butterflies are VALU work.  Measured balance: DESIGN.md "Measurement".
 #include "launch.hpp"
 #include "butterfly.hpp"
-#if VGPU_STANDIN_FUSE
-#include "keccak.hpp"
-#endif
 
 namespace vk {
-#if VGPU_STANDIN_FUSE
-thread_local double g_standin_perms_per_elem = 0.0;
-static uint32_t* standin_out() {  // 32 bytes per stood-in row hash: as many digest bytes as the real leaf layer
-    static uint32_t* p = [] { void* q = nullptr; (void)hipMalloc(&q, (size_t)1 << 30); return (uint32_t*)q; }();
-    return p;
-}
-// `perms` single-block row hashes per workgroup over the (Montgomery) words of its LDS tile: canonical form, absorb 34 words, permute, squeeze, store 32 bytes
-__device__ __forceinline__ void standin_hashes(const uint32_t* lds, int tile_words, int perms, uint32_t* out, uint64_t wg_linear) {
-    for (int j = threadIdx.x; j < perms; j += blockDim.x) {
-        KState a;
-        kstate_zero(a);
-#pragma unroll
-        for (int kk = 0; kk < 34; kk++) {
-            int idx = kk * (int)blockDim.x + j;
-            idx = idx % tile_words;
-            absorb_word(a, kk, Fp::raw(lds[idx]).canonical());
-        }
-        keccak_f1600<true>(a);
-        uint32_t* o = out + (((wg_linear * (uint64_t)perms + (uint64_t)j) * 8) & (((uint64_t)1 << 28) - 8));
-        reinterpret_cast<uint4*>(o)[0] = make_uint4(a.lo[0], a.hi[0], a.lo[1], a.hi[1]);
-        reinterpret_cast<uint4*>(o)[1] = make_uint4(a.lo[2], a.hi[2], a.lo[3], a.hi[3]);
-    }
-}
-#endif
 
 // Contiguous tiles (T = 1) are stored padded: word i at i + (i >> 4), so the stride-16 accesses of the
 // last round are bank-conflict free.  Strided tiles use element (h, c) at h * LD + c with LD = T + 1.
@@ -357,9 +330,6 @@ __global__ void k_ntt_strided(DMatView src, DMatView dst, uint64_t dst_row0, int
 // transform fits one pass (k_hi == 0) the input is read from `src` and multiplied by shift^i first.
 __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int k, int k_lo, DeviceTables tb, uint32_t shift_mont,
                              int from_src
-#if VGPU_STANDIN_FUSE
-                             , int standin_perms, uint32_t* standin_o
-#endif
                              ) {
     extern __shared__ uint32_t lds[];
     const int n_lo = 1 << k_lo;
@@ -383,9 +353,6 @@ __global__ void k_ntt_contig(DMatView src, DMatView dst, uint64_t dst_row0, int 
         if (!from_src && t + gridDim.x < total) prefetch_tile(pre, tile_ptr(t + gridDim.x), n_lo);
         tile_transform<false, true>(lds, tw, k_lo, 0, 0);
         for (int i = threadIdx.x; i < n_lo; i += blockDim.x) out[i] = lds[tile_addr<true>(i, 0, 0)];
-#if VGPU_STANDIN_FUSE
-        if (standin_perms > 0) standin_hashes(lds, n_lo, standin_perms, standin_o, t);
-#endif
         __syncthreads();
     }
 }
@@ -584,15 +551,6 @@ __global__ void __launch_bounds__(MAXT) k_lde_mid(DMatView src, DMatView dst, in
 // fed straight from the global loads, its last round and the first round of every forward transform joined in registers (both work on the
 // thread's own 16 consecutive positions: the coefficients never leave the register file), the last forward round stored straight to
 // HBM: ONE LDS tile instead of two, 2 + 3 b barriers per tile instead of 4 + 5 b, half the LDS traffic.  256 threads x 16 points.
-#ifndef VGPU_MID12_WAVES
-#define VGPU_MID12_WAVES 0  // > 0: occupancy the register allocator must reach (waves per SIMD); A/B builds: tools/build_variant.py
-#endif
-#ifndef VGPU_MID12_PREFETCH
-#define VGPU_MID12_PREFETCH 1
-#endif
-#if VGPU_MID12_WAVES > 0
-__attribute__((amdgpu_waves_per_eu(VGPU_MID12_WAVES, VGPU_MID12_WAVES)))
-#endif
 __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, int k, int lb, DeviceTables tb, LdeTables lt) {
     extern __shared__ uint32_t lds[];
     constexpr int K_LO = 12, N_LO = 1 << K_LO;
@@ -600,31 +558,20 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
     const uint64_t N = 1ull << k, tiles_per_col = (uint64_t)n_hi, total = tiles_per_col * src.width;
     const uint32_t nmask = (uint32_t)(N - 1);
     auto tile_ptr = [&](uint64_t t) { const uint64_t cidx = t >> k_hi; return src.col(cidx) + (t & (tiles_per_col - 1)) * N_LO; };
-#ifndef VGPU_MID12_TWREG
-#define VGPU_MID12_TWREG 1  // the twiddles of the two outer rounds (stages 9 .. 12: they depend on the thread, not on the tile) held in registers
-#endif
-#if VGPU_MID12_TWREG
     Fp tw_in[15], tw_out[15];
     load_round_twiddles<4>(tw_in, tb.itwc, tid, 8);
     load_round_twiddles<4>(tw_out, tb.twc, tid, 8);
     const Fp* const held_in = tw_in;
     const Fp* const held_out = tw_out;
-#else
-    const Fp* const held_in = nullptr;
-    const Fp* const held_out = nullptr;
-#endif
-#if VGPU_MID12_PREFETCH
     uint32_t pre[16];
     if (blockIdx.x < total) {
         const uint32_t* sp = tile_ptr(blockIdx.x);
 #pragma unroll
         for (int g = 0; g < 16; g++) pre[g] = sp[tid + 256 * g];
     }
-#endif
     for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
         const uint64_t cidx = t >> k_hi, p = t & (tiles_per_col - 1);
         Fp x[16];
-#if VGPU_MID12_PREFETCH
 #pragma unroll
         for (int g = 0; g < 16; g++) x[g] = Fp::raw(pre[g]);
         if (t + gridDim.x < total) {  // the next tile's loads land while this one computes
@@ -632,13 +579,6 @@ __global__ void __launch_bounds__(256) k_lde_mid12(DMatView src, DMatView dst, i
 #pragma unroll
             for (int g = 0; g < 16; g++) pre[g] = sp[tid + 256 * g];
         }
-#else
-        {
-            const uint32_t* sp = tile_ptr(t);
-#pragma unroll
-            for (int g = 0; g < 16; g++) x[g] = Fp::raw(sp[tid + 256 * g]);
-        }
-#endif
         // inverse, stages 12 .. 9 on the points tid + 256 g (DIF, inverse roots)
         butterflies<4, false, false>(x, tb.itwc, tid, 8, held_in);
         {
@@ -768,9 +708,6 @@ __global__ void __launch_bounds__(1024) k_lde_mid14(DMatView src, DMatView dst, 
 // ---- pass C: forward, strided, transposing store: grid = (n_lo / T, columns, cosets) --------------------
 template <int FK_HI, int FLOGT>  // as k_lde_a
 __global__ void __launch_bounds__(FK_HI ? 512 : 1024) k_lde_c(DMatView src, DMatView dst, int k, int k_lo, int lb, int logT_arg, DeviceTables tb
-#if VGPU_STANDIN_FUSE
-                        , int standin_perms, uint32_t* standin_o
-#endif
                         ) {
     extern __shared__ uint32_t lds[];
     const int k_hi = FK_HI ? FK_HI : k - k_lo, logT = FK_HI ? FLOGT : logT_arg, n_hi = 1 << k_hi, T = 1 << logT, LD = T + 1;
@@ -814,9 +751,6 @@ __global__ void __launch_bounds__(FK_HI ? 512 : 1024) k_lde_c(DMatView src, DMat
         const uint32_t qb = __brev((uint32_t)(q0 + c)) >> (32 - k_lo);
         out[(uint64_t)qb * n_hi + p2] = lds[p2 * LD + c];
     }
-#if VGPU_STANDIN_FUSE
-    if (standin_perms > 0) standin_hashes(lds, n_hi * LD, standin_perms, standin_o, ((uint64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
-#endif
 }
 
 // ---- host launchers -----------------------------------------------------------------------------------
@@ -906,18 +840,10 @@ void launch_coset_ntt(hipStream_t st, DMatView coeffs, DMatView dst, uint64_t ds
             VK_LAUNCH(k_ntt_strided, gs, dim3(p.threads_strided), p.lds_strided, st, coeffs, dst, dst_row0, k, p.k_lo, p.logT, tb, cp);
         }
         ProfScope ps("k_ntt_contig", st, pass_bytes);
-#if VGPU_STANDIN_FUSE
-        VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0, (int)((double)(1u << p.k_lo) * g_standin_perms_per_elem + 0.5), standin_out());
-#else
         VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 0);
-#endif
     } else {
         ProfScope ps("k_ntt_contig", st, pass_bytes);
-#if VGPU_STANDIN_FUSE
-        VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1, 0, standin_out());
-#else
         VK_LAUNCH(k_ntt_contig, gc, dim3(p.threads_contig), p.lds_contig, st, coeffs, dst, dst_row0, k, p.k_lo, tb, shift.v, 1);
-#endif
     }
 }
 
@@ -944,14 +870,11 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
         else if (shape == 10) VK_LAUNCH((k_lde_a<10, 4>), gs, dim3(512), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
         else VK_LAUNCH((k_lde_a<0, 0>), gs, dim3(p.threads_strided), p.lds_strided, st, nat, s1, k, p.k_lo, p.logT, tb);
     }
-    static const bool mid12 = [] { const char* e = getenv("VGPU_LDE_MID12"); return !(e && e[0] == '0'); }();
-    static const bool mid14 = [] { const char* e = getenv("VGPU_LDE_MID14"); return !(e && e[0] == '0'); }();
-    if (p.k_lo == 12 && mid12) {
-        static const unsigned cap = [] { const char* e = getenv("VGPU_MID12_GRID"); return e ? (unsigned)atoi(e) : 4096u; }();  // persistent blocks (A/B)
-        if (cap && gm.x > cap) gm.x = cap;
+    if (p.k_lo == 12) {
+        if (gm.x > 4096u) gm.x = 4096u;  // persistent blocks
         ProfScope ps("k_lde_mid12", st, nw * (1.0 + b));
         VK_LAUNCH(k_lde_mid12, gm, dim3(256), (size_t)padded_words(4096) * 4, st, s1, s2, k, log_blowup, tb, lt);
-    } else if (p.k_lo == 14 && mid12 && mid14) {
+    } else if (p.k_lo == 14) {
         ProfScope ps("k_lde_mid14", st, nw * (1.0 + b));
         VK_LAUNCH(k_lde_mid14, gm, dim3(1024), 2 * (size_t)padded_words(16384) * 4, st, s1, s2, k, log_blowup, tb, lt);  // work tile + coefficient tile: 139 KiB
     } else {
@@ -962,11 +885,7 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
     dim3 gc((unsigned)((1u << p.k_lo) >> p.logT), (unsigned)nat.width, 1u << log_blowup);
     ProfScope ps("k_lde_c", st, 2.0 * nw * b);
     const int shape_c = VGPU_STRIDED_IO && VGPU_STRIDED_FIXED && p.threads_strided == 512 ? (p.k_hi == 8 && p.logT == 6 ? 8 : (p.k_hi == 10 && p.logT == 4 ? 10 : 0)) : 0;
-#if VGPU_STANDIN_FUSE
-#define VG_LDE_C(A, B, THREADS) VK_LAUNCH((k_lde_c<A, B>), gc, dim3(THREADS), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb, (int)((double)((1u << p.k_hi) << p.logT) * g_standin_perms_per_elem + 0.5), standin_out())
-#else
 #define VG_LDE_C(A, B, THREADS) VK_LAUNCH((k_lde_c<A, B>), gc, dim3(THREADS), p.lds_strided, st, s2, lde, k, p.k_lo, log_blowup, p.logT, tb)
-#endif
     if (shape_c == 8) VG_LDE_C(8, 6, 512);
     else if (shape_c == 10) VG_LDE_C(10, 4, 512);
     else VG_LDE_C(0, 0, p.threads_strided);

@@ -779,12 +779,14 @@ void launch_open_y(hipStream_t st, const uint32_t* vals_dev, const uint32_t* apo
     ProfScope ps("k_open_y", st, 0.0);
     VK_LAUNCH(k_open_y, dim3(n_entries), dim3(64), 0, st, vals_dev, apow_dev, desc_dev, entry_off_dev, pool_dev);
 }
-void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width, bool accumulate, int n_points) {
+void launch_reduce_openings(hipStream_t st, const uint32_t* desc_dev, uint64_t L, Fp shift, const DeviceTables& tb, uint32_t* out, uint64_t total_width, bool accumulate, int n_points, bool vec_ok) {
     ProfScope ps("k_reduce_openings", st, 4.0 * L * (total_width + (accumulate ? 10.0 : 5.0)));
     // VGPU_REDUCE_ROWS = rows per thread: 4, 2 or 1 (1: the thread-per-row kernel everywhere; A/B).  Default: 4 rows for launches of at most two distinct
     // points, 2 rows for three and four (register budget: see k_reduce_openings_rows)
     static const int rows_env = [] { const char* e = getenv("VGPU_REDUCE_ROWS"); return e ? atoi(e) : 0; }();
-    if (rows_env != 1 && L >= 1024) {
+    // the rows kernel's invariants (8- / 16-byte column loads at j0 = R * thread, uint2 stores into `out`): see launch.hpp; not met -> the row kernel
+    const bool rows_kernel_ok = vec_ok && L >= 1024 && (L & (L - 1)) == 0 && ((uintptr_t)out & 15) == 0;
+    if (rows_env != 1 && rows_kernel_ok) {
         const int np = n_points >= 1 && n_points <= MAX_OPEN_POINTS ? n_points : MAX_OPEN_POINTS;
         const int R = rows_env == 2 || rows_env == 4 ? rows_env : (np <= 2 ? 4 : 2);
         const dim3 grid((unsigned)((L / R + 255) / 256)), block(256);

@@ -175,10 +175,11 @@ __device__ __forceinline__ void poseidon_node_row(const uint32_t* __restrict__ p
     if (l16 < 8) next[8 * node + l16] = st.canonical();
 }
 
-// A layer of the latency-bound MIDDLE of a tree (256 < parents <= 16384: VGPU_POSEIDON_ROW_MAX) with one node per 16-lane row (round 5): with a thread per
+// A layer of the latency-bound MIDDLE of a tree (256 < parents <= POSEIDON_ROW_MAX) with one node per 16-lane row (round 5): with a thread per
 // node such a layer is at most a quarter of a wave per SIMD, every wave alone with its ~9 200 dependent instructions (16-19 us per layer, 26 trees
 // x up to 4 such layers per proof); a row finishes its node in ~2 600.  The price is 4.4 x the lane-instructions per permutation, so the
-// threshold stays where the GPU is mostly idle anyway (VGPU_POSEIDON_ROW_MAX: A/B, 0 = off).
+// threshold stays where the GPU is mostly idle anyway (thresholds 0 .. 65536 measured: profiles/r05_ab_valu_sensitivity_poseidon_rows.txt).
+constexpr uint64_t POSEIDON_ROW_MAX = 16384;
 __global__ void __launch_bounds__(256) k_poseidon_compress_row(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int n_elems, uint64_t n_out,
                                                                PoseidonTab tab, uint32_t* __restrict__ next) {
     uint32_t m[16];
@@ -237,8 +238,7 @@ void launch_poseidon_leaves_strided(hipStream_t st, const uint32_t* pos_dev, boo
                        tab_of(pos_dev, sparse), digests);
 }
 void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
-    static const uint64_t row_max = [] { const char* e = getenv("VGPU_POSEIDON_ROW_MAX"); return e ? (uint64_t)atoll(e) : (uint64_t)16384; }();
-    if (VGPU_POSEIDON_ROWS && n_out > 256 && n_out <= row_max) {  // (layers of <= 256 parents belong to k_poseidon_top in a tree; the emulated-source tests launch tiny ones here)
+    if (VGPU_POSEIDON_ROWS && n_out > 256 && n_out <= POSEIDON_ROW_MAX) {  // (layers of <= 256 parents belong to k_poseidon_top in a tree; the emulated-source tests launch tiny ones here)
         ProfScope ps("k_poseidon_compress_row", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * p_node_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
         VK_LAUNCH(k_poseidon_compress_row, dim3((unsigned)((16 * n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, tab_of(pos_dev, sparse), next);
         return;
