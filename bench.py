@@ -689,7 +689,7 @@ def main():
     # 2.35-2.4 GHz, the device settles at 2.2 GHz after a few seconds of this load; a production prover lives in the second regime).
     sustained = None
     if args.sustained_seconds > 0:
-        s_steps = max(args.steps, int(np.ceil(args.sustained_seconds / (elapsed / args.steps))))
+        s_steps = max(args.steps, int(np.ceil(1.15 * args.sustained_seconds / (elapsed / args.steps))))  # a count, not a deadline: the ranks must agree on it (one collective per step)
         s_steps = -(-s_steps // len(provers)) * len(provers)
         if world > 1:  # every rank must run the same number of steps (one collective per step)
             ns = torch.tensor([s_steps], dtype=torch.int64, device=coll_device)
