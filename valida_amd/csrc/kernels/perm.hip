@@ -131,7 +131,6 @@ __device__ __forceinline__ Ext5 perm_row_native(const DMatView& main, const uint
     *m_out = v.m;
     return delta;
 }
-// reciprocal columns + the row's contribution, the running sum left to the three-phase scan below (the form tools/hipemu runs: no wave primitives)
 template <int CHIP>
 __global__ void __launch_bounds__(256) k_perm_recip_native(DMatView main, const uint32_t* __restrict__ iw, const uint32_t* __restrict__ chal, DMatView perm) {
     const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,111 +140,8 @@ __global__ void __launch_bounds__(256) k_perm_recip_native(DMatView main, const 
     store_ext(perm.data + (uint64_t)(5 * m) * perm.stride, perm.stride, n, delta);
 }
 
-#if defined(__HIPCC__) && !defined(HIPEMU_CHECKS) && !defined(VGPU_NO_FUSED_SCAN)  // (-DVGPU_NO_FUSED_SCAN: the A/B build with the three-phase scan)
-// ---- ... and the running sum in the SAME launch (round 6; SURVEY.md K7: one decoupled-look-back pass) --------------------------------------
-// The three-phase scan behind k_perm_recip_native read the contribution column twice and wrote it twice (60 n bytes, three launches per chip:
-// 0.41 ms of a lone C2 proof, 0.9 TB/s).  Here a workgroup (256 consecutive rows, in TICKET order: a workgroup's predecessors have all started)
-// scans its rows' contributions in registers / LDS, publishes its aggregate, looks back over its predecessors' published aggregates until it meets
-// an inclusive prefix, publishes its own inclusive prefix and stores phi directly: the contribution never travels to HBM.
-// Status words: two Montgomery values (31 bits each) and a 2-bit VALID mark in one 64-bit word, written and read with relaxed agent-scope atomics —
-// a word is valid or not as a whole, so no fence and no cache maintenance is needed between the XCDs' L2s (the values ride with the flag).  Per
-// workgroup 3 words for the aggregate and 3 for the inclusive prefix (5 coefficients), in slots of their own: the aggregate stays readable while the
-// prefix is being published.  Zeroed by a hipMemsetAsync ahead of the launch (word 0: the ticket counter).
-constexpr int SCAN1_WORDS_PER_BLOCK = 6;
-__device__ __forceinline__ uint64_t scan1_pack(uint32_t v0, uint32_t v1) { return (3ull << 62) | ((uint64_t)v1 << 31) | v0; }
-__device__ __forceinline__ void scan1_publish(unsigned long long* slot, const Ext5& e, int lane) {  // lanes 0..2
-    const uint32_t v0 = lane == 0 ? e.c[0].v : (lane == 1 ? e.c[2].v : e.c[4].v), v1 = lane == 0 ? e.c[1].v : (lane == 1 ? e.c[3].v : 0u);
-    if (lane < 3) __hip_atomic_store(slot + lane, (unsigned long long)scan1_pack(v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ Fp wave_scan_incl(Fp v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const Fp t = Fp::raw((uint32_t)__shfl_up((int)v.v, off, 64));
-        if (lane >= off) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ Fp wave_total(Fp v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += Fp::raw((uint32_t)__shfl_xor((int)v.v, off, 64));
-    return v;
-}
-template <int CHIP>
-__global__ void __launch_bounds__(256) k_perm_native_scan(DMatView main, const uint32_t* __restrict__ iw, const uint32_t* __restrict__ chal, DMatView perm, unsigned long long* status) {
-    __shared__ uint32_t sh[4 * 5 + 5 + 1];  // wave totals, the workgroup's exclusive prefix, its ticket
-    if (threadIdx.x == 0) sh[25] = (uint32_t)__hip_atomic_fetch_add(status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const uint32_t b = sh[25];
-    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    const uint64_t n = (uint64_t)b * 256 + threadIdx.x;
-    const bool live = n < main.height;
-    int m = 0;
-    Ext5 phi = Ext5::zero();
-    if (live) phi = perm_row_native<CHIP>(main, iw, chal, perm, n, &m);
-    // inclusive scan inside the wave, wave totals through LDS
-#pragma unroll
-    for (int c = 0; c < 5; c++) phi.c[c] = wave_scan_incl(phi.c[c], lane);
-    if (lane == 63) {
-#pragma unroll
-        for (int c = 0; c < 5; c++) sh[5 * wave + c] = phi.c[c].v;
-    }
-    __syncthreads();
-    Ext5 agg = Ext5::zero(), before = Ext5::zero();  // the workgroup's aggregate; the totals of this thread's earlier waves
-#pragma unroll
-    for (int w = 0; w < 4; w++)
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            const Fp t = Fp::raw(sh[5 * w + c]);
-            agg.c[c] += t;
-            if (w < wave) before.c[c] += t;
-        }
-    unsigned long long* const mine = status + 1 + (size_t)SCAN1_WORDS_PER_BLOCK * b;
-    if (wave == 0) {
-        Ext5 excl = Ext5::zero();
-        if (b == 0) scan1_publish(mine + 3, agg, lane);
-        else {
-            scan1_publish(mine, agg, lane);
-            long long j = (long long)b - 1;  // lane l looks at workgroup j - l
-            for (;;) {
-                const long long pred = j - lane;
-                unsigned long long w[6] = {0, 0, 0, 0, 0, 0};
-                if (pred >= 0) {
-                    const unsigned long long* q = status + 1 + (size_t)SCAN1_WORDS_PER_BLOCK * (size_t)pred;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) w[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                const bool has_p = pred >= 0 && (w[3] >> 62) == 3 && (w[4] >> 62) == 3 && (w[5] >> 62) == 3;
-                const bool has_a = pred >= 0 && (w[0] >> 62) == 3 && (w[1] >> 62) == 3 && (w[2] >> 62) == 3;
-                if (!__all(pred < 0 || has_p || has_a)) { __builtin_amdgcn_s_sleep(1); continue; }  // a predecessor has not published yet: look again
-                const unsigned long long pmask = __ballot(has_p);
-                const int first = pmask ? __builtin_ctzll(pmask) : 64;  // the nearest predecessor with an inclusive prefix ends the walk
-                const bool take_p = lane == first, take_a = lane < first && pred >= 0;
-                const int o = take_p ? 3 : 0;
-                const uint32_t mask31 = 0x7fffffffu;
-                const uint32_t v[5] = {(uint32_t)w[o] & mask31, (uint32_t)(w[o] >> 31) & mask31, (uint32_t)w[o + 1] & mask31, (uint32_t)(w[o + 1] >> 31) & mask31, (uint32_t)w[o + 2] & mask31};
-#pragma unroll
-                for (int c = 0; c < 5; c++) excl.c[c] += wave_total(Fp::raw((take_p || take_a) ? v[c] : 0u));
-                if (pmask) break;  // (workgroup 0 publishes a prefix: the walk always ends)
-                j -= 64;
-            }
-            scan1_publish(mine + 3, excl + agg, lane);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) sh[20 + c] = excl.c[c].v;
-        }
-    }
-    __syncthreads();
-    if (live) {
-#pragma unroll
-        for (int c = 0; c < 5; c++) phi.c[c] = phi.c[c] + before.c[c] + Fp::raw(sh[20 + c]);
-        store_ext(perm.data + (uint64_t)(5 * m) * perm.stride, perm.stride, n, phi);
-    }
-}
-#define VGPU_PERM_FUSED_SCAN 1
-#else
-#define VGPU_PERM_FUSED_SCAN 0
-#endif
+// (Round 6 measured the running sum in the SAME launch — a decoupled-look-back pass over 256-row workgroups, SURVEY.md K7 — against the three-phase scan
+// below: not faster alone, 1.2 % slower with three proofs in flight; profiles/r06_ab_onepass_scan.txt, kernel in the history at commit f92d09a.)
 
 // ---- inclusive prefix sum of a base-field column (blockIdx.y selects the column) ----------------------
 constexpr int SCAN_ITEMS = 4, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;
@@ -319,8 +215,7 @@ void launch_add_ext_const(hipStream_t st, uint32_t* data, uint64_t stride, uint6
     VK_LAUNCH(k_add_ext_const, dim3((unsigned)((n + 255) / 256), 5), dim3(256), 0, st, data, stride, n, off5_dev);
 }
 
-// the three-phase scan's block sums, or the one-pass scan's ticket + status words (64-bit, SCAN1_WORDS_PER_BLOCK per 256 rows)
-uint64_t perm_scratch_words(uint64_t n) { return std::max<uint64_t>(5 * ((n + SCAN_BLOCK - 1) / SCAN_BLOCK), 2 * (1 + 6 * ((n + 255) / 256)) + 2); }
+uint64_t perm_scratch_words(uint64_t n) { return 5 * ((n + SCAN_BLOCK - 1) / SCAN_BLOCK); }
 
 // main/prep: natural-order column-major.  perm: n x 5(M+1), natural order.  scratch: >= 5 * ceil(n / SCAN_BLOCK) words.
 void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint32_t* iw_dev, const uint32_t* chal_dev, uint32_t M, DMatView perm,
@@ -328,22 +223,6 @@ void launch_perm_trace(hipStream_t st, DMatView main, DMatView prep, const uint3
     uint64_t n = main.height;
     static const bool native_on = [] { const char* e = getenv("VGPU_PERM_NATIVE"); return !(e && e[0] == '0'); }();
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-#if VGPU_PERM_FUSED_SCAN
-    if (native_on && M <= (uint32_t)PERM_NATIVE_MAX_M && native_chip >= 0 && native_chip < 14) {
-        // reciprocal columns and running sum in one launch (k_perm_native_scan); its status words zeroed first
-        unsigned long long* status = reinterpret_cast<unsigned long long*>(scratch);
-        VG_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)(1 + 6 * grid.x) * 8, st));
-        ProfScope ps("k_perm_recip", st, 4.0 * n * (main.width + perm.width));
-        switch (native_chip) {
-#define VG_PERM_SCAN(C) case vchips::C: VK_LAUNCH((k_perm_native_scan<vchips::C>), grid, block, 0, st, main, iw_dev, chal_dev, perm, status); break;
-            VG_PERM_SCAN(CHIP_CPU) VG_PERM_SCAN(CHIP_PROGRAM) VG_PERM_SCAN(CHIP_MEM) VG_PERM_SCAN(CHIP_ADD) VG_PERM_SCAN(CHIP_SUB) VG_PERM_SCAN(CHIP_MUL)
-            VG_PERM_SCAN(CHIP_DIV) VG_PERM_SCAN(CHIP_SHIFT) VG_PERM_SCAN(CHIP_LT) VG_PERM_SCAN(CHIP_COM) VG_PERM_SCAN(CHIP_BITWISE) VG_PERM_SCAN(CHIP_OUTPUT)
-            VG_PERM_SCAN(CHIP_RANGE) VG_PERM_SCAN(CHIP_STATIC_DATA)
-#undef VG_PERM_SCAN
-        }
-        return;
-    }
-#endif
     { ProfScope ps("k_perm_recip", st, 4.0 * n * (main.width + perm.width));
     bool done = false;
     if (native_on && M <= (uint32_t)PERM_NATIVE_MAX_M) {
