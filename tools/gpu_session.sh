@@ -9,7 +9,8 @@
 #   --tests "<pytest -k expression>" | --tests all | --tests none    parity first (default: a quick subset); under EVERY candidate when --tests-per-candidate
 #   --reps N            interleaved repetitions of every candidate (default 3; boxes differ by a few per cent, so A and B always share a session)
 #   --legs "three lone" which bench legs to run per candidate: three (default run, three proofs in flight), lone (--inflight 1 --no-kernel-events),
-#                       full (with the extra legs and the CPU baseline, once, candidate 0 only), c3, c4, poseidon, c4poseidon
+#                       lonek (one proof in flight WITH per-launch events: exclusive per-kernel times), full (with the extra legs and the CPU baseline, once per candidate),
+#                       c3, c4, poseidon, poseidonlone, c4poseidon
 #   --bench "<args>"    extra bench.py arguments for the three / lone legs (e.g. "--steps 24 --warmup 6")
 #   --profile           tools/profile_round.sh <tag> afterwards (rocprofv3 kernel stats + PMC passes + summaries)
 #   --timeline          kernel timeline of a lone proof (rocprofv3 --kernel-trace; tools/summarize_prof.py timeline)
@@ -63,6 +64,7 @@ run_leg() {  # label rep leg env...
   case "$leg" in
     three)      env "$@" $B --no-extra-legs $BENCH > "$f" 2>>"$OUT/$lab.err";;
     lone)       env "$@" $B --no-extra-legs --inflight 1 --no-kernel-events --sustained-seconds 0 $BENCH > "$f" 2>>"$OUT/$lab.err";;
+    lonek)      env "$@" VGPU_PROF_QUOTIENT_BY_CHIP=1 $B --no-extra-legs --inflight 1 --sustained-seconds 0 $BENCH > "$f" 2>>"$OUT/$lab.err";;  # one proof in flight WITH per-launch events: exclusive per-kernel times (kernel_ms_per_step), quotient launches named by chip
     full)       [ "$rep" = 1 ] && env "$@" python bench.py > "$f" 2>>"$OUT/$lab.err";;
     c3)         env "$@" $B --no-extra-legs --workload c3 --steps 6 --warmup 2 --sustained-seconds 0 > "$f" 2>>"$OUT/$lab.err";;
     c4)         env "$@" $B --no-extra-legs --workload c4 --sustained-seconds 0 > "$f" 2>>"$OUT/$lab.err";;
@@ -100,6 +102,16 @@ for leg in legs:
                     extra = " pool_peak %.1f GB" % (d["hbm_pool_peak_bytes"] / 1e9)
             except Exception as e:  # noqa: BLE001
                 extra += " [%s: %s]" % (f.rsplit("/", 1)[-1], e)
+        if leg == "lonek":
+            ks = {}
+            for f in sorted(glob.glob("%s/%s_rep*.%s.json" % (out, lab, leg))):
+                try:
+                    d = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+                    for k, x in d["kernel_ms_per_step"].items():
+                        ks.setdefault(k, []).append(x)
+                except Exception:  # noqa: BLE001
+                    pass
+            print("%-12s %-14s kernel ms per lone proof (median over reps): %s" % (leg, lab, ", ".join("%s %.3f" % (k, statistics.median(x)) for k, x in sorted(ks.items(), key=lambda kv: -statistics.median(kv[1]))[:40])))
         if v:
             print("%-12s %-14s ms/step median %.3f mean %.3f %s%s%s" % (leg, lab, statistics.median(v), statistics.mean(v), [round(x, 2) for x in v],
                   (" | sustained median %.3f %s" % (statistics.median(s), [round(x, 2) for x in s])) if s else "", extra))

@@ -52,11 +52,18 @@ def short(d):
 
 def main():
     files = ["kernels/ntt.hip", "kernels/layout.hip", "kernels/merkle.hip", "kernels/poseidon_mmcs.hip", "kernels/perm.hip", "kernels/quotient.hip", "kernels/open.hip", "kernels/tracegen.hip"]
+    # python tools/isa_mix.py [OUT.txt] [--only kernels/x.hip] [-DFLAG=v ...]: one file and / or an A/B build's flags (the table of a variant before GPU minutes go into it)
+    argv, defs = [a for a in sys.argv[1:] if not a.startswith("-D")], [a for a in sys.argv[1:] if a.startswith("-D")]
+    if "--only" in argv:
+        i = argv.index("--only")
+        files = [argv[i + 1]]
+        del argv[i:i + 2]
+    sys.argv[1:] = argv
     rows = []
     with tempfile.TemporaryDirectory() as td:
         for f in files:
             base = os.path.basename(f).replace(".hip", "")
-            subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-save-temps=obj", "-x", "hip", "-c", os.path.join(CSRC, f), "-o",
+            subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-save-temps=obj"] + defs + ["-x", "hip", "-c", os.path.join(CSRC, f), "-o",
                             os.path.join(td, base + ".o")], check=True, cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             co = [os.path.join(td, x) for x in os.listdir(td) if x.startswith(base) and x.endswith("gfx950.out")]
             if not co:

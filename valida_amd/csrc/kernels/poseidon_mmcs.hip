@@ -86,6 +86,7 @@ __device__ __forceinline__ PoseidonTab poseidon_tab_in_lds(const PoseidonTab& ta
 #endif
 }
 
+// (forcing 6 / 7 / 8 waves per SIMD on the two thread-per-node kernels was measured in round 6: nothing at 6, slower beyond — profiles/r06_ab_quotient_acc2_poseidon_waves.txt)
 template <class Cols>
 __global__ void __launch_bounds__(256) k_poseidon_leaves(const Cols cols, int n_elems, uint64_t n_rows, PoseidonTab gtab, uint32_t* __restrict__ digests) {
     __shared__ uint32_t s_opt[POPT_WORDS];

@@ -140,6 +140,8 @@ struct DeviceFolder {
         for (int c = 0; c < 5; c++) { total.c[c] += Fp::raw(vg::monty_reduce_wide(t[c])); t[c] = 0; }
         pending = 0;
     }
+    // (two alternating accumulator sets were measured in round 6: the cpu chip's kernel drops to 3 waves per SIMD and runs 7x slower — the
+    // accumulators are not a dependency chain, the powers of alpha are precomputed; profiles/r06_ab_quotient_acc2_poseidon_waves.txt)
     __device__ __forceinline__ void assert_zero(const Fp& e) {
 #pragma unroll
         for (int c = 0; c < 5; c++) t[c] += (uint64_t)apow[5 * k + c] * e.v;
