@@ -10,7 +10,7 @@
 #   --reps N            interleaved repetitions of every candidate (default 3; boxes differ by a few per cent, so A and B always share a session)
 #   --legs "three lone" which bench legs to run per candidate: three (default run, three proofs in flight), lone (--inflight 1 --no-kernel-events),
 #                       lonek (one proof in flight WITH per-launch events: exclusive per-kernel times), full (with the extra legs and the CPU baseline, once per candidate),
-#                       c3, c4, poseidon, poseidonlone, c4poseidon
+#                       c3, c4, poseidon, poseidonlone, poseidonlonek, c4poseidon
 #   --bench "<args>"    extra bench.py arguments for the three / lone legs (e.g. "--steps 24 --warmup 6")
 #   --profile           tools/profile_round.sh <tag> afterwards (rocprofv3 kernel stats + PMC passes + summaries)
 #   --timeline          kernel timeline of a lone proof (rocprofv3 --kernel-trace; tools/summarize_prof.py timeline)
@@ -70,6 +70,7 @@ run_leg() {  # label rep leg env...
     c4)         env "$@" $B --no-extra-legs --workload c4 --sustained-seconds 0 > "$f" 2>>"$OUT/$lab.err";;
     poseidon)   env "$@" $B --no-extra-legs --mmcs poseidon --steps 6 --warmup 2 --sustained-seconds 0 > "$f" 2>>"$OUT/$lab.err";;
     poseidonlone) env "$@" $B --no-extra-legs --mmcs poseidon --inflight 1 --steps 6 --warmup 2 --no-kernel-events --sustained-seconds 0 > "$f" 2>>"$OUT/$lab.err";;
+    poseidonlonek) env "$@" $B --no-extra-legs --mmcs poseidon --inflight 1 --steps 6 --warmup 2 --sustained-seconds 0 > "$f" 2>>"$OUT/$lab.err";;
     c4poseidon) env "$@" $B --no-extra-legs --workload c4 --mmcs poseidon --steps 4 --warmup 1 --sustained-seconds 0 > "$f" 2>>"$OUT/$lab.err";;
     *) echo "unknown leg $leg" >&2;;
   esac
@@ -102,7 +103,7 @@ for leg in legs:
                     extra = " pool_peak %.1f GB" % (d["hbm_pool_peak_bytes"] / 1e9)
             except Exception as e:  # noqa: BLE001
                 extra += " [%s: %s]" % (f.rsplit("/", 1)[-1], e)
-        if leg == "lonek":
+        if leg in ("lonek", "poseidonlonek"):
             ks = {}
             for f in sorted(glob.glob("%s/%s_rep*.%s.json" % (out, lab, leg))):
                 try:

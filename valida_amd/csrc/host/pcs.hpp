@@ -116,7 +116,14 @@ struct DeviceTree {
         else vk::launch_keccak_leaves(st, pd + groups[0].first, (int)groups[0].count, maxh, layers[0].data);
         size_t gi = 1;
         // mid: the consecutive layers of 256 < parents <= 32768 (at most seven) as ONE launch of 64-parent workgroups; top: the rest in one workgroup
-        vk::KeccakTopArgs top{}, mid{};
+        vk::KeccakTopArgs top{}, mid{}, pgrp{};  // pgrp: the Poseidon tree's current group of row-parallel layers (launch_poseidon_levels)
+        int pgroup = -1;
+        auto flush_pos = [&](bool ends_at_root) {
+            if (!pgrp.levels) return;
+            if (ends_at_root && challenger_) { pgrp.ch_pos = challenger_->pos; pgrp.ch_state = challenger_->state; pgrp.ch_beta5 = challenger_->beta5; pgrp.ch_commit8 = challenger_->commit8; }
+            vk::launch_poseidon_levels(st, tab, c->poseidon_sparse, pgrp);
+            pgrp.levels = 0;
+        };
         auto add_level = [&](vk::KeccakTopArgs& g, uint64_t len, const Group* inj) {
             if (g.levels == 0) { g.prev = layers[layers.size() - 2].data; g.first_len = len; }
             g.out[g.levels] = layers.back().data;
@@ -142,9 +149,15 @@ struct DeviceTree {
             // Layers of more than TOP_FIRST_LEN parents are spread over the whole GPU (the big ones a launch each); the rest of the tree is one
             // single-workgroup launch.  256, not the 1024 a workgroup could take: inside one workgroup a 1024-parent layer puts four
             // waves on each SIMD of ONE CU and costs 27 us (512 parents: 15 us), as a launch of its own across the CUs 9 + 2 us.
-            if (len > TOP_FIRST_LEN) {
-                if (pos) vk::launch_poseidon_compress(st, tab, c->poseidon_sparse, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
-                else if (vk::keccak_levels_fused(len)) add_level(mid, len, inj);
+            if (pos) {  // big layers a thread per node, the rest in groups of five layers by 16-row workgroups (kernels/poseidon_mmcs.hip)
+                if (!vk::poseidon_levels_take(len)) vk::launch_poseidon_compress(st, tab, c->poseidon_sparse, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len, layers.back().data);
+                else {
+                    if (pgrp.levels && vk::poseidon_levels_group(len) != pgroup) flush_pos(false);
+                    pgroup = vk::poseidon_levels_group(len);
+                    add_level(pgrp, len, inj);
+                }
+            } else if (len > TOP_FIRST_LEN) {
+                if (vk::keccak_levels_fused(len)) add_level(mid, len, inj);
                 else vk::launch_keccak_compress(st, layers[layers.size() - 2].data, inj ? pd + inj->first : nullptr, inj ? (int)inj->count : 0, len,
                                                 layers.back().data);
             } else {  // the last <= 9 layers go into one launch
@@ -160,11 +173,12 @@ struct DeviceTree {
             if (!top.levels || top.prev != layers[0].data) throw std::logic_error("mmcs: leaf prologue without a top launch over the leaf layer");
             top.leaf_base = single_view->data; top.leaf_stride = single_view->stride; top.leaf_elems = (int)single_view->width; top.leaf_rows = maxh;
         }
-        if (challenger_) {
+        flush_pos(true);
+        if (challenger_ && !pos) {
             if (!top.levels) throw std::logic_error("mmcs: the challenger epilogue needs a tree with at least one parent layer");
             top.ch_pos = challenger_->pos; top.ch_state = challenger_->state; top.ch_beta5 = challenger_->beta5; top.ch_commit8 = challenger_->commit8;
         }
-        if (top.levels) { if (pos) vk::launch_poseidon_top(st, tab, c->poseidon_sparse, top); else vk::launch_keccak_top(st, top); }
+        if (top.levels) vk::launch_keccak_top(st, top);
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
         c->check_launch("mmcs build");
         if (fetch_root) c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished

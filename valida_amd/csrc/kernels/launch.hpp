@@ -103,7 +103,12 @@ bool keccak_top_takes_leaves(uint64_t n_rows);  // whether launch_keccak_top can
 void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);
 void launch_poseidon_leaves_strided(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests);
 void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next);
-void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, bool sparse, const KeccakTopArgs& a);
+// the layers of at most 16384 parents: launches of 16-row workgroups, each walking its sub-tree up to five layers down (one permutation per 16-lane row);
+// layers group by log2(parents) / 5, the group that ends at the root is one workgroup and may carry the FRI challenger step (a.ch_*)
+bool poseidon_levels_take(uint64_t parents);
+int poseidon_levels_group(uint64_t parents);
+void launch_poseidon_levels(hipStream_t st, const uint32_t* pos_dev, bool sparse, const KeccakTopArgs& a);
+void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, bool sparse, const KeccakTopArgs& a);  // first_len <= 16: the last group alone (sharded commitments)
 // perm.hip
 uint64_t perm_scratch_words(uint64_t n);
 void launch_add_ext_const(hipStream_t st, uint32_t* data, uint64_t stride, uint64_t n, const uint32_t* off5_dev);  // 5 columns += 5 Montgomery constants

@@ -130,10 +130,7 @@ __global__ void __launch_bounds__(256) k_poseidon_compress(const uint32_t* __res
 // lane, and the circulant MDS layer as 16 row rotations (v_mov_dpp row_ror:d brings x[(l - d) & 15] to lane l) times the wave-uniform
 // coefficient mds[d], accumulated lazily four at a time: ~85 dependent instructions per round, ~2 600 per permutation, four permutations per
 // wave.  Plain rounds (no sparse form: the partial rounds' saving is in the products the other lanes do in parallel anyway).  Levels of more
-// than 64 nodes stay with the thread-per-node permutation (1024 threads / 16 lanes = 64 rows).  VGPU_POSEIDON_ROWS=0: A/B builds.
-#ifndef VGPU_POSEIDON_ROWS
-#define VGPU_POSEIDON_ROWS 1
-#endif
+// than 64 nodes stay with the thread-per-node permutation (1024 threads / 16 lanes = 64 rows).
 template <int D> __device__ __forceinline__ uint32_t p_row_ror(uint32_t v) {
     if (D == 0) return v;
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + D, 0xF, 0xF, true);  // DPP row_ror:D — lane l of each row reads lane (l - D) & 15
@@ -145,8 +142,8 @@ template <int D0> __device__ __forceinline__ Fp p_mds4(uint32_t x, const uint32_
     t += (uint64_t)m[D0 + 3] * p_row_ror<D0 + 3>(x);
     return Fp::raw(vg::monty_reduce_wide(t));
 }
-// st = this lane's coordinate; all 16 lanes of the row run it together
-__device__ __forceinline__ Fp poseidon16_row(Fp st, const PoseidonTab& tab, const uint32_t (&m)[16], int l16) {
+// st = this lane's coordinate; all 16 lanes of the row run it together.  Plain form: 30 rounds with the dense circulant layer.
+__device__ __forceinline__ Fp poseidon16_row_plain(Fp st, const PoseidonTab& tab, const uint32_t (&m)[16], int l16) {
     uint32_t c_next = tab.rc[l16];  // the lane's round constant, fetched one round ahead (a vector load in the dependent chain would cost more than the round)
 #pragma unroll 1
     for (int r = 0; r < 30; r++) {
@@ -158,59 +155,111 @@ __device__ __forceinline__ Fp poseidon16_row(Fp st, const PoseidonTab& tab, cons
     }
     return st;
 }
-// one tree node by the 16 lanes of a row: compress of the two child digests, plus the injected rows' hash and a second compress
-__device__ __forceinline__ void poseidon_node_row(const uint32_t* __restrict__ prev, const uint32_t* const* cols, int n_elems, uint64_t node, int l16, const PoseidonTab& tab,
-                                                  const uint32_t (&m)[16], uint32_t* __restrict__ next) {
-    Fp st = poseidon16_row(Fp::from_canonical(prev[16 * node + l16]), tab, m, l16);  // lanes 0..7: left digest, 8..15: right — as they lie in the layer below
-    if (n_elems > 0) {
-        const Fp d = st;
-        Fp h = Fp::zero();
-        for (int base = 0; base < n_elems; base += 8) {  // PaddingFreeSponge: each chunk of 8 overwrites the head of the state
-            if (l16 < 8 && base + l16 < n_elems) h = Fp::raw(cols[base + l16][node]);
-            h = poseidon16_row(h, tab, m, l16);
-        }
-        // compress(d, h): the canonical words of both digests re-enter as field elements (canonical -> Montgomery is the identity on the value)
-        const uint32_t hs = p_row_ror<8>(h.v);  // lane 8 + k reads lane k
-        st = poseidon16_row(l16 < 8 ? d : Fp::raw(hs), tab, m, l16);
+// The SPARSE form of the 22 partial rounds by a row (round 6; host/poseidon_opt.hpp: S = [[a, u^T],[w, I]] per round, one dense matrix F at the end).
+// A sparse round costs the row: the broadcast of coordinate 0 (DPP row_newbcast), its S-box in every lane (redundantly: no divergence), ONE product per
+// lane — a x0 in lane 0, u[l] x[l] elsewhere — summed over the row by four rotate-and-add steps (the new coordinate 0), and x[l] += w[l] x0 beside it:
+// ~50 instructions, ~40 of them dependent, against the dense round's 85.  The per-lane coefficients (two words per round) are fetched a round ahead.
+__device__ __forceinline__ uint32_t p_row_bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150, 0xF, 0xF, true); }  // DPP row_newbcast:0
+template <int D> __device__ __forceinline__ Fp p_row_add_ror(Fp v) { return v + Fp::raw(p_row_ror<D>(v.v)); }
+template <int D0> __device__ __forceinline__ Fp p_dense4(uint32_t x, const uint32_t (&f)[16]) {
+    uint64_t t = (uint64_t)f[D0] * p_row_ror<D0>(x);
+    t += (uint64_t)f[D0 + 1] * p_row_ror<D0 + 1>(x);
+    t += (uint64_t)f[D0 + 2] * p_row_ror<D0 + 2>(x);
+    t += (uint64_t)f[D0 + 3] * p_row_ror<D0 + 3>(x);
+    return Fp::raw(vg::monty_reduce_wide(t));
+}
+__device__ __forceinline__ Fp poseidon16_row(Fp st, const PoseidonTab& tab, const uint32_t (&m)[16], int l16) {
+    if (tab.opt == nullptr) return poseidon16_row_plain(st, tab, m, l16);
+    const uint32_t* __restrict__ o = tab.opt;
+    uint32_t c_next = o[POPT_RC_FULL + l16];
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+        const uint32_t c = c_next;
+        c_next = o[POPT_RC_FULL + 16 * (r < 3 ? r + 1 : 4) + l16];  // (after round 3: the constants of the first closing full round)
+        const Fp x = poseidon_sbox_plus(st, c);
+        st = (p_mds4<0>(x.v, m) + p_mds4<4>(x.v, m)) + (p_mds4<8>(x.v, m) + p_mds4<12>(x.v, m));
     }
-    if (l16 < 8) next[8 * node + l16] = st.canonical();
+    const uint32_t c_close = c_next;
+    // 21 sparse rounds.  Coordinate 0 carries its round's scalar t_i as PENDING: it rides in the S-box's input (poseidon_sbox_plus), as in the thread form.
+    uint32_t dot_next = o[POPT_SPARSE + l16], upd_next = l16 ? o[POPT_SPARSE + 15 + l16] : 0u;
+#pragma unroll 1
+    for (int i = 0; i < 21; i++) {
+        const uint32_t dot = dot_next, upd = upd_next, t_i = o[POPT_T + i];
+        const int nx = i < 20 ? i + 1 : 0;
+        dot_next = o[POPT_SPARSE + 32 * nx + l16];
+        upd_next = l16 ? o[POPT_SPARSE + 32 * nx + 15 + l16] : 0u;
+        const Fp x0 = poseidon_sbox_plus(Fp::raw(p_row_bcast0(st.v)), t_i);
+        Fp r = Fp::raw(dot) * (l16 == 0 ? x0 : st);   // lane 0: a x0; lane l: u[l] x[l]
+        r = p_row_add_ror<8>(r); r = p_row_add_ror<4>(r); r = p_row_add_ror<2>(r); r = p_row_add_ror<1>(r);  // every lane: the row's sum = the new coordinate 0
+        const Fp up = st + Fp::raw(upd) * x0;         // x[l] + w[l] x0
+        st = l16 == 0 ? r : up;
+    }
+    {   // the last partial round: S-box on coordinate 0 (scalar t_21 pending), then the dense matrix F: y[l] = sum_d F[l][(l - d) & 15] x[(l - d) & 15]
+        uint32_t f[16];
+#pragma unroll
+        for (int d = 0; d < 16; d++) f[d] = o[POPT_F + 16 * l16 + ((l16 - d) & 15)];
+        const Fp sb = poseidon_sbox_plus(st, o[POPT_T + 21]);
+        const Fp x = l16 == 0 ? sb : st;
+        st = (p_dense4<0>(x.v, f) + p_dense4<4>(x.v, f)) + (p_dense4<8>(x.v, f) + p_dense4<12>(x.v, f));
+    }
+    c_next = c_close;
+#pragma unroll 1
+    for (int r = 4; r < 8; r++) {
+        const uint32_t c = c_next;
+        c_next = o[POPT_RC_FULL + 16 * (r < 7 ? r + 1 : 0) + l16];
+        const Fp x = poseidon_sbox_plus(st, c);
+        st = (p_mds4<0>(x.v, m) + p_mds4<4>(x.v, m)) + (p_mds4<8>(x.v, m) + p_mds4<12>(x.v, m));
+    }
+    return st;
 }
 
-// A layer of the latency-bound MIDDLE of a tree (256 < parents <= POSEIDON_ROW_MAX) with one node per 16-lane row (round 5): with a thread per
-// node such a layer is at most a quarter of a wave per SIMD, every wave alone with its ~9 200 dependent instructions (16-19 us per layer, 26 trees
-// x up to 4 such layers per proof); a row finishes its node in ~2 600.  The price is 4.4 x the lane-instructions per permutation, so the
-// threshold stays where the GPU is mostly idle anyway (thresholds 0 .. 65536 measured: profiles/r05_ab_valu_sensitivity_poseidon_rows.txt).
+// ---- THE LATENCY-BOUND PART OF A TREE (parents <= POSEIDON_ROW_MAX per layer) AS MULTI-LAYER LAUNCHES OF 16-ROW WORKGROUPS (round 6) ------------
+// Round 5 ran every layer of 256 < parents <= 16384 as a launch of its own (one node per 16-lane row) and the last nine layers in ONE 1024-thread
+// workgroup whose 256- and 128-parent layers fell back to a thread per node (~19 us each): 26 trees x (6 launches + a ~146 us top) = 5 ms of a lone
+// proof.  Here a 256-thread workgroup owns 16 consecutive parents of a launch's first layer and walks its own sub-tree DOWN TO ONE NODE — five
+// layers, every node by a 16-lane row, the children's digests handed from layer to layer through LDS (and stored for the query phase) — so that the
+// layers below 16384 parents cost a tree three launches (16384 .. 1024, 512 .. 32, 16 .. 1), each five row-permutations deep.  The last launch of a
+// tree (one workgroup) carries the FRI challenger step as k_keccak_top does.  Layers group by log2(parents) / 5 (DeviceTree, host/pcs.hpp).
 constexpr uint64_t POSEIDON_ROW_MAX = 16384;
-__global__ void __launch_bounds__(256) k_poseidon_compress_row(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int n_elems, uint64_t n_out,
-                                                               PoseidonTab tab, uint32_t* __restrict__ next) {
+constexpr int POSEIDON_LEVELS_PER_LAUNCH = 5, POSEIDON_LEVELS_ROWS = 16;
+__global__ void __launch_bounds__(256) k_poseidon_levels_row(KeccakTopArgs a, PoseidonTab tab) {
+    __shared__ uint32_t dig[2][POSEIDON_LEVELS_ROWS * 8];  // the digests a layer hands to the next one (double-buffered: one barrier per layer)
     uint32_t m[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, node = t >> 4;
-    if (node >= n_out) return;  // whole rows leave together (256 threads = 16 rows)
-    poseidon_node_row(prev, cols, n_elems, node, (int)(t & 15), tab, m, next);
-}
-
-// the last <= 11 levels of a tree in one launch (one 1024-thread workgroup, a barrier per level), as k_keccak_top
-__global__ void __launch_bounds__(1024) k_poseidon_top(KeccakTopArgs a, PoseidonTab gtab) {
-    __shared__ uint32_t s_opt[POPT_WORDS];
-    const PoseidonTab tab = poseidon_tab_in_lds(gtab, s_opt);
-    uint32_t m[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
-    const uint32_t* prev = a.prev;
+    const int row = (int)(threadIdx.x >> 4), l16 = (int)(threadIdx.x & 15);
+    const uint64_t rows0 = a.first_len < (uint64_t)POSEIDON_LEVELS_ROWS ? a.first_len : (uint64_t)POSEIDON_LEVELS_ROWS;  // nodes of the first layer in this workgroup
+    const uint64_t base0 = (uint64_t)blockIdx.x * rows0;
     for (int l = 0; l < a.levels; l++) {
-        const uint64_t len = a.first_len >> l;
-        if (VGPU_POSEIDON_ROWS && len <= 64) {
-            if ((threadIdx.x >> 4) < len) poseidon_node_row(prev, a.cols[l], a.n_elems[l], threadIdx.x >> 4, (int)(threadIdx.x & 15), tab, m, a.out[l]);
-        } else if (threadIdx.x < len) {
-            poseidon_node(prev, a.cols[l], a.n_elems[l], threadIdx.x, tab, a.out[l]);
+        const uint64_t cnt = rows0 >> l, node = (base0 >> l) + (uint64_t)row;  // this workgroup's nodes of layer l: cnt of them from base0 >> l
+        if ((uint64_t)row < cnt) {
+            // lanes 0..7: the left child's digest, 8..15: the right one's — from the layer below in HBM (first layer) or from the previous layer's LDS slots
+            const uint32_t child = l == 0 ? a.prev[16 * node + l16] : dig[(l - 1) & 1][(2 * row + (l16 >> 3)) * 8 + (l16 & 7)];
+            Fp st = poseidon16_row(Fp::from_canonical(child), tab, m, l16);
+            const int n_elems = a.n_elems[l];
+            if (n_elems > 0) {  // C(parent, H(rows)) at a layer that injects shorter matrices (FieldMerkleTree, App. B5)
+                const uint32_t* const* cols = a.cols[l];
+                const Fp d = st;
+                Fp h = Fp::zero();
+                for (int b = 0; b < n_elems; b += 8) {  // PaddingFreeSponge: each chunk of 8 overwrites the head of the state
+                    if (l16 < 8 && b + l16 < n_elems) h = Fp::raw(cols[b + l16][node]);
+                    h = poseidon16_row(h, tab, m, l16);
+                }
+                const uint32_t hs = p_row_ror<8>(h.v);  // lane 8 + k reads lane k
+                st = poseidon16_row(l16 < 8 ? d : Fp::raw(hs), tab, m, l16);
+            }
+            if (l16 < 8) {
+                const uint32_t w = st.canonical();
+                a.out[l][8 * node + l16] = w;
+                dig[l & 1][row * 8 + l16] = w;
+            }
         }
-        __threadfence_block();
         __syncthreads();
-        prev = a.out[l];
     }
-    if (a.ch_pos && threadIdx.x < 64) fri_challenge_step((int)threadIdx.x, a.ch_pos, a.ch_state, prev, a.ch_beta5, a.ch_commit8);
+    if (a.ch_pos && threadIdx.x < 64) {  // (one workgroup: the launch that ends at the root)
+        __threadfence_block();
+        fri_challenge_step((int)threadIdx.x, a.ch_pos, a.ch_state, a.out[a.levels - 1], a.ch_beta5, a.ch_commit8);
+    }
 }
 
 // Algorithmic VALU work for the profiler's valu_ops column (like KECCAK_VALU_PER_PERM): the instructions of ONE permutation as these kernels run
@@ -239,22 +288,29 @@ void launch_poseidon_leaves_strided(hipStream_t st, const uint32_t* pos_dev, boo
                        tab_of(pos_dev, sparse), digests);
 }
 void launch_poseidon_compress(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next) {
-    if (VGPU_POSEIDON_ROWS && n_out > 256 && n_out <= POSEIDON_ROW_MAX) {  // (layers of <= 256 parents belong to k_poseidon_top in a tree; the emulated-source tests launch tiny ones here)
-        ProfScope ps("k_poseidon_compress_row", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * p_node_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
-        VK_LAUNCH(k_poseidon_compress_row, dim3((unsigned)((16 * n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, tab_of(pos_dev, sparse), next);
-        return;
-    }
     ProfScope ps("k_poseidon_compress", st, (double)n_out * (96.0 + 4.0 * n_elems), (double)n_out * p_node_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
     VK_LAUNCH(k_poseidon_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, prev, cols_dev, n_elems, n_out, tab_of(pos_dev, sparse), next);
 }
-void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, bool sparse, const KeccakTopArgs& a) {
+bool poseidon_levels_take(uint64_t parents) { return parents <= POSEIDON_ROW_MAX; }
+int poseidon_levels_group(uint64_t parents) { return (int)(vg::log2_strict_u64(parents) / POSEIDON_LEVELS_PER_LAUNCH); }
+// a.first_len parents in the first layer, a.levels <= 5 layers, first_len >> (levels - 1) >= first_len / 16 (a workgroup's sub-tree ends at one node at the latest)
+void launch_poseidon_levels(hipStream_t st, const uint32_t* pos_dev, bool sparse, const KeccakTopArgs& a) {
+    if (a.levels < 1 || a.levels > POSEIDON_LEVELS_PER_LAUNCH || (a.first_len & (a.first_len - 1)) || !a.first_len) throw std::logic_error("poseidon levels: 1..5 layers from a power-of-two first layer");
+    const uint64_t rows0 = a.first_len < (uint64_t)POSEIDON_LEVELS_ROWS ? a.first_len : (uint64_t)POSEIDON_LEVELS_ROWS;
+    if ((rows0 >> (a.levels - 1)) == 0) throw std::logic_error("poseidon levels: more layers than a workgroup's sub-tree has");
+    if (a.ch_pos && a.first_len > rows0) throw std::logic_error("poseidon levels: the challenger step belongs to the launch that ends at the root");
     double bytes = 0, perms = 0;
     for (int l = 0; l < a.levels; l++) {
         bytes += (double)(a.first_len >> l) * (96.0 + 4.0 * a.n_elems[l]);
         perms += (double)(a.first_len >> l) * p_node_perms(a.n_elems[l]);
     }
-    ProfScope ps("k_poseidon_top", st, bytes, perms * POSEIDON_VALU_PER_PERM / 64.0);
-    VK_LAUNCH(k_poseidon_top, dim3(1), dim3(1024), 0, st, a, tab_of(pos_dev, sparse));
+    ProfScope ps(a.first_len <= rows0 ? "k_poseidon_top" : "k_poseidon_levels_row", st, bytes, perms * POSEIDON_VALU_PER_PERM / 64.0);
+    VK_LAUNCH(k_poseidon_levels_row, dim3((unsigned)(a.first_len / rows0)), dim3(256), 0, st, a, tab_of(pos_dev, sparse));
+}
+// the top of a sharded commitment (W / 2 <= 16 parents down to the root): the same launch as a tree's last group
+void launch_poseidon_top(hipStream_t st, const uint32_t* pos_dev, bool sparse, const KeccakTopArgs& a) {
+    if (a.first_len > (uint64_t)POSEIDON_LEVELS_ROWS) throw std::invalid_argument("poseidon top: at most 16 parents in the first layer (32 ranks)");
+    launch_poseidon_levels(st, pos_dev, sparse, a);
 }
 
 }  // namespace vk
