@@ -35,6 +35,17 @@ struct DeviceTree {
     std::vector<uint64_t> layer_len;
     unsigned log_max_height = 0;
     uint32_t root[8] = {0};            // canonical
+    // drop_bottom (set before build): a tree of at least DROP_MIN_LEAVES leaves built on the context's main stream returns its leaf layer — and the layer
+    // above it, unless that one injects rows — to the pool as soon as the layers above are enqueued (half / three quarters of the tree's digests; the pool
+    // hands a block only to work enqueued later on the same stream).  `dropped` layers have no buffer; the query phase recomputes their 40 sibling digests
+    // from the committed rows (vk::launch_*_bottom_q), which `leaf_ptr / leaf_stride / leaf_elems` describe: a column-pointer table (stride 0, kept alive
+    // in ptr_table_) or the one strided matrix of a FRI layer.  Only Prover::open_multi_batches reads such trees; the sharded prover keeps every layer.
+    static constexpr uint64_t DROP_MIN_LEAVES = 1ull << 16;
+    bool drop_bottom = false;
+    unsigned dropped = 0;
+    const void* leaf_ptr = nullptr;
+    uint64_t leaf_stride = 0;
+    int leaf_elems = 0;
 
     // mats: views in commit order.  Enqueues all kernels; root is read back (sync) at the end.
     // fetch_root = false leaves the root on the device only (layers.back()): the FRI commit phase consumes it there.
@@ -181,8 +192,17 @@ struct DeviceTree {
         if (top.levels) vk::launch_keccak_top(st, top);
         if (gi != groups.size()) throw std::runtime_error("mmcs: matrix heights must be powers of two >= 1 and <= max height");
         c->check_launch("mmcs build");
+        dropped = 0;
+        if (drop_bottom && st == c->stream && !c->in_section && maxh >= DROP_MIN_LEAVES && layers.size() >= 4) {
+            leaf_elems = (int)groups[0].count;
+            if (single) { leaf_ptr = single_view->data; leaf_stride = single_view->stride; }
+            else { leaf_ptr = pd + groups[0].first; leaf_stride = 0; }
+            layers[0] = DBuf();
+            dropped = 1;
+            if (!(groups.size() > 1 && groups[1].height == maxh / 2)) { layers[1] = DBuf(); dropped = 2; }
+        }
         if (fetch_root) c->download_small(root, layers.back().data, 32);  // sync: also keeps ptr_buf alive until the kernels finished
-        else ptr_table_ = std::move(ptr_buf);  // the kernels may still be queued: the table lives as long as the tree
+        if (!fetch_root || dropped) ptr_table_ = std::move(ptr_buf);  // the kernels may still be queued / the query phase reads the table: it lives as long as the tree
     }
 
 };
@@ -285,6 +305,7 @@ inline std::unique_ptr<ProverData> commit_batches(DeviceCtx* c, const std::vecto
     std::vector<vk::DMatView> views;
     for (auto& l : pd->ldes) views.push_back(l.view());
     lde_section.join();
+    pd->tree.drop_bottom = true;  // (big trees only: DeviceTree::DROP_MIN_LEAVES)
     pd->tree.build(c, views);
     // The rider's root: the build above synchronised on the main stream AFTER it had waited for the auxiliary stream at the join; the auxiliary
     // stream is still synchronised here in its own right (it has long drained: microseconds).

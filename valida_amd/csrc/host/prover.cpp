@@ -969,12 +969,14 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     for (unsigned lf = log_max; lf-- > lb; li++) {
         uint64_t L = 2ull << lf, half = L >> 1;  // current length 2^(lf+1)
         layer_trees.emplace_back();
+        layer_trees.back().drop_bottom = true;  // (layers of >= 2^16 pairs)
         // the challenger step rides on the tree-top launch (its first wave, on the root it has just written): one launch and one gap less per layer
         const DeviceTree::TopChallenger step{pow_pos_.data, ch_dev.data, betas_dev.data + 5 * li, commits_dev.data + 8 * li};
         layer_trees.back().build(&c, {vk::DMatView{cur.data, half, 10, half}}, false, nullptr, &step);
         DBuf next(&c, (size_t)(5 * half));
         auto it = ro.find(lf);
         vk::launch_fri_fold(c.stream, cur.data, L, betas_dev.data + 5 * li, it != ro.end() ? it->second.data : nullptr, c.tables, next.data);
+        if (it != ro.end()) ro.erase(it);  // folded in: back to the pool (the fold is enqueued; the pool orders reuse on this stream)
         layer_bufs.push_back(std::move(cur));
         cur = std::move(next);
     }
@@ -984,7 +986,7 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     // as placeholders).  After the indices are sampled only they travel (k_gather_q).
     const size_t NQ = fri_.num_queries, NL = layer_trees.size();
     if (NQ > 256) throw std::invalid_argument("open: at most 256 queries");
-    std::vector<uint32_t> templ;
+    std::vector<uint32_t> templ, bottom_jobs;
     std::vector<std::pair<uint32_t, uint32_t>> fix;  // (position in the tail, value) of the words the host writes
     size_t fix_roots_at = 0, fix_final_at = 0;
     uint32_t tail_pos = 0;
@@ -1005,10 +1007,18 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
             templ.insert(templ.end(), d8, d8 + 8);
             pos += count;
         };
-        // the path of leaf (index >> shift0) in tree t: level l's sibling is ((index >> shift0) >> l) ^ 1
+        // the path of leaf (index >> shift0) in tree t: level l's sibling is ((index >> shift0) >> l) ^ 1.  The layers a big tree did not keep
+        // (DeviceTree::dropped) are recomputed from the committed rows by a job each (vk::launch_*_bottom_q) instead of gathered.
         auto gather_path = [&](const DeviceTree& t, size_t q, uint32_t shift0) {
             host_word(t.log_max_height);
-            for (unsigned l = 0; l < t.log_max_height; l++) gather(t.layers[l].data, 1, 8, 1, q, 1, shift0 + l, 0);
+            for (unsigned l = 0; l < t.log_max_height; l++) {
+                if (l < t.dropped) {
+                    const uint64_t pv = (uint64_t)t.leaf_ptr;
+                    const uint32_t j8[8] = {(uint32_t)pv, (uint32_t)(pv >> 32), (uint32_t)t.leaf_stride, (uint32_t)(t.leaf_stride >> 32), (uint32_t)t.leaf_elems, pos, (uint32_t)q | (l << 8) | (shift0 << 16), 0};
+                    bottom_jobs.insert(bottom_jobs.end(), j8, j8 + 8);
+                    pos += 8;
+                } else gather(t.layers[l].data, 1, 8, 1, q, 1, shift0 + l, 0);
+            }
         };
         host_word((uint32_t)NL);
         fix_roots_at = fix.size();
@@ -1043,6 +1053,9 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     }
     const size_t tail_words = tail_pos;
     templ.push_back(0);
+    const size_t n_bottom = bottom_jobs.size() / 8;
+    bottom_jobs.push_back(0);
+    DBuf bottom_dev(&c, bottom_jobs);
     DBuf templ_dev(&c, templ), gout(&c, tail_words + 4);  // the upload is enqueued behind the commit phase; nothing waits for it until the gather
     // `cur` now holds 2^lb values that must all be equal (a constant polynomial)
     std::vector<uint32_t> fin(5ull << lb), commits(8 * n_layers + 8);
@@ -1102,6 +1115,8 @@ PcsOpening Prover::open_multi_batches(const std::vector<OpenRound>& rounds, Chal
     fix[fix_final_at + 5].second = pow_witness;
     DBuf idx_dev(&c, indices);
     vk::launch_gather_q(c.stream, templ_dev.data, (templ.size() - 1) / 8, idx_dev.data, gout.data);
+    if (c.hash_kind == 1) vk::launch_poseidon_bottom_q(c.stream, c.poseidon_tab, c.poseidon_sparse, bottom_dev.data, (uint32_t)n_bottom, idx_dev.data, gout.data);
+    else vk::launch_keccak_bottom_q(c.stream, bottom_dev.data, (uint32_t)n_bottom, idx_dev.data, gout.data);
     c.check_launch("query gather");
     res.proof_words.resize(tail_words);
     c.download_small(res.proof_words.data(), gout.data, tail_words * 4);  // through pinned memory

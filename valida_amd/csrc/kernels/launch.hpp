@@ -63,6 +63,10 @@ void launch_lde_natural(hipStream_t st, DMatView nat, DMatView lde, int log_blow
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests);
 void launch_keccak_leaves_strided(hipStream_t st, const uint32_t* base, uint64_t stride, int n_elems, uint64_t n_rows, uint32_t* digests);
 void launch_keccak_compress(hipStream_t st, const uint32_t* prev, const uint32_t* const* cols_dev, int n_elems, uint64_t n_out, uint32_t* next);
+// The sibling digests of the two BOTTOM layers of a tree that did not keep them (DeviceTree::drop_bottom), recomputed at query time from the committed rows.
+// jobs: 8 words each (merkle.hip, k_keccak_bottom_q); indices_dev: the sampled query indices; dst: the proof tail being gathered.
+void launch_keccak_bottom_q(hipStream_t st, const uint32_t* jobs_dev, uint32_t n_jobs, const uint32_t* indices_dev, uint32_t* dst);
+void launch_poseidon_bottom_q(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* jobs_dev, uint32_t n_jobs, const uint32_t* indices_dev, uint32_t* dst);
 constexpr int KECCAK_TOP_MAX_LEVELS = 11;  // first_len <= 1024
 struct KeccakTopArgs {
     const uint32_t* prev;  // layer with 2 * first_len digests

@@ -358,6 +358,39 @@ void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
     VK_LAUNCH(k_keccak_top, dim3(1), dim3(1024), 0, st, a);
 }
 
+// ---- the bottom of a big tree at QUERY time (round 6) ------------------------------------------------------------------------------------------
+// A tree of 2^k leaves keeps 2 x 2^k digests: half of them the leaf layer, a quarter the layer above — 2.1 + 1.1 GB per 2^26-row commitment of C3
+// (three of them plus the FRI layers: 12 GB of the 45 GB a context held).  Both layers are needed again for 40 sibling digests each, so big trees
+// give them back to the pool once the layers above are built (DeviceTree::drop_bottom) and the query phase RECOMPUTES the siblings from the committed
+// rows: a job = the leaf hash of one row (level 0) or the compression of two neighbouring leaf hashes (level 1; only when that layer injects nothing).
+// job: [0..1] column-pointer table (PtrCols) or matrix base (StridedCols)  [2..3] stride (0: pointer table)  [4] n_elems  [5] destination word
+//      [6] query | level << 8 | shift << 16  [7] unused;  node = ((index[query] >> shift) >> level) ^ 1
+template <class Cols> __device__ __forceinline__ void bottom_digest(const Cols cols, int n_elems, uint64_t node, uint32_t level, uint32_t (&d)[8]) {
+    if (level == 0) { hash_row(cols, n_elems, node, d); return; }
+    uint32_t l[8], r[8];
+    hash_row(cols, n_elems, 2 * node, l);
+    hash_row(cols, n_elems, 2 * node + 1, r);
+    compress2(l, r, d);
+}
+__global__ void __launch_bounds__(64) k_keccak_bottom_q(const uint32_t* __restrict__ jobs, uint32_t n_jobs, const uint32_t* __restrict__ indices, uint32_t* __restrict__ dst) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_jobs) return;
+    const uint32_t* e = jobs + 8 * j;
+    const uint64_t ptr = ((uint64_t)e[1] << 32) | e[0], stride = ((uint64_t)e[3] << 32) | e[2];
+    const uint32_t q = e[6] & 0xffu, level = (e[6] >> 8) & 0xffu, shift = e[6] >> 16;
+    const uint64_t node = (((uint64_t)indices[q] >> shift) >> level) ^ 1u;
+    uint32_t d[8];
+    if (stride) bottom_digest(StridedCols{reinterpret_cast<const uint32_t*>(ptr), stride}, (int)e[4], node, level, d);
+    else bottom_digest(PtrCols{reinterpret_cast<const uint32_t* const*>(ptr)}, (int)e[4], node, level, d);
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[e[5] + k] = d[k];  // (proof positions are not 16-byte aligned)
+}
+void launch_keccak_bottom_q(hipStream_t st, const uint32_t* jobs_dev, uint32_t n_jobs, const uint32_t* indices_dev, uint32_t* dst) {
+    if (!n_jobs) return;
+    ProfScope ps("k_gather", st, 0.0);
+    VK_LAUNCH(k_keccak_bottom_q, dim3((n_jobs + 63) / 64), dim3(64), 0, st, jobs_dev, n_jobs, indices_dev, dst);
+}
+
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
     const bool pairs = keccak_pairs_enabled() && n_rows <= KECCAK_PAIR_MAX_NODES;
