@@ -11,14 +11,15 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 B="python $ROOT/bench.py --no-cpu-baseline"
+Q="--sustained-seconds 0"  # the profiled passes run the contract region only (a 6 s sustained region under rocprofv3 would be all trace)
 # bench line alone first (no profiler attached)
 $B > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 $B --inflight 1 > "$OUT/bench_inflight1.json" 2> "$OUT/bench_inflight1.err"
 # 1) kernel trace + stats of the default command and of the one-proof-in-flight command
-rocprofv3 --kernel-trace --stats -d "$OUT/stats2" -o run -- $B --no-extra-legs --steps 24 --warmup 3 > "$OUT/stats2.json" 2> "$OUT/stats2.err"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats1" -o run -- $B --no-extra-legs --inflight 1 --steps 10 --warmup 1 > "$OUT/stats1.json" 2> "$OUT/stats1.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats2" -o run -- $B $Q --no-extra-legs --steps 24 --warmup 3 > "$OUT/stats2.json" 2> "$OUT/stats2.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats1" -o run -- $B $Q --no-extra-legs --inflight 1 --steps 10 --warmup 1 > "$OUT/stats1.json" 2> "$OUT/stats1.err"
 # 2) counters, separate passes, one proof in flight, few steps
-P="env VGPU_BENCH_SHARDED=0 $B --inflight 1 --steps 2 --warmup 1"  # without the sharded-prover leg: its shard-size launches would mix into the per-launch averages
+P="env VGPU_BENCH_SHARDED=0 $B $Q --inflight 1 --steps 2 --warmup 1"  # without the sharded-prover leg: its shard-size launches would mix into the per-launch averages
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d "$OUT/pmc_valu" -o run -- $P > "$OUT/pmc_valu.json" 2> "$OUT/pmc_valu.err"
 # VALU issue utilisation per SIMD: busy cycles of the CUs and of the whole GPU next to the VALU-active wave cycles
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_busy" -o run -- $P > "$OUT/pmc_busy.json" 2> "$OUT/pmc_busy.err"
