@@ -365,30 +365,38 @@ void launch_keccak_top(hipStream_t st, const KeccakTopArgs& a) {
 // rows: a job = the leaf hash of one row (level 0) or the compression of two neighbouring leaf hashes (level 1; only when that layer injects nothing).
 // job: [0..1] column-pointer table (PtrCols) or matrix base (StridedCols)  [2..3] stride (0: pointer table)  [4] n_elems  [5] destination word
 //      [6] query | level << 8 | shift << 16  [7] unused;  node = ((index[query] >> shift) >> level) ^ 1
-template <class Cols> __device__ __forceinline__ void bottom_digest(const Cols cols, int n_elems, uint64_t node, uint32_t level, uint32_t (&d)[8]) {
-    if (level == 0) { hash_row(cols, n_elems, node, d); return; }
-    uint32_t l[8], r[8];
-    hash_row(cols, n_elems, 2 * node, l);
-    hash_row(cols, n_elems, 2 * node + 1, r);
-    compress2(l, r, d);
+// FOUR lanes per job (the lane-pair permutation of keccak_pair.hpp, ~8 us deep): pair A = lanes 0, 1 hashes row `node` (level 0) or row 2 node
+// (level 1), pair B = lanes 2, 3 row 2 node + 1; at level 1 pair A then compresses its digest with pair B's (one quad_perm exchange).
+template <class Cols> __device__ __forceinline__ void bottom_digest_quad(const Cols cols, int n_elems, uint64_t node, uint32_t level, int pair, int h, uint32_t (&d)[4]) {
+    uint32_t own[4];
+    hash_row_pair(cols, n_elems, level ? 2 * node + (uint64_t)pair : node, h, own);
+    if (level == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[i] = own[i];
+        return;
+    }
+    uint32_t right[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) right[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[i], 0xEE, 0xF, 0xF, true);  // quad_perm [2, 3, 2, 3]: pair B's halves
+    compress2_pair(own, right, h, d);  // (pair B runs it too, on its own digest twice: discarded)
 }
-__global__ void __launch_bounds__(64) k_keccak_bottom_q(const uint32_t* __restrict__ jobs, uint32_t n_jobs, const uint32_t* __restrict__ indices, uint32_t* __restrict__ dst) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_jobs) return;
+__global__ void __launch_bounds__(256) k_keccak_bottom_q(const uint32_t* __restrict__ jobs, uint32_t n_jobs, const uint32_t* __restrict__ indices, uint32_t* __restrict__ dst) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, j = t >> 2;
+    if (j >= n_jobs) return;  // whole quads leave together
+    const int pair = (int)((t >> 1) & 1u), h = (int)(t & 1u);
     const uint32_t* e = jobs + 8 * j;
     const uint64_t ptr = ((uint64_t)e[1] << 32) | e[0], stride = ((uint64_t)e[3] << 32) | e[2];
     const uint32_t q = e[6] & 0xffu, level = (e[6] >> 8) & 0xffu, shift = e[6] >> 16;
     const uint64_t node = (((uint64_t)indices[q] >> shift) >> level) ^ 1u;
-    uint32_t d[8];
-    if (stride) bottom_digest(StridedCols{reinterpret_cast<const uint32_t*>(ptr), stride}, (int)e[4], node, level, d);
-    else bottom_digest(PtrCols{reinterpret_cast<const uint32_t* const*>(ptr)}, (int)e[4], node, level, d);
-#pragma unroll
-    for (int k = 0; k < 8; k++) dst[e[5] + k] = d[k];  // (proof positions are not 16-byte aligned)
+    uint32_t d[4];
+    if (stride) bottom_digest_quad(StridedCols{reinterpret_cast<const uint32_t*>(ptr), stride}, (int)e[4], node, level, pair, h, d);
+    else bottom_digest_quad(PtrCols{reinterpret_cast<const uint32_t* const*>(ptr)}, (int)e[4], node, level, pair, h, d);
+    if (pair == 0) store_digest_half(dst + e[5], h, d);
 }
 void launch_keccak_bottom_q(hipStream_t st, const uint32_t* jobs_dev, uint32_t n_jobs, const uint32_t* indices_dev, uint32_t* dst) {
     if (!n_jobs) return;
     ProfScope ps("k_gather", st, 0.0);
-    VK_LAUNCH(k_keccak_bottom_q, dim3((n_jobs + 63) / 64), dim3(64), 0, st, jobs_dev, n_jobs, indices_dev, dst);
+    VK_LAUNCH(k_keccak_bottom_q, dim3((4 * n_jobs + 255) / 256), dim3(256), 0, st, jobs_dev, n_jobs, indices_dev, dst);
 }
 
 void launch_keccak_leaves(hipStream_t st, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {

@@ -278,31 +278,38 @@ constexpr double POSEIDON_HALF_PER_PERM = 1350.0 + 1152.0 + 1059.0 + 384.0, POSE
 constexpr double POSEIDON_VALU_PER_PERM = POSEIDON_HALF_PER_PERM + POSEIDON_FULL_PER_PERM;
 static double p_row_perms(int n_elems) { return (double)((n_elems + 7) / 8); }
 static double p_node_perms(int n_inject) { return n_inject > 0 ? 2.0 + p_row_perms(n_inject) : 1.0; }
-// the bottom of a big tree at query time (merkle.hip, k_keccak_bottom_q: same job words)
-template <class Cols> __device__ __forceinline__ void poseidon_bottom_digest(const Cols cols, int n_elems, uint64_t node, uint32_t level, const PoseidonTab& tab, uint32_t (&d)[8]) {
-    if (level == 0) { poseidon_hash_row(cols, n_elems, node, tab, d); return; }
-    uint32_t l[8], r[8];
-    poseidon_hash_row(cols, n_elems, 2 * node, tab, l);
-    poseidon_hash_row(cols, n_elems, 2 * node + 1, tab, r);
-    poseidon_compress2(l, r, tab, d);
-}
-__global__ void __launch_bounds__(64) k_poseidon_bottom_q(const uint32_t* __restrict__ jobs, uint32_t n_jobs, const uint32_t* __restrict__ indices, PoseidonTab tab, uint32_t* __restrict__ dst) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_jobs) return;
+// the bottom of a big tree at query time (merkle.hip, k_keccak_bottom_q: same job words).  32 lanes per job, the ROW permutation: lanes 0..15 hash row `node`
+// (level 0) or row 2 node (level 1), lanes 16..31 row 2 node + 1; at level 1 the first row then compresses its digest with the second one's.
+__global__ void __launch_bounds__(256) k_poseidon_bottom_q(const uint32_t* __restrict__ jobs, uint32_t n_jobs, const uint32_t* __restrict__ indices, PoseidonTab tab, uint32_t* __restrict__ dst) {
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, j = t >> 5;
+    if (j >= n_jobs) return;  // whole half-waves leave together
+    const int grp = (int)((t >> 4) & 1u), l16 = (int)(t & 15u);
     const uint32_t* e = jobs + 8 * j;
     const uint64_t ptr = ((uint64_t)e[1] << 32) | e[0], stride = ((uint64_t)e[3] << 32) | e[2];
+    const int n_elems = (int)e[4];
     const uint32_t q = e[6] & 0xffu, level = (e[6] >> 8) & 0xffu, shift = e[6] >> 16;
-    const uint64_t node = (((uint64_t)indices[q] >> shift) >> level) ^ 1u;
-    uint32_t d[8];
-    if (stride) poseidon_bottom_digest(PStridedCols{reinterpret_cast<const uint32_t*>(ptr), stride}, (int)e[4], node, level, tab, d);
-    else poseidon_bottom_digest(PPtrCols{reinterpret_cast<const uint32_t* const*>(ptr)}, (int)e[4], node, level, tab, d);
-#pragma unroll
-    for (int k = 0; k < 8; k++) dst[e[5] + k] = d[k];
+    const uint64_t node = (((uint64_t)indices[q] >> shift) >> level) ^ 1u, row = level ? 2 * node + (uint64_t)grp : node;
+    Fp h = Fp::zero();
+    for (int b = 0; b < n_elems; b += 8) {  // PaddingFreeSponge: each chunk of 8 overwrites the head of the state
+        if (l16 < 8 && b + l16 < n_elems) {
+            const uint32_t* col = stride ? reinterpret_cast<const uint32_t*>(ptr) + (uint64_t)(b + l16) * stride : reinterpret_cast<const uint32_t* const*>(ptr)[b + l16];
+            h = Fp::raw(col[row]);
+        }
+        h = poseidon16_row(h, tab, m, l16);
+    }
+    if (level) {  // compress(left, right): lanes 8..15 of the first row take lanes 0..7 of the second (the Montgomery words re-enter as they are)
+        const uint32_t other = (uint32_t)__shfl((int)h.v, (int)((threadIdx.x & 32u) + 16u + (uint32_t)(l16 & 7)), 64);  // source lane within the wave
+        h = poseidon16_row(l16 < 8 ? h : Fp::raw(other), tab, m, l16);
+    }
+    if (grp == 0 && l16 < 8) dst[e[5] + l16] = h.canonical();
 }
 void launch_poseidon_bottom_q(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* jobs_dev, uint32_t n_jobs, const uint32_t* indices_dev, uint32_t* dst) {
     if (!n_jobs) return;
     ProfScope ps("k_gather", st, 0.0);
-    VK_LAUNCH(k_poseidon_bottom_q, dim3((n_jobs + 63) / 64), dim3(64), 0, st, jobs_dev, n_jobs, indices_dev, tab_of(pos_dev, sparse), dst);
+    VK_LAUNCH(k_poseidon_bottom_q, dim3((32 * n_jobs + 255) / 256), dim3(256), 0, st, jobs_dev, n_jobs, indices_dev, tab_of(pos_dev, sparse), dst);
 }
 void launch_poseidon_leaves(hipStream_t st, const uint32_t* pos_dev, bool sparse, const uint32_t* const* cols_dev, int n_elems, uint64_t n_rows, uint32_t* digests) {
     ProfScope ps("k_poseidon_leaves", st, (double)n_rows * (4.0 * n_elems + 32.0), (double)n_rows * p_row_perms(n_elems) * POSEIDON_VALU_PER_PERM / 64.0);
