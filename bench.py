@@ -624,7 +624,9 @@ def main():
     # Per-kernel table: a few steps with events on EVERY launch, outside the timed region.  Timed region: events on the launches
     # of the dominant kernel only — a timed launch carries a pair of events, and 1270 of them per proof cost ~4 % of the throughput
     # being measured; the roofline needs that kernel's live average, the table does not need the timed region.
+    pool_peak_whole = sum(p_.memory()[1] for p_ in provers)  # with the legs above (uploads of the PCIe legs, the sharded leg's shards) in it
     for p_ in provers:
+        p_.reset_memory_peak()  # from here on: the proving path alone (kernel table, contract region, sustained region)
         p_.set_profiling(True)
     run_steps(2 * len(provers))
     torch.cuda.synchronize()
@@ -880,7 +882,10 @@ def main():
             "proof_words": int(p.words.size),
             "proof_sha256": hashlib.sha256(p.bytes()).hexdigest(),  # the LAST proof of the timed region (the one vgpu_verify checks below)
             "proof_checked_by_vgpu_verify": verified,  # Machine::verify of the library (host) on the last timed proof
+            # peak of the contexts' HBM pools over the PROVING path (kernel table, contract and sustained regions); the reporting legs before it (PCIe uploads,
+            # operation logs, one proof over W contexts) have their own, larger, high-water mark
             "hbm_pool_peak_bytes": sum(p_.memory()[1] for p_ in provers),
+            "hbm_pool_peak_bytes_with_reporting_legs": max(pool_peak_whole, sum(p_.memory()[1] for p_ in provers)),
         }
         if not args.no_cpu_baseline and world == 1:
             headline = min(args.log_rows, 20)

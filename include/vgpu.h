@@ -136,6 +136,8 @@ void vgpu_prover_memory(const vgpu_prover_t* p, uint64_t* live_bytes, uint64_t* 
 /* The prover caches device blocks by size and reuses them (no hipMalloc in the steady state).  Returns the cached-but-unused
  * blocks to the driver (bytes freed); also done automatically, once, when an allocation runs out of memory. */
 uint64_t vgpu_prover_trim(vgpu_prover_t* p);
+/* The pool's peak restarts from what is held now (a host that wants the high-water mark of ONE phase: bench.py reports the proving path's own). */
+void vgpu_prover_memory_reset_peak(vgpu_prover_t* p);
 
 /* per-kernel HIP-event timing (bench): switch on/off (resets the accumulators); the profile is text,
  * one line per kernel: "name launches total_ms total_algorithmic_bytes".  Returns the size needed. */

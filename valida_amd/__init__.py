@@ -1021,6 +1021,10 @@ class Prover:
         lib().vgpu_prover_trim.restype = ctypes.c_uint64
         return int(lib().vgpu_prover_trim(self._h))
 
+    def reset_memory_peak(self):
+        """The pool's peak restarts from what is held now (vgpu_prover_memory_reset_peak)."""
+        lib().vgpu_prover_memory_reset_peak(self._h)
+
     def memory(self):
         live, peak = ctypes.c_uint64(), ctypes.c_uint64()
         lib().vgpu_prover_memory(self._h, ctypes.byref(live), ctypes.byref(peak))

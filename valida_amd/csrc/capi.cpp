@@ -297,6 +297,12 @@ void vgpu_prover_memory(const vgpu_prover_t* p, uint64_t* live, uint64_t* peak) 
     if (live) *live = c.live;
     if (peak) *peak = c.peak_live;
 }
+void vgpu_prover_memory_reset_peak(vgpu_prover_t* p) {
+    if (!p) return;
+    DeviceCtx& c = p->p->ctx();
+    std::lock_guard<std::mutex> lk(c.pool_mu);
+    c.peak_live = c.live;
+}
 uint64_t vgpu_prover_trim(vgpu_prover_t* p) {
     if (!p) return 0;
     DeviceCtx& c = p->p->ctx();
