@@ -301,10 +301,10 @@ def test_proof_cbor_matches_independent_encoder(flags):
 
 
 def test_committed_bench_line_follows_the_contract():
-    # profiles/r05_bench_full.json is the line bench.py printed on the MI355X in the round's profile session: every field the driver reads is there
+    # profiles/r06_bench_full.json is the line bench.py printed on the MI355X in the round's profile session: every field the driver reads is there
     import json
 
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_bench_full.json")) as f:
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_bench_full.json")) as f:
         d = json.load(f)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
@@ -340,6 +340,13 @@ def test_committed_bench_line_follows_the_contract():
     assert d["proof_checked_by_vgpu_verify"]["accepted"] is True
     p = d["pcie_inclusive"]
     assert p["value"] < d["value"] and p["from_pinned_host_memory"]["value"] < d["value"] * 1.02  # the host-resident readings, beside the headline
+    # round 6: the line carries the SUSTAINED figure of >= 5 s behind the contract region, its own clock, and the dominant kernel's roofline at both clocks
+    su = d["sustained"]
+    assert su["seconds"] >= 5.0 and su["steps"] >= 300 and abs(su["proofs_per_s"] - su["steps"] / su["seconds"]) < 1e-6 * su["proofs_per_s"]
+    assert su["proofs_per_s"] <= d["value"] * 1.02 and 1.5 < su["shader_clock_GHz"] <= 2.45
+    sr = su["roofline"]
+    assert sr["kernel"] == r["kernel"] and 0 < sr["frac_at_guide_clock"] < sr["frac_at_measured_clock"] < 1
+    assert abs(sr["frac_at_measured_clock"] - sr["frac_at_guide_clock"] * 2.4 / su["shader_clock_GHz"]) < 1e-9
 
 
 def test_bench_reads_its_valu_peaks_from_the_committed_microbench_report():

@@ -134,6 +134,7 @@ inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned 
 // device challenger step behind the tree-top kernels — take that branch only when asked to)
 inline int __builtin_amdgcn_readlane(int, int) { throw std::runtime_error("hipemu: wave intrinsic (v_readlane) reached"); }
 inline int __builtin_amdgcn_update_dpp(int, int, int, int, int, bool) { throw std::runtime_error("hipemu: wave intrinsic (DPP) reached"); }
+inline int __shfl(int, int, int = 64) { throw std::runtime_error("hipemu: wave intrinsic (__shfl) reached"); }
 // per-lane integer primitives of gfx950 that ARE plain functions of their operands
 inline unsigned __builtin_amdgcn_bitop3_b32(unsigned a, unsigned b, unsigned c, unsigned truth_table) {  // bit i of the result = table[(a_i, b_i, c_i)]
     unsigned r = 0;
