@@ -821,6 +821,10 @@ def test_proof_assembled_from_fine_grained_calls_is_the_same_proof(machine, rc, 
 @pytest.mark.parametrize("shapes", [
     [[(64, 130), (64, 3)], [(256, 2), (8, 7), (1, 4)]],                       # every matrix below the matrix-core threshold (VALU k_col_dot)
     [[(2048, 130), (1024, 3)], [(4096, 17), (1024, 33), (64, 5)]],            # k_col_dot_mfma: column groups of 16 with ragged tails, chunked columns
+    # trees of >= 2^16 leaves, whose bottom digest layers are NOT kept (round 6, DeviceTree::drop_bottom): round 0 injects a matrix at layer 1 (only the leaf
+    # layer goes; its siblings are recomputed as row hashes), round 1 drops two layers (level-1 siblings = compress of two recomputed row hashes); the FRI
+    # layer trees of 2^16 pairs likewise
+    [[(1 << 15, 3), (1 << 14, 2)], [(1 << 16, 2), (1 << 13, 4), (1 << 16, 1)]],
 ])
 def test_open_multi_batches_generic_shapes_match_oracle(machine, rc, shapes):
     """Shapes Machine::prove never produces: one round with a 130-column matrix (column chunks in k_col_dot), five points on one
@@ -832,6 +836,8 @@ def test_open_multi_batches_generic_shapes_match_oracle(machine, rc, shapes):
     ext = lambda: [int(x) for x in rng.integers(1, P, 5)]
     pts = [ext() for _ in range(6)]
     points = [[[pts[0]], [pts[0], pts[1], pts[2], pts[3], pts[4]]], [[pts[5], pts[0]], [pts[1]], [pts[2], pts[3], pts[4]]]]
+    if rounds[0][0].shape[0] >= 1 << 15:  # the tall case: fewer points (the oracle's barycentric sums are the slow part there)
+        points = [[[pts[0]], [pts[0], pts[1]]], [[pts[5], pts[0]], [pts[1]], [pts[2]]]]
     obs = [int(x) for x in rng.integers(0, P, 11)]
     roots, values, proof = po.pcs_open(rounds, points, rc, observed=obs, num_queries=9, pow_bits=3)
     pds = [p.commit_batches([p.upload(m) for m in rnd]) for rnd in rounds]
@@ -871,6 +877,27 @@ def test_poseidon_mmcs_commit_roots(machine, rc, poseidon_oracle):
     for mats in batches:
         pd = p.commit_batches([p.upload(m) for m in mats])
         assert first_mismatch(pd.root, po.commit_root(mats)) is None, [m.shape for m in mats]
+
+
+def test_poseidon_open_of_trees_that_dropped_their_bottom_layers(machine, rc, poseidon_oracle):
+    """As the tall case of test_open_multi_batches_generic_shapes_match_oracle with the Poseidon-16 MMCS: the sibling digests of the dropped layers come from
+    k_poseidon_bottom_q (row permutation, 32 lanes per sibling) — one round with an injection at layer 1 (one layer dropped), one without (two)."""
+    p = va.Prover(machine, rc, num_queries=9, pow_bits=3, hash_kind=va.HASH_POSEIDON16)
+    rng = np.random.default_rng(77)
+    rounds = [[rand_matrix(rng, 1 << 15, 9), rand_matrix(rng, 1 << 14, 2)], [rand_matrix(rng, 1 << 16, 2), rand_matrix(rng, 1 << 13, 17)]]
+    ext = lambda: [int(x) for x in rng.integers(1, P, 5)]
+    pts = [ext() for _ in range(3)]
+    points = [[[pts[0]], [pts[0], pts[1]]], [[pts[2], pts[0]], [pts[1]]]]
+    obs = [int(x) for x in rng.integers(0, P, 5)]
+    roots, values, proof = po.pcs_open(rounds, points, rc, observed=obs, num_queries=9, pow_bits=3)
+    pds = [p.commit_batches([p.upload(m) for m in rnd]) for rnd in rounds]
+    for k, pd in enumerate(pds):
+        assert first_mismatch(pd.root, roots[k]) is None
+    ch = va.Challenger(rc)
+    ch.observe(obs)
+    opened, words = p.open_multi_batches(pds, points, ch)
+    assert first_mismatch(np.concatenate([v.ravel() for rnd in opened for mat in rnd for v in mat]), values) is None
+    assert first_mismatch(words, proof) is None
 
 
 @pytest.mark.parametrize("make", [lambda: va.Workload.fib(25), lambda: va.Workload.alu(40), lambda: va.Workload.fib(582)])
