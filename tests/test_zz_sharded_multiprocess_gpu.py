@@ -353,7 +353,7 @@ def _device_count():
 
 
 def _rccl_world(world):
-    res = _run(world, "fib582_oracle.json", 10, target=_rccl_worker, deadline_s=200)
+    res = _run(world, "fib582_oracle.json", 10 if world == 2 else 12, target=_rccl_worker, deadline_s=200)  # (world, threshold) pairs the gloo runs above already prove with
     refused = [r for r in range(world) if "rccl_refused" in res[r]]
     return res, refused
 

@@ -144,10 +144,36 @@ __global__ void __launch_bounds__(256) k_perm_recip_native(DMatView main, const 
 // below: not faster alone, 1.2 % slower with three proofs in flight; profiles/r06_ab_onepass_scan.txt, kernel in the history at commit f92d09a.)
 
 // ---- inclusive prefix sum of a base-field column (blockIdx.y selects the column) ----------------------
-constexpr int SCAN_ITEMS = 4, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;
+constexpr int SCAN_ITEMS = 4, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;  // (8 items per thread: 32-byte lane stride, slower — profiles/r06_ab_scan.txt)
 
+// exclusive scan of one value per thread over the workgroup; *total = the workgroup's sum
+#if defined(__HIPCC__) && !defined(HIPEMU_CHECKS)
+// device: inclusive scan inside the wave by shuffles, the four wave totals through LDS — two barriers (round 6; the LDS Hillis-Steele form below
+// spent 72 % of the scan kernels' wave cycles at its sixteen barriers: profiles/r06_pmc.json, k_scan_apply)
 __device__ __forceinline__ Fp block_exclusive_scan(Fp v, uint32_t* lds, Fp* total) {
-    // Hillis-Steele over blockDim.x values
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    Fp incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Fp t = Fp::raw((uint32_t)__shfl_up((int)incl.v, off, 64));
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) lds[wave] = incl.v;
+    __syncthreads();
+    Fp before = Fp::zero(), all = Fp::zero();
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        const Fp t = Fp::raw(lds[w]);
+        all += t;
+        if (w < wave) before += t;
+    }
+    __syncthreads();  // lds is reused by the caller's next scan
+    *total = all;
+    return before + incl - v;
+}
+#else
+// host emulation (tools/hipemu: no wave primitives): Hillis-Steele over blockDim.x values in LDS
+__device__ __forceinline__ Fp block_exclusive_scan(Fp v, uint32_t* lds, Fp* total) {
     lds[threadIdx.x] = v.v;
     __syncthreads();
     for (int off = 1; off < SCAN_THREADS; off <<= 1) {
@@ -162,14 +188,28 @@ __device__ __forceinline__ Fp block_exclusive_scan(Fp v, uint32_t* lds, Fp* tota
     __syncthreads();
     return incl - v;
 }
+#endif
 
+// a thread's SCAN_ITEMS consecutive elements: one 16-byte access where the column allows it (n a multiple of 4 and a 16-byte-aligned column), else word by word
+static_assert(SCAN_ITEMS == 4, "scan_load4 / k_scan_apply move four consecutive elements as one uint4");
+__device__ __forceinline__ void scan_load4(const uint32_t* col, uint64_t base, uint64_t n, bool vec, Fp (&v)[SCAN_ITEMS]) {
+    if (vec && base + 4 <= n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(col + base);
+        v[0] = Fp::raw(q.x); v[1] = Fp::raw(q.y); v[2] = Fp::raw(q.z); v[3] = Fp::raw(q.w);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) v[i] = base + i < n ? Fp::raw(col[base + i]) : Fp::zero();
+}
 // phase 1: block sums
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_block_sums(const uint32_t* __restrict__ data, uint64_t stride, uint64_t n, uint32_t* __restrict__ sums, uint64_t n_blocks) {
     __shared__ uint32_t lds[SCAN_THREADS];
     const uint32_t* col = data + (uint64_t)blockIdx.y * stride;
+    const bool vec = ((n | stride) & 3) == 0 && ((uintptr_t)data & 15) == 0;
     uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    Fp s = Fp::zero();
-    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += Fp::raw(col[base + i]);
+    Fp v[SCAN_ITEMS];
+    scan_load4(col, base, n, vec, v);
+    const Fp s = (v[0] + v[1]) + (v[2] + v[3]);
     Fp total;
     block_exclusive_scan(s, lds, &total);
     if (threadIdx.x == 0) sums[(uint64_t)blockIdx.y * n_blocks + blockIdx.x] = total.v;
@@ -192,15 +232,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(uint32_t* __restrict
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(uint32_t* __restrict__ data, uint64_t stride, uint64_t n, const uint32_t* __restrict__ sums, uint64_t n_blocks) {
     __shared__ uint32_t lds[SCAN_THREADS];
     uint32_t* col = data + (uint64_t)blockIdx.y * stride;
+    const bool vec = ((n | stride) & 3) == 0 && ((uintptr_t)data & 15) == 0;
     uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
     Fp v[SCAN_ITEMS];
-    Fp s = Fp::zero();
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = base + i < n ? Fp::raw(col[base + i]) : Fp::zero(); s += v[i]; }
+    scan_load4(col, base, n, vec, v);
+    const Fp s = (v[0] + v[1]) + (v[2] + v[3]);
     Fp total;
     Fp run = block_exclusive_scan(s, lds, &total) + Fp::raw(sums[(uint64_t)blockIdx.y * n_blocks + blockIdx.x]);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) { run += v[i]; if (base + i < n) col[base + i] = run.v; }
+    for (int i = 0; i < SCAN_ITEMS; i++) { run += v[i]; v[i] = run; }
+    if (vec && base + 4 <= n) { *reinterpret_cast<uint4*>(col + base) = make_uint4(v[0].v, v[1].v, v[2].v, v[3].v); return; }
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) col[base + i] = v[i].v;
 }
 
 // five base-field columns (one Ext5 column of a flattened trace) += a constant: the offset of a row range's running sum (sharded prover)
