@@ -287,3 +287,27 @@ def test_sharded_proof_over_contexts_on_different_devices(machine, rc, world, n)
         assert_oracle_proof(sharded.words, mt, prep, rc)
     rows = va.prove_sharded_rows_local(provers, mt, prep, log_min_sharded=10 if n == 582 else 12)  # the traces themselves in row ranges, one range per device
     assert_same_proof(rows.words, single.words)
+
+
+def test_local_fabric_staged_copies_give_the_same_proof():
+    """LocalFabric's fallback for device pairs WITHOUT a peer path (exchanges staged through page-locked host memory, csrc/host/fabric.hpp: copy_staged) cannot
+    occur on a 1-GPU box; the test-only hook VGPU_TESTING=1 VGPU_FAILPOINT=local_stage_copies@0 sends every exchange of a sharded proof through it.  In a
+    process of its own (the hook is read once): the sharded proof of fib(582) over four contexts must be the oracle's."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import hashlib, json, sys; sys.path.insert(0, %r); import valida_amd as va\n"
+            "g = json.load(open(%r)); w = va.Workload.fib(g['n']); mt, prep = w.main_traces(), w.preprocessed()\n"
+            "m, rc = va.Machine.basic(), va.poseidon_round_constants()\n"
+            "ps = [va.Prover(m, rc) for _ in range(4)]\n"
+            "pr = va.prove_sharded_local(ps, mt, prep, log_min_sharded=10)\n"
+            "print(json.dumps({'sha': hashlib.sha256(pr.bytes()).hexdigest()}))\n") % (root, os.path.join(root, "tests", "golden", "fib582_oracle.json"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VGPU_TESTING="1", VGPU_FAILPOINT="local_stage_copies@0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "test hook local_stage_copies" in r.stderr  # the staged path really ran
+    with open(os.path.join(root, "tests", "golden", "fib582_oracle.json")) as f:
+        g = json.load(f)
+    assert json.loads(r.stdout.strip().splitlines()[-1])["sha"] == g["proof_sha256"]

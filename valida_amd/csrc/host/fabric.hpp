@@ -49,7 +49,8 @@ struct FabricTransportFailure : std::runtime_error {
 
 // Test-only fault injection (documented in DESIGN.md §7): VGPU_FAILPOINT="<name>@<rank>" makes the named step throw on that rank, once
 // per process — honoured only together with VGPU_TESTING=1 (a second, explicit opt-in: a stray variable in a production environment must
-// not be able to fail proofs).  Names: fabric_stage (inside the all-to-all's staging, before the status round), fabric_finish (after the exchange).
+// not be able to fail proofs).  Names: fabric_stage (inside the all-to-all's staging, before the status round), fabric_finish (after the exchange);
+// local_stage_copies@0 does not throw: it sends the first LocalFabric's exchanges through the host-staged path (tests/test_sharded_prove_gpu.py).
 inline bool fabric_failpoint(const char* name, int rank) {
     static const std::string spec = [] {
         const char* t = getenv("VGPU_TESTING");
@@ -166,11 +167,14 @@ struct LocalFabric : Fabric {
     // through page-locked host memory, with one warning on stderr (a slow path that says so; one process per GPU, vgpu_prove_sharded, avoids it).
   private:
     bool peers_ready = false;
+    bool stage_all = false;  // test hook (VGPU_TESTING=1 VGPU_FAILPOINT=local_stage_copies@0): EVERY exchange of this fabric through the staged path — the one way a 1-GPU box can run it
     std::vector<std::pair<int, int>> staged_pairs;  // (reader device, owner device) without a peer path
     uint32_t* stage_host = nullptr;
     size_t stage_words = 0;
     void prepare_peers(const std::vector<A2A>& plan) {
         if (peers_ready) return;
+        stage_all = fabric_failpoint("local_stage_copies", 0);
+        if (stage_all) fprintf(stderr, "vgpu: fabric: test hook local_stage_copies: every exchange of this fabric is staged through host memory\n");
         std::vector<int> devs;
         for (auto& p : plan) if (std::find(devs.begin(), devs.end(), p.c->device) == devs.end()) devs.push_back(p.c->device);
         for (int dev : devs)
@@ -192,7 +196,7 @@ struct LocalFabric : Fabric {
         peers_ready = true;
     }
     bool staged(int reader, int owner) const {
-        return reader != owner && std::find(staged_pairs.begin(), staged_pairs.end(), std::make_pair(reader, owner)) != staged_pairs.end();
+        return stage_all || (reader != owner && std::find(staged_pairs.begin(), staged_pairs.end(), std::make_pair(reader, owner)) != staged_pairs.end());
     }
     void copy_staged(const std::vector<Seg>& from, int from_dev, const std::vector<Seg>& to, int to_dev) {
         if (from.size() != to.size()) throw std::logic_error("fabric: send / receive segment lists disagree");
