@@ -266,29 +266,6 @@ def test_device_proofs_pass_the_products_own_verifier(machine, rc, fib25):
         assert va.verify(machine, rc, bad, pc) is not None
 
 
-@pytest.mark.parametrize("world,n", [(2, 582), (2, 149794), (4, 582), (8, 149794)])
-def test_sharded_proof_over_contexts_on_different_devices(machine, rc, world, n):
-    """vgpu_prove_sharded_local with context r on DEVICE r: the LocalFabric's exchanges become cross-device copies (hipDeviceEnablePeerAccess /
-    hipMemcpyPeerAsync over xGMI, csrc/host/fabric.hpp) instead of copies inside one device.  Needs `world` devices: on the 1-GPU box this is
-    the skip that says the peer path has never executed (round-5 verdict, item 1)."""
-    import torch
-
-    have = torch.cuda.device_count()
-    if have < world:
-        pytest.skip("needs %d devices (one prover context per device); this box has %d: LocalFabric's cross-device copies and peer access have never run" % (world, have))
-    w = va.Workload.fib(n)
-    p0, mt, prep, single = single_and_inputs(machine, rc, w)
-    provers = [p0] + [va.Prover(machine, rc, device=r) for r in range(1, world)]
-    sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=10 if n == 582 else 12)
-    assert_same_proof(sharded.words, single.words)
-    if n == 149794:
-        assert_fixture(sharded, mt, "full_c2_fib149794.json")
-    else:
-        assert_oracle_proof(sharded.words, mt, prep, rc)
-    rows = va.prove_sharded_rows_local(provers, mt, prep, log_min_sharded=10 if n == 582 else 12)  # the traces themselves in row ranges, one range per device
-    assert_same_proof(rows.words, single.words)
-
-
 def test_local_fabric_staged_copies_give_the_same_proof():
     """LocalFabric's fallback for device pairs WITHOUT a peer path (exchanges staged through page-locked host memory, csrc/host/fabric.hpp: copy_staged) cannot
     occur on a 1-GPU box; the test-only hook VGPU_TESTING=1 VGPU_FAILPOINT=local_stage_copies@0 sends every exchange of a sharded proof through it.  In a

@@ -384,3 +384,39 @@ def test_rccl_fabric_one_rank_per_device(world):
     for rank in range(world):
         assert res[rank].get("allgather_ok") and res[rank].get("device") == rank, _describe(res)
     _assert_oracle_proof(res, world)
+
+
+# ---- one PROCESS, one prover context per DEVICE (vgpu_prove_sharded_local over LocalFabric's cross-device copies) --------------------------------------
+# Lives in this file, which sorts last, with the other tests only a multi-GPU box can run: a first-contact failure here must not cut the suite short under `-x`.
+import numpy as np  # noqa: E402
+
+import valida_amd as va  # noqa: E402
+from test_sharded_prove_gpu import assert_fixture, assert_oracle_proof, assert_same_proof  # noqa: E402
+
+
+@pytest.mark.parametrize("world,n", [(2, 582), (2, 149794), (4, 582), (8, 149794)])
+def test_sharded_proof_over_contexts_on_different_devices(world, n):
+    """vgpu_prove_sharded_local with context r on DEVICE r: the LocalFabric's exchanges become cross-device copies (hipDeviceEnablePeerAccess /
+    hipMemcpyPeerAsync over xGMI, csrc/host/fabric.hpp) instead of copies inside one device.  Needs `world` devices: on the 1-GPU box this is
+    the skip that says the peer path has never executed (round-5 verdict, item 1)."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < world:
+        pytest.skip("needs %d devices (one prover context per device); this box has %d: LocalFabric's cross-device copies and peer access have never run" % (world, have))
+    machine, rc = va.Machine.basic(), va.poseidon_round_constants()
+    w = va.Workload.fib(n)
+    mt, prep = w.main_traces(), w.preprocessed()
+    p0 = va.Prover(machine, rc)
+    single = p0.prove([p0.upload(m) for m in mt], [(c, p0.upload(m)) for c, m in prep])
+    provers = [p0] + [va.Prover(machine, rc, device=r) for r in range(1, world)]
+    sharded = va.prove_sharded_local(provers, mt, prep, log_min_sharded=10 if n == 582 else 12)
+    assert_same_proof(sharded.words, single.words)
+    if n == 149794:
+        assert_fixture(sharded, mt, "full_c2_fib149794.json")
+    else:
+        assert_oracle_proof(sharded.words, mt, prep, rc)
+    rows = va.prove_sharded_rows_local(provers, mt, prep, log_min_sharded=10 if n == 582 else 12)  # the traces themselves in row ranges, one range per device
+    assert_same_proof(rows.words, single.words)
+
+
