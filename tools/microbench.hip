@@ -371,6 +371,53 @@ static void copy_sweep() {
     CHECK(hipFree(a)); CHECK(hipFree(b));
 }
 
+// ---- many column streams a power of two apart (round 6): the reduced openings read every column of an LDE height in one pass — a workgroup takes 512 rows (2 KiB)
+// of each of S columns that lie `pitch` words apart, eight 8-byte loads per lane in flight — and stop at 2.2 TB/s whatever their instruction count, occupancy, load width,
+// column order or cache policy (profiles/r05_ab_reduce_rows.txt, r06_ab_reduce_openings_traversal.txt).  Is it the PATTERN?  The same reads with nothing else, for
+// pitch = 2^k rows exactly (the LDE layout) and for pitches padded by 64 / 2112 words.
+__global__ void __launch_bounds__(256) k_read_columns(const uint32_t* __restrict__ base, size_t pitch, int n_cols, uint32_t* __restrict__ sink) {
+    const size_t j0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const uint32_t* p = base + j0;
+    uint32_t acc = 0;
+    int c = 0;
+    for (; c + 8 <= n_cols; c += 8) {
+        uint2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const uint2*>(p + (size_t)(c + u) * pitch);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc ^= v[u].x ^ v[u].y;
+    }
+    for (; c < n_cols; c++) { const uint2 v = *reinterpret_cast<const uint2*>(p + (size_t)c * pitch); acc ^= v.x ^ v.y; }
+    if (acc == 0x12345678u) sink[threadIdx.x] = acc;
+}
+static void column_streams() {
+    const size_t max_words = (size_t)1 << 30;  // 4 GiB
+    uint32_t *a, *sink;
+    CHECK(hipMalloc(&a, max_words * 4 + (1 << 24))); CHECK(hipMalloc(&sink, 4096));
+    CHECK(hipMemset(a, 1, max_words * 4 + (1 << 24)));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    printf("column streams: S columns of `rows` rows, `pitch` words apart, each workgroup 512 rows of every column (8-byte loads, 8 in flight); best of 5 launches\n");
+    for (int log_rows : {21, 23})
+        for (int n_cols : {1, 8, 34, 142}) {
+            const size_t rows = (size_t)1 << log_rows;
+            if ((rows + 2112) * (size_t)n_cols > max_words) continue;
+            for (size_t pad : {(size_t)0, (size_t)64, (size_t)2112}) {
+                const size_t pitch = rows + pad;
+                float best = 1e30f;
+                for (int r = 0; r < 6; r++) {
+                    float ms;
+                    CHECK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(k_read_columns, dim3((unsigned)(rows / 512)), dim3(256), 0, 0, a, pitch, n_cols, sink);
+                    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (r && ms < best) best = ms;
+                }
+                printf("column_streams rows 2^%d  columns %3d  pitch rows+%-4zu  %.3f ms  %.2f TB/s\n", log_rows, n_cols, pad, best, (double)rows * n_cols * 4.0 / best / 1e9);
+            }
+        }
+    CHECK(hipFree(a)); CHECK(hipFree(sink));
+}
+
 int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
     hipDeviceProp_t prop;
@@ -468,5 +515,6 @@ int main(int argc, char** argv) {
     }
     if (!strcmp(what, "copies") || !strcmp(what, "all")) copy_rows();
     if (!strcmp(what, "copysweep") || !strcmp(what, "all")) copy_sweep();
+    if (!strcmp(what, "columns") || !strcmp(what, "all")) column_streams();
     return 0;
 }
