@@ -222,8 +222,25 @@ __device__ __forceinline__ Fp poseidon16_row(Fp st, const PoseidonTab& tab, cons
 // tree (one workgroup) carries the FRI challenger step as k_keccak_top does.  Layers group by log2(parents) / 5 (DeviceTree, host/pcs.hpp).
 constexpr uint64_t POSEIDON_ROW_MAX = 16384;
 constexpr int POSEIDON_LEVELS_PER_LAUNCH = 5, POSEIDON_LEVELS_ROWS = 16;
-__global__ void __launch_bounds__(256) k_poseidon_levels_row(KeccakTopArgs a, PoseidonTab tab) {
+#ifndef VGPU_POSEIDON_ROW_LDS
+#define VGPU_POSEIDON_ROW_LDS 1  // the row permutation's per-lane tables (full-round constants, sparse rounds, dense matrix: 1080 words) staged in LDS by the workgroup; 0: read through L1 / L2 (A/B builds)
+#endif
+constexpr int POPT_ROW_WORDS = POPT_F + 256;  // RC_FULL | T | SPARSE | F: contiguous at the head of the table image
+// call at the top of a kernel, by every thread of the workgroup, before any early return
+__device__ __forceinline__ PoseidonTab poseidon_row_tab_in_lds(const PoseidonTab& tab, uint32_t* s_row) {
+#if VGPU_POSEIDON_ROW_LDS
+    if (tab.opt == nullptr) return tab;
+    for (int i = (int)threadIdx.x; i < POPT_ROW_WORDS; i += (int)blockDim.x) s_row[i] = tab.opt[i];
+    __syncthreads();
+    return PoseidonTab{tab.rc, tab.mds, s_row};
+#else
+    return tab;
+#endif
+}
+__global__ void __launch_bounds__(256) k_poseidon_levels_row(KeccakTopArgs a, PoseidonTab gtab) {
     __shared__ uint32_t dig[2][POSEIDON_LEVELS_ROWS * 8];  // the digests a layer hands to the next one (double-buffered: one barrier per layer)
+    __shared__ uint32_t s_row[POPT_ROW_WORDS];
+    const PoseidonTab tab = poseidon_row_tab_in_lds(gtab, s_row);
     uint32_t m[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
@@ -280,7 +297,9 @@ static double p_row_perms(int n_elems) { return (double)((n_elems + 7) / 8); }
 static double p_node_perms(int n_inject) { return n_inject > 0 ? 2.0 + p_row_perms(n_inject) : 1.0; }
 // the bottom of a big tree at query time (merkle.hip, k_keccak_bottom_q: same job words).  32 lanes per job, the ROW permutation: lanes 0..15 hash row `node`
 // (level 0) or row 2 node (level 1), lanes 16..31 row 2 node + 1; at level 1 the first row then compresses its digest with the second one's.
-__global__ void __launch_bounds__(256) k_poseidon_bottom_q(const uint32_t* __restrict__ jobs, uint32_t n_jobs, const uint32_t* __restrict__ indices, PoseidonTab tab, uint32_t* __restrict__ dst) {
+__global__ void __launch_bounds__(256) k_poseidon_bottom_q(const uint32_t* __restrict__ jobs, uint32_t n_jobs, const uint32_t* __restrict__ indices, PoseidonTab gtab, uint32_t* __restrict__ dst) {
+    __shared__ uint32_t s_row[POPT_ROW_WORDS];
+    const PoseidonTab tab = poseidon_row_tab_in_lds(gtab, s_row);
     uint32_t m[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) m[i] = tab.mds[i];
