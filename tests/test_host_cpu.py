@@ -563,3 +563,20 @@ def test_build_says_what_it_did():
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")) as f:
         src = f.read()
     assert "build_vgpu(force=" in src and "compiled %d of %d sources" in src
+
+
+def test_bench_launcher_spawns_ranks_and_returns_the_first_failure():
+    """`python bench.py --gpus 2` without a launcher's WORLD_SIZE becomes the launcher itself (round-5 verdict, item 1).  Without a GPU its two ranks refuse to run
+    ("the product path has no CPU fallback"); the launcher must come back with their status, name the rank, and print no JSON line."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run (tests/test_gpu_parity.py covers that form)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stderr[-500:])
+    assert r.stderr.count("bench.py needs a HIP device") == 2 and "ended with status 1; ending the other ranks" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
